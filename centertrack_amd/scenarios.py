@@ -1,0 +1,230 @@
+"""Seeded synthetic workloads shared by the golden generator, the parity tests and
+bench.py: head maps for decode, detection lists for post-process / tracker, and the
+end-to-end stream configs of BASELINE.json.  Pure numpy/torch CPU
+generators; MT19937 / torch CPU generators are stable across machines, so the same seed
+reproduces the same inputs on the GPU box."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+from . import weights as W
+
+HEAD_SETS = {'mot': W.MOT_HEADS, 'kitti': W.KITTI_HEADS, 'coco': W.COCO_HEADS, 'nusc': W.NUSC_HEADS}
+
+# BASELINE.json configs -> (head set, input H, input W, streams/batch, flip_test, track_thresh)
+CONFIGS = OrderedDict([
+    ('mot17_512', dict(heads='mot', H=512, W=512, B=1, flip=False, track_thresh=0.4, pre_thresh=0.5)),
+    ('kitti_1280x384', dict(heads='kitti', H=384, W=1280, B=4, flip=True, track_thresh=0.4, pre_thresh=0.4)),
+    ('coco_512', dict(heads='coco', H=512, W=512, B=32, flip=False, track_thresh=0.3, pre_thresh=0.3)),
+    ('nusc_800x448', dict(heads='nusc', H=448, W=800, B=16, flip=False, track_thresh=0.1, pre_thresh=0.1)),
+])
+
+
+# ----------------------------------------------------------------------------- decode
+def decode_cases():
+    return [
+        dict(name='mot_32x40', heads=W.MOT_HEADS, B=1, h=32, w=40, K=100, seed=1),
+        dict(name='kitti_24x80', heads=W.KITTI_HEADS, B=2, h=24, w=80, K=100, seed=2),
+        dict(name='coco_16x16', heads=W.COCO_HEADS, B=1, h=16, w=16, K=100, seed=3),
+        dict(name='nusc_28x50', heads=W.NUSC_HEADS, B=3, h=28, w=50, K=64, seed=4),
+        dict(name='mot_128x128', heads=W.MOT_HEADS, B=1, h=128, w=128, K=100, seed=5),
+    ]
+
+
+def make_head_maps(case):
+    """Post-``_sigmoid_output`` head maps: hm in (0,1) with distinct values (smooth bumps +
+    noise so that the 3x3 NMS keeps ~10 % of the pixels), regression heads ~ N(0,s)."""
+    g = torch.Generator().manual_seed(1000 + case['seed'])
+    B, h, w = case['B'], case['h'], case['w']
+    out = OrderedDict()
+    for name, c in case['heads'].items():
+        if name == 'hm':
+            v = torch.rand((B, c, h, w), generator=g, dtype=torch.float64)
+            out[name] = (v ** 2 * 0.98 + 0.001).float()
+        elif name == 'reg':
+            out[name] = torch.rand((B, c, h, w), generator=g, dtype=torch.float64).float()
+        elif name == 'wh':
+            out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 4 + 3).float()
+        elif name == 'dep':
+            out[name] = (torch.rand((B, c, h, w), generator=g, dtype=torch.float64) * 60 + 1).float()
+        else:
+            out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 2).float()
+    return out
+
+
+# ----------------------------------------------------------------------- post-process
+def _sorted_dets(rs, K, F_extra, n_above, thresh):
+    scores = np.sort(rs.uniform(0.0, 1.0, size=K).astype(np.float32))[::-1].copy()
+    scores[:n_above] = np.maximum(scores[:n_above], thresh + 0.01)
+    scores[n_above:] = np.minimum(scores[n_above:], thresh - 0.01)
+    scores = np.sort(scores)[::-1].copy()
+    d = {'scores': scores[None]}
+    for k, f in F_extra.items():
+        d[k] = f(rs, K)[None]
+    return d
+
+
+def postprocess_cases():
+    cases = []
+    rs = np.random.RandomState(11)
+    K = 40
+    ext2d = {
+        'clses': lambda r, k: r.randint(0, 3, size=k).astype(np.float32),
+        'cts': lambda r, k: r.uniform(0, 100, size=(k, 2)).astype(np.float32),
+        'tracking': lambda r, k: r.normal(0, 3, size=(k, 2)).astype(np.float32),
+        'bboxes': lambda r, k: np.sort(r.uniform(0, 100, size=(k, 2, 2)), axis=1).reshape(k, 4).astype(np.float32),
+    }
+    cases.append(dict(name='mot2d', out_thresh=0.4, num_classes=3, h=96, w=128,
+                      c=np.array([640., 360.], np.float32), s=1280.0, height=720, width=1280,
+                      calib=np.array([[1200., 0, 640, 0], [0, 1200., 360, 0], [0, 0, 1, 0]], np.float32),
+                      dets=_sorted_dets(rs, K, ext2d, 17, 0.4)))
+    ext3d = dict(ext2d)
+    ext3d.update({
+        'dep': lambda r, k: r.uniform(2, 60, size=(k, 1)).astype(np.float32),
+        'rot': lambda r, k: r.normal(0, 1, size=(k, 8)).astype(np.float32),
+        'dim': lambda r, k: r.uniform(0.5, 4, size=(k, 3)).astype(np.float32),
+        'amodel_offset': lambda r, k: r.normal(0, 1, size=(k, 2)).astype(np.float32),
+    })
+    cases.append(dict(name='nusc3d', out_thresh=0.1, num_classes=10, h=112, w=200,
+                      c=np.array([800., 450.], np.float32), s=1600.0, height=900, width=1600,
+                      calib=np.array([[1266.4, 0, 816.3, 0], [0, 1266.4, 491.5, 0], [0, 0, 1, 0]], np.float32),
+                      dets=_sorted_dets(rs, K, ext3d, 25, 0.1)))
+    # s given as an array (keep_res path, detector.py:195-199)
+    cases.append(dict(name='keepres', out_thresh=0.3, num_classes=1, h=96, w=320,
+                      c=np.array([620., 187.], np.float32), s=np.array([1280., 384.], np.float32),
+                      height=375, width=1242,
+                      calib=np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2], [0, 0, 1, 0.003]], np.float32),
+                      dets=_sorted_dets(rs, K, ext2d, 9, 0.3)))
+    return cases
+
+
+# ---------------------------------------------------------------------------- tracker
+def _det(score, cls, ct, tracking, size):
+    ct = [float(ct[0]), float(ct[1])]
+    half = size / 2.0
+    return {'score': float(score), 'class': int(cls), 'ct': ct,
+            'tracking': [float(tracking[0]), float(tracking[1])],
+            'bbox': [ct[0] - half, ct[1] - half, ct[0] + half, ct[1] + half]}
+
+
+def tracker_sequences():
+    seqs = []
+    base = dict(new_thresh=0.4, max_age=-1, hungarian=False, public_det=False)
+    # A: three objects moving +8 px/frame; tracking points back by -8; births and deaths
+    frames = []
+    for t in range(5):
+        dets = []
+        for i, (x0, y0, sc) in enumerate([(100, 100, 0.9), (300, 120, 0.8), (200, 300, 0.7)]):
+            if i == 1 and t >= 3:
+                continue                                     # object 1 leaves at t=3
+            dets.append(_det(sc - 0.01 * t, 1, (x0 + 8 * t, y0 + 2 * t), (-8, -2), 40))
+        if t >= 2:
+            dets.append(_det(0.95, 1, (500 + 8 * t, 400), (-8, 0), 50))   # born at t=2, top score
+        dets.sort(key=lambda d: -d['score'])
+        frames.append({'dets': dets})
+    seqs.append(dict(name='basic', opt=base, frames=frames))
+    # B: gating -- far jump, class change, low score, size gate by track vs item
+    frames = [
+        {'dets': [_det(0.9, 1, (100, 100), (0, 0), 30), _det(0.8, 2, (200, 100), (0, 0), 30),
+                  _det(0.7, 1, (300, 100), (0, 0), 8), _det(0.35, 1, (400, 100), (0, 0), 30)]},
+        {'dets': [_det(0.9, 1, (160, 100), (0, 0), 30),     # jumped 60 px  -> new id
+                  _det(0.8, 1, (200, 100), (0, 0), 30),     # class changed -> new id
+                  _det(0.7, 1, (307, 100), (0, 0), 30),     # 49 > track size 64? no: 49<64 & <900
+                  _det(0.6, 1, (400, 100), (0, 0), 30)]},   # previous was below new_thresh
+        {'dets': [_det(0.9, 1, (163, 104), (0, 0), 4),      # dist 25 > item size 16 -> new id
+                  _det(0.5, 1, (200, 100), (0, 0), 30)]},
+    ]
+    seqs.append(dict(name='gating', opt=base, frames=frames))
+    # C: max_age keeps an unmatched track alive
+    opt_c = dict(base, max_age=2)
+    frames = [{'dets': [_det(0.9, 1, (100, 100), (0, 0), 40), _det(0.8, 1, (300, 100), (0, 0), 40)]},
+              {'dets': [_det(0.9, 1, (102, 100), (-2, 0), 40)]},
+              {'dets': [_det(0.9, 1, (104, 100), (-2, 0), 40), _det(0.8, 1, (301, 100), (-1, 0), 40)]},
+              {'dets': []},
+              {'dets': [_det(0.8, 1, (302, 100), (-1, 0), 40)]},
+              {'dets': [_det(0.8, 1, (303, 100), (-1, 0), 40)]}]
+    seqs.append(dict(name='max_age', opt=opt_c, frames=frames))
+    # D: greedy vs Hungarian differ when the best det of a track is taken first
+    frames = [{'dets': [_det(0.9, 1, (100, 100), (0, 0), 60), _det(0.8, 1, (120, 100), (0, 0), 60)]},
+              {'dets': [_det(0.9, 1, (112, 100), (0, 0), 60), _det(0.8, 1, (131, 100), (0, 0), 60)]},
+              {'dets': [_det(0.9, 1, (125, 100), (0, 0), 60), _det(0.8, 1, (140, 100), (0, 0), 60)]}]
+    seqs.append(dict(name='greedy_cross', opt=base, frames=frames))
+    seqs.append(dict(name='hungarian_cross', opt=dict(base, hungarian=True), frames=frames))
+    # E: public detection mode (tracker.py:83-101)
+    frames = [{'dets': [_det(0.9, 1, (100, 100), (0, 0), 40), _det(0.8, 1, (300, 100), (0, 0), 40)],
+               'public_det': [{'ct': [101., 101.]}, {'ct': [500., 500.]}]},
+              {'dets': [_det(0.9, 1, (102, 100), (-2, 0), 40), _det(0.85, 1, (300, 102), (0, -2), 40),
+                        _det(0.7, 1, (400, 300), (0, 0), 40)],
+               'public_det': [{'ct': [299., 101.]}, {'ct': [402., 301.]}]}]
+    seqs.append(dict(name='public_det', opt=dict(base, public_det=True), frames=frames))
+    # F: random stress, many dets, random motion, three classes, inherited init tracks
+    rs = np.random.RandomState(7)
+    objs = [dict(p=rs.uniform(50, 900, 2), v=rs.normal(0, 6, 2), c=int(rs.randint(1, 4)),
+                 s=float(rs.uniform(15, 80))) for _ in range(40)]
+    frames = []
+    for t in range(8):
+        dets = []
+        for o in objs:
+            if rs.uniform() < 0.1:
+                continue
+            o['p'] = o['p'] + o['v']
+            noise = rs.normal(0, 2.0, 2)
+            dets.append(_det(float(np.float32(rs.uniform(0.2, 1.0))), o['c'], np.float32(o['p']),
+                             np.float32(-o['v'] + noise), o['s']))
+        dets.sort(key=lambda d: -d['score'])
+        frames.append({'dets': dets})
+    pre = [dict(_det(0.9, 1, (60, 60), (0, 0), 30)), dict(_det(0.3, 2, (90, 90), (0, 0), 30))]
+    for p in pre:
+        del p['ct']                                           # init_track derives ct from bbox
+    seqs.append(dict(name='random', opt=base, frames=frames, pre_dets=pre))
+    seqs.append(dict(name='random_hungarian', opt=dict(base, hungarian=True, max_age=3), frames=frames))
+    return seqs
+
+
+# ----------------------------------------------------------------------------- pre-hm
+def pre_hm_cases():
+    from .image import make_meta
+    cases = []
+    rs = np.random.RandomState(5)
+    for name, (ih, iw, oh, ow), flip in [('mot', (720, 1280, 512, 512), False),
+                                        ('kitti', (375, 1242, 384, 1280), True),
+                                        ('small', (96, 128, 96, 128), False)]:
+        meta = make_meta(oh, ow, ih, iw, down_ratio=4)
+        tracks = []
+        for i in range(12):
+            cx, cy = rs.uniform(-20, iw + 20), rs.uniform(-20, ih + 20)
+            bw, bh = rs.uniform(2, iw / 3), rs.uniform(2, ih / 3)
+            tracks.append({'score': float(rs.uniform(0.2, 1.0)), 'active': int(rs.randint(0, 3)),
+                           'bbox': np.array([cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2], np.float32)})
+        cases.append(dict(name=name, meta=meta, tracks=tracks, pre_thresh=0.5, flip_test=flip))
+    return cases
+
+
+# -------------------------------------------------------------------------------- e2e
+def e2e_config():
+    return dict(heads=W.MOT_HEADS, H=128, W=160, T=4, seed=317, hm_gain=14.0,
+                orig_h=360, orig_w=480,
+                ref_args=['--pre_hm', '--ltrb_amodal', '--track_thresh', '0.4', '--pre_thresh', '0.5'],
+                track_thresh=0.4, pre_thresh=0.5)
+
+
+def e2e_state_dict(cfg):
+    """Synthetic weights of the e2e stream: hm output layer scaled so scores spread over
+    (0,1), and the amodal-box head biased to ~6x6-cell boxes so the tracker's size gate
+    (dist^2 < box area, tracker.py:47-48) lets consecutive frames associate."""
+    sd = W.make_synthetic_state_dict(cfg['heads'], seed=cfg['seed'], hm_gain=cfg['hm_gain'])
+    sd['ltrb_amodal.2.bias'] = torch.tensor([-3.0, -3.0, 3.0, 3.0])
+    return sd
+
+
+def e2e_frames(cfg):
+    """T frames of one synthetic stream: a fixed N(0,1) image scrolled by 4 input px/frame
+    (so detections drift by one output cell) + the per-frame ``meta`` of pre_process."""
+    from .image import make_meta
+    g = torch.Generator().manual_seed(cfg['seed'] + 7)
+    base = torch.randn((3, cfg['H'], cfg['W'] + 4 * cfg['T']), generator=g, dtype=torch.float64).float()
+    meta = make_meta(cfg['H'], cfg['W'], cfg['orig_h'], cfg['orig_w'], down_ratio=4)
+    for t in range(cfg['T']):
+        img = base[:, :, 4 * t:4 * t + cfg['W']].contiguous().unsqueeze(0)
+        yield img, dict(meta)

@@ -1,0 +1,100 @@
+"""Oracle: heat-map decode on CPU (torch).  TEST INFRASTRUCTURE ONLY.
+
+Restates ``src/lib/model/utils.py`` (_nms :52-58, _topk :71-87, _gather_feat
+:16-20, _tranpose_and_gather_feat :22-26) and ``src/lib/model/decode.py``
+(generic_decode :83-182, non-pose branches).  Pinned against the imported
+reference by tests/golden/make_golden.py.
+"""
+import torch
+import torch.nn.functional as F
+
+REGRESSION_HEADS = ['tracking', 'dep', 'rot', 'dim', 'amodel_offset',
+                    'nuscenes_att', 'velocity']          # decode.py:142-143
+
+
+def nms(heat, kernel=3):
+    """utils.py:52-58 : keep = (maxpool3x3(heat) == heat)"""
+    hmax = F.max_pool2d(heat, (kernel, kernel), stride=1, padding=(kernel - 1) // 2)
+    return heat * (hmax == heat).float()
+
+
+def gather_feat(feat, ind):
+    """utils.py:16-20 : feat [B,N,F], ind [B,K] -> [B,K,F]"""
+    ind = ind.unsqueeze(2).expand(ind.size(0), ind.size(1), feat.size(2))
+    return feat.gather(1, ind)
+
+
+def transpose_and_gather_feat(feat, ind):
+    """utils.py:22-26 : NCHW -> [B,HW,C] -> gather rows"""
+    feat = feat.permute(0, 2, 3, 1).contiguous()
+    feat = feat.view(feat.size(0), -1, feat.size(3))
+    return gather_feat(feat, ind)
+
+
+def topk(scores, K=100):
+    """utils.py:71-87 : per-class top-K over H*W, then top-K over C*K."""
+    batch, cat, height, width = scores.size()
+    topk_scores, topk_inds = torch.topk(scores.view(batch, cat, -1), K)
+    topk_inds = topk_inds % (height * width)
+    topk_ys = (topk_inds / width).int().float()       # true division + truncation (:77)
+    topk_xs = (topk_inds % width).int().float()
+    topk_score, topk_ind = torch.topk(topk_scores.view(batch, -1), K)
+    topk_clses = (topk_ind / K).int()
+    topk_inds = gather_feat(topk_inds.view(batch, -1, 1), topk_ind).view(batch, K)
+    topk_ys = gather_feat(topk_ys.view(batch, -1, 1), topk_ind).view(batch, K)
+    topk_xs = gather_feat(topk_xs.view(batch, -1, 1), topk_ind).view(batch, K)
+    return topk_score, topk_inds, topk_clses, topk_ys, topk_xs
+
+
+def generic_decode(output, K=100, zero_tracking=False, return_inds=False):
+    """decode.py:83-182 without the pose (hps) branch.  ``output`` maps head name ->
+    [B,c,h,w]; 'hm' must already be sigmoid-ed (detector.py:300-308)."""
+    if 'hm' not in output:
+        return {}
+    if zero_tracking:
+        output['tracking'] *= 0
+    heat = output['hm']
+    batch, cat, height, width = heat.size()
+    heat = nms(heat)
+    scores, inds, clses, ys0, xs0 = topk(heat, K=K)
+    clses = clses.view(batch, K)
+    scores = scores.view(batch, K)
+    cts = torch.cat([xs0.unsqueeze(2), ys0.unsqueeze(2)], dim=2)
+    ret = {'scores': scores, 'clses': clses.float(), 'xs': xs0, 'ys': ys0, 'cts': cts}
+    if 'reg' in output:
+        reg = transpose_and_gather_feat(output['reg'], inds).view(batch, K, 2)
+        xs = xs0.view(batch, K, 1) + reg[:, :, 0:1]
+        ys = ys0.view(batch, K, 1) + reg[:, :, 1:2]
+    else:
+        xs = xs0.view(batch, K, 1) + 0.5
+        ys = ys0.view(batch, K, 1) + 0.5
+    if 'wh' in output:
+        wh = transpose_and_gather_feat(output['wh'], inds).view(batch, K, 2)
+        wh[wh < 0] = 0                                                     # decode.py:117
+        ret['bboxes'] = torch.cat([xs - wh[..., 0:1] / 2, ys - wh[..., 1:2] / 2,
+                                   xs + wh[..., 0:1] / 2, ys + wh[..., 1:2] / 2], dim=2)
+    if 'ltrb' in output:
+        ltrb = transpose_and_gather_feat(output['ltrb'], inds).view(batch, K, 4)
+        ret['bboxes'] = torch.cat([xs0.view(batch, K, 1) + ltrb[..., 0:1],
+                                   ys0.view(batch, K, 1) + ltrb[..., 1:2],
+                                   xs0.view(batch, K, 1) + ltrb[..., 2:3],
+                                   ys0.view(batch, K, 1) + ltrb[..., 3:4]], dim=2)
+    for head in REGRESSION_HEADS:
+        if head in output:
+            ret[head] = transpose_and_gather_feat(output[head], inds).view(batch, K, -1)
+    if 'ltrb_amodal' in output:
+        la = transpose_and_gather_feat(output['ltrb_amodal'], inds).view(batch, K, 4)
+        amodal = torch.cat([xs0.view(batch, K, 1) + la[..., 0:1],
+                            ys0.view(batch, K, 1) + la[..., 1:2],
+                            xs0.view(batch, K, 1) + la[..., 2:3],
+                            ys0.view(batch, K, 1) + la[..., 3:4]], dim=2)
+        ret['bboxes_amodal'] = amodal
+        ret['bboxes'] = amodal                                             # decode.py:159
+    if output.get('pre_inds', None) is not None:
+        pre_inds = output['pre_inds']
+        pre_ys = (pre_inds / width).int().float()
+        pre_xs = (pre_inds % width).int().float()
+        ret['pre_cts'] = torch.cat([pre_xs.unsqueeze(2), pre_ys.unsqueeze(2)], dim=2)
+    if return_inds:
+        ret['inds'] = inds
+    return ret

@@ -1,0 +1,84 @@
+"""CPU: known-answer tests of the DCNv2 oracle (parity unpinned -> anchored on KATs and on
+two independent restatements agreeing).  SURVEY.md section 8c KAT-1..4."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import dcn_v2 as odcn
+from oracle import dcn_v2_c
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(shape, generator=g, dtype=torch.float64).float() * scale
+
+
+def test_kat1_zero_offset_is_conv2d():
+    x, w, b = _rand(2, 5, 9, 11, seed=1), _rand(7, 5, 3, 3, seed=2), _rand(7, seed=3)
+    off = torch.zeros(2, 18, 9, 11)
+    mask = torch.ones(2, 9, 9, 11)
+    y = odcn.dcn_v2_conv(x, off, mask, w, b)
+    np.testing.assert_allclose(y.numpy(), F.conv2d(x, w, b, padding=1).numpy(), atol=1e-5)
+    yc = dcn_v2_c.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy())
+    np.testing.assert_allclose(yc, y.numpy(), atol=1e-5)
+
+
+@pytest.mark.parametrize('dy,dx', [(1, 0), (0, -2), (-1, 3), (2, 2)])
+def test_kat2_integer_offset_is_shifted_conv(dy, dx):
+    x, w = _rand(1, 3, 8, 10, seed=4), _rand(4, 3, 3, 3, seed=5)
+    off = torch.zeros(1, 18, 8, 10)
+    off[:, 0::2] = dy
+    off[:, 1::2] = dx
+    mask = torch.ones(1, 9, 8, 10)
+    y = odcn.dcn_v2_conv(x, off, mask, w, None)
+    p = 4
+    xp = F.pad(x, (p, p, p, p))
+    full = F.conv2d(xp, w)                      # 'valid' conv over the zero-extended plane
+    ref = full[:, :, p - 1 + dy:p - 1 + dy + 8, p - 1 + dx:p - 1 + dx + 10]
+    np.testing.assert_allclose(y.numpy(), ref.numpy(), atol=1e-5)
+
+
+def test_kat3_zero_mask_gives_bias():
+    x, w, b = _rand(1, 4, 6, 6, seed=6), _rand(3, 4, 3, 3, seed=7), _rand(3, seed=8)
+    y = odcn.dcn_v2_conv(x, _rand(1, 18, 6, 6, seed=9), torch.zeros(1, 9, 6, 6), w, b)
+    np.testing.assert_allclose(y.numpy(), b.view(1, 3, 1, 1).expand(1, 3, 6, 6).numpy(), atol=1e-6)
+
+
+def test_kat4_out_of_range_and_partial_taps():
+    x = torch.ones(1, 1, 4, 4)
+    w = torch.zeros(1, 1, 3, 3)
+    w[0, 0, 1, 1] = 1.0                         # centre tap only (k = 4)
+    mask = torch.ones(1, 9, 4, 4)
+    off = torch.zeros(1, 18, 4, 4)
+    off[0, 8, 0, 0] = -1.0                      # y = -1  -> exactly outside -> 0
+    off[0, 8, 0, 1] = -0.25                     # y = -0.25 -> 0.75 * in[0] + 0.25 * 0
+    off[0, 9, 0, 2] = 1.5                       # x = 3.5 -> 0.5 * in[3] + 0.5 * 0 (corner outside)
+    off[0, 9, 0, 3] = 1.0                       # x = 4.0 = W -> outside -> 0
+    y = odcn.dcn_v2_conv(x, off, mask, w, None)
+    np.testing.assert_allclose(y[0, 0, 0].numpy(), [0.0, 0.75, 0.5, 0.0], atol=1e-6)
+    yc = dcn_v2_c.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), None)
+    np.testing.assert_allclose(yc[0, 0, 0], [0.0, 0.75, 0.5, 0.0], atol=1e-6)
+
+
+@pytest.mark.parametrize('scale', [0.5, 3.0])
+def test_two_restatements_agree_random(scale):
+    x, w, b = _rand(2, 6, 10, 13, seed=10), _rand(5, 6, 3, 3, seed=11), _rand(5, seed=12)
+    off = _rand(2, 18, 10, 13, seed=13, scale=scale)
+    mask = torch.sigmoid(_rand(2, 9, 10, 13, seed=14))
+    y = odcn.dcn_v2_conv(x, off, mask, w, b)
+    yc = dcn_v2_c.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy())
+    np.testing.assert_allclose(yc, y.numpy(), rtol=1e-4, atol=2e-5)
+    y64 = odcn.dcn_v2_conv(x.double(), off.double(), mask.double(), w.double(), b.double())
+    np.testing.assert_allclose(y.numpy(), y64.numpy(), rtol=1e-4, atol=2e-5)
+
+
+def test_dcn_module_matches_functional():
+    m = odcn.DCN(4, 6, (3, 3), 1, 1)
+    m.conv_offset_mask.weight.data.normal_(0, 0.1)
+    x = _rand(1, 4, 7, 7, seed=15)
+    with torch.no_grad():
+        y = m(x)
+        om = F.conv2d(x, m.conv_offset_mask.weight, m.conv_offset_mask.bias, padding=1)
+        y2 = odcn.dcn_v2_conv(x, om[:, :18], torch.sigmoid(om[:, 18:]), m.weight, m.bias)
+    np.testing.assert_allclose(y.numpy(), y2.numpy(), atol=1e-6)
