@@ -1,0 +1,117 @@
+"""ctypes binding of libcentertrack_hip.so (the C ABI of include/centertrack_hip.h).
+
+No torch types cross the boundary: tensors are passed as raw device pointers
+(``tensor.data_ptr()``) plus sizes, and the HIP stream as ``void*``.  There is NO CPU
+fallback: if the shared library is missing or a call fails this raises."""
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, 'libcentertrack_hip.so')
+
+c_float_p = ctypes.c_void_p      # device pointers are opaque to the host
+NUM_HEADS = 11
+(HEAD_REG, HEAD_WH, HEAD_TRACKING, HEAD_LTRB, HEAD_LTRB_AMODAL, HEAD_DEP, HEAD_ROT, HEAD_DIM,
+ HEAD_AMODEL_OFFSET, HEAD_NUSCENES_ATT, HEAD_VELOCITY) = range(NUM_HEADS)
+HEAD_INDEX = {'reg': HEAD_REG, 'wh': HEAD_WH, 'tracking': HEAD_TRACKING, 'ltrb': HEAD_LTRB,
+              'ltrb_amodal': HEAD_LTRB_AMODAL, 'dep': HEAD_DEP, 'rot': HEAD_ROT, 'dim': HEAD_DIM,
+              'amodel_offset': HEAD_AMODEL_OFFSET, 'nuscenes_att': HEAD_NUSCENES_ATT,
+              'velocity': HEAD_VELOCITY}
+HEAD_CH = {'reg': 2, 'wh': 2, 'tracking': 2, 'ltrb': 4, 'ltrb_amodal': 4, 'dep': 1, 'rot': 8, 'dim': 3,
+           'amodel_offset': 2, 'nuscenes_att': 8, 'velocity': 3}
+
+CT_RELU = 1
+CT_OUT_NCHW = 2
+
+
+class ConvDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int),
+                ('Cin', ctypes.c_int), ('ldx', ctypes.c_int),
+                ('w_packed', ctypes.c_void_p), ('Cout', ctypes.c_int), ('ks', ctypes.c_int),
+                ('stride', ctypes.c_int),
+                ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p),
+                ('res', ctypes.c_void_p), ('ldr', ctypes.c_int),
+                ('y', ctypes.c_void_p), ('ldy', ctypes.c_int),
+                ('flags', ctypes.c_int),
+                ('sig_lo', ctypes.c_int), ('sig_hi', ctypes.c_int),
+                ('dep_lo', ctypes.c_int), ('dep_hi', ctypes.c_int), ('depth_scale', ctypes.c_float),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
+                ('split_k', ctypes.c_int)]
+
+
+class DcnDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int),
+                ('Cin', ctypes.c_int), ('ldx', ctypes.c_int),
+                ('om', ctypes.c_void_p), ('ldom', ctypes.c_int),
+                ('w_packed', ctypes.c_void_p), ('Cout', ctypes.c_int),
+                ('scale', ctypes.c_void_p), ('shift', ctypes.c_void_p),
+                ('y', ctypes.c_void_p), ('ldy', ctypes.c_int),
+                ('flags', ctypes.c_int),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
+                ('split_k', ctypes.c_int)]
+
+
+class DecodeDesc(ctypes.Structure):
+    _fields_ = [('hm', ctypes.c_void_p), ('B', ctypes.c_int), ('C', ctypes.c_int), ('h', ctypes.c_int),
+                ('w', ctypes.c_int), ('K', ctypes.c_int),
+                ('heads', ctypes.c_void_p * NUM_HEADS),
+                ('out', ctypes.c_void_p), ('inds', ctypes.c_void_p),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+
+
+EXPORTS = ['ct_last_error', 'ct_version', 'ct_packed_weight_elems', 'ct_pack_conv_weight', 'ct_conv2d',
+           'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_stem_forward',
+           'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
+           'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode']
+
+_lib = None
+
+
+class CTError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the HIP library (once).  Raises if it has not been built: the product path
+    never falls back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise CTError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                      '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    i, p, sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
+    lib.ct_last_error.restype = ctypes.c_char_p
+    lib.ct_version.restype = i
+    lib.ct_packed_weight_elems.restype = sz
+    lib.ct_packed_weight_elems.argtypes = [i, i, i]
+    lib.ct_pack_conv_weight.argtypes = [p, p, i, i, i, p]
+    lib.ct_conv2d.argtypes = [ctypes.POINTER(ConvDesc), p]
+    lib.ct_conv2d_workspace_bytes.restype = sz
+    lib.ct_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.ct_dcn_v2.argtypes = [ctypes.POINTER(DcnDesc), p]
+    lib.ct_dcn_v2_workspace_bytes.restype = sz
+    lib.ct_dcn_v2_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
+    lib.ct_stem_forward.argtypes = [p, p, p, i, i, i, p, p, p, p, p, p, i, p]
+    lib.ct_maxpool2x2.argtypes = [p, i, i, i, i, i, p, i, p]
+    lib.ct_upsample_add.argtypes = [p, i, i, i, i, i, p, i, p, i, p, i, p]
+    lib.ct_nchw_to_nhwc.argtypes = [p, i, i, i, i, p, i, p]
+    lib.ct_nhwc_to_nchw.argtypes = [p, i, i, i, i, i, p, p]
+    lib.ct_decode_row_floats.argtypes = [ctypes.POINTER(DecodeDesc)]
+    lib.ct_decode_workspace_bytes.restype = sz
+    lib.ct_decode_workspace_bytes.argtypes = [ctypes.POINTER(DecodeDesc)]
+    lib.ct_decode.argtypes = [ctypes.POINTER(DecodeDesc), p]
+    _lib = lib
+    return lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        raise CTError('%s failed (code %d): %s' % (what or 'libcentertrack_hip call', rc,
+                                                  load().ct_last_error().decode()))
+
+
+def stream_ptr():
+    import torch
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)

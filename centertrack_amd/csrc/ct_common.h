@@ -1,0 +1,92 @@
+// Shared device/host helpers of libcentertrack_hip (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "centertrack_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+void ct_set_error(const char *fmt, ...);
+
+#define CT_FAIL_ARG(...)            \
+    do {                            \
+        ct_set_error(__VA_ARGS__);  \
+        return CT_ERR_ARG;          \
+    } while (0)
+
+#define CT_CHECK_LAUNCH(name)                                              \
+    do {                                                                   \
+        hipError_t e__ = hipGetLastError();                                \
+        if (e__ != hipSuccess) {                                           \
+            ct_set_error("%s: launch failed: %s", name, hipGetErrorString(e__)); \
+            return CT_ERR_LAUNCH;                                          \
+        }                                                                  \
+    } while (0)
+
+static inline int ct_cdiv(int a, int b) { return (a + b - 1) / b; }
+
+// Epilogue description shared by the conv / dcn / split-K-reduce kernels.
+struct EpiArgs {
+    const float *scale;   // [>=Cout] or nullptr
+    const float *shift;   // [>=Cout] or nullptr
+    const float *res;     // NHWC residual view or nullptr
+    float *y;
+    int ldr, ldy;
+    int Cout;
+    int Ho, Wo;           // output grid (per image)
+    int flags;
+    int sig_lo, sig_hi, dep_lo, dep_hi;
+    float depth_scale;
+};
+
+__device__ __forceinline__ float ct_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+// Apply scale/shift/residual/activation to one accumulator value of channel `co`.
+__device__ __forceinline__ float ct_epilogue_value(const EpiArgs &e, float v, int co, float sc, float sh,
+                                                   float r)
+{
+    v = v * sc + sh + r;
+    if (e.flags & CT_RELU) v = fmaxf(v, 0.0f);
+    if (co >= e.sig_lo && co < e.sig_hi) v = 1.0f / (1.0f + expf(-v));
+    if (co >= e.dep_lo && co < e.dep_hi) v = (1.0f / (1.0f / (1.0f + expf(-v)) + 1e-6f) - 1.0f) * e.depth_scale;
+    return v;
+}
+
+// Store the 16x16 MFMA tile `acc` (C/D layout: col = lane&15, row = (lane>>4)*4 + e) whose
+// rows are the 16 consecutive output pixels (n, oy, ox0..ox0+15) and whose columns are the
+// couts co0..co0+15.
+__device__ __forceinline__ void ct_store_tile(const EpiArgs &e, f32x4 acc, int n, int oy, int ox0, int co0,
+                                              int lane)
+{
+    if (oy >= e.Ho) return;
+    const int co = co0 + (lane & 15);
+    const int xr = ox0 + ((lane >> 4) << 2);
+    if (co >= e.Cout) return;
+    const float sc = e.scale ? e.scale[co] : 1.0f;
+    const float sh = e.shift ? e.shift[co] : 0.0f;
+    const size_t pix = ((size_t)n * e.Ho + oy) * e.Wo;
+    float v[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int ox = xr + i;
+        float r = 0.0f;
+        if (e.res && ox < e.Wo) r = e.res[(pix + ox) * e.ldr + co];
+        v[i] = ct_epilogue_value(e, acc[i], co, sc, sh, r);
+    }
+    if (e.flags & CT_OUT_NCHW) {
+        float *dst = e.y + ((size_t)n * e.Cout + co) * ((size_t)e.Ho * e.Wo) + (size_t)oy * e.Wo + xr;
+        if (xr + 3 < e.Wo && ((e.Wo & 3) == 0)) {
+            *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (xr + i < e.Wo) dst[i] = v[i];
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            if (xr + i < e.Wo) e.y[(pix + xr + i) * e.ldy + co] = v[i];
+    }
+}

@@ -1,0 +1,329 @@
+// Modulated deformable convolution v2 (3x3, stride 1, pad 1, dilation 1, one deformable
+// group) fused with its BatchNorm + ReLU, as ONE kernel: no im2col buffer ever reaches HBM.
+//
+//   y[p,co] = act( scale[co] * sum_{k,ci} W[co,ci,k] * m_k(p) * bilinear(x[.,ci], p+tap_k+d_k(p))
+//                  + shift[co] )
+//
+// Layout choice (MI355X-first): activations are NHWC, so the four bilinear corners of a
+// sampling point are four contiguous channel vectors -> 16-byte loads, and the bilinear
+// weights / validity / mask of a (pixel, tap) are computed ONCE per workgroup (a 9-tap
+// table in LDS) instead of once per input channel as the upstream NCHW im2col kernel does.
+//
+// One workgroup = 4 waves = 64 output pixels (4 rows x 16) x BN couts.  Loop over
+// (channel chunk of 32, tap): every thread gathers 4 corners x 2 float4 for its
+// (pixel, channel quad), blends them with the table weights and writes the A tile
+// [2][64 px][16 ch] to LDS (double buffered, XOR-swizzled 16-B slots, conflict-free
+// ds_read_b128 fragments); B fragments (packed weights, 1 KiB contiguous per wave load) go
+// straight from L2 to VGPRs one step ahead; v_mfma_f32_16x16x4_f32 accumulates in fp32.
+// The gather of step s+1 is in flight while the MFMAs of step s run.  Chunk-outer /
+// tap-inner order keeps the 9 taps' footprint of one chunk in L1.
+#include "ct_common.h"
+
+namespace {
+
+struct DcnArgs {
+    const float *x;
+    const float *om;
+    const float *wp;
+    int N, H, W, Cin, ldx, ldom;
+    int tilesX, tilesY, coutBlocks;
+    int NT;
+    int nchunks, chunksPerSplit;     // chunks of 32 channels
+    float *ws;
+    int wsCout;
+    EpiArgs epi;
+};
+
+template <int WN>   // wave grid is 2 (pixel rows) x 2 (couts); wave tile = 2 m-tiles x WN n-tiles
+__global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
+{
+    constexpr int BM = 64, NKK = 2, WM = 2;
+    constexpr int SLAB = BM * 16;            // floats
+    constexpr int BUF = NKK * SLAB;
+    // LDS: A tile double buffer | table offsets int4[BM*9] | table weights float4[BM*9]
+    __shared__ __attribute__((aligned(16))) float lds_a[2 * BUF];
+    __shared__ __attribute__((aligned(16))) int tab_off[BM * 9 * 4];
+    __shared__ __attribute__((aligned(16))) float tab_w[BM * 9 * 4];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    int bid = blockIdx.x;
+    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int tx = bid % a.tilesX; bid /= a.tilesX;
+    const int ty = bid % a.tilesY; bid /= a.tilesY;
+    const int n = bid;
+    const int oy0 = ty * 4, ox0 = tx * 16;
+    const int split = blockIdx.y;
+    const int c_begin = split * a.chunksPerSplit;
+    const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
+
+    const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
+    const float *omn = a.om + (size_t)n * a.H * a.W * a.ldom;
+
+    // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
+    for (int it = tid; it < BM * 9; it += 256) {
+        const int m = it / 9, k = it - m * 9;
+        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+        int o[4] = {0, 0, 0, 0};
+        float wgt[4] = {0.f, 0.f, 0.f, 0.f};
+        if (oy < a.H && ox < a.W) {
+            const float *omp = omn + ((size_t)oy * a.W + ox) * a.ldom;
+            const float dy = omp[2 * k], dx = omp[2 * k + 1], mk = omp[18 + k];
+            const float ys = (float)(oy - 1 + k / 3) + dy;
+            const float xs = (float)(ox - 1 + k % 3) + dx;
+            if (ys > -1.0f && xs > -1.0f && ys < (float)a.H && xs < (float)a.W) {
+                const float yf = floorf(ys), xf = floorf(xs);
+                const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
+                const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
+                const bool vy0 = y0 >= 0, vy1 = y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
+                if (vy0 && vx0) { o[0] = (y0 * a.W + x0) * a.ldx; wgt[0] = hy * hx * mk; }
+                if (vy0 && vx1) { o[1] = (y0 * a.W + x1) * a.ldx; wgt[1] = hy * lx * mk; }
+                if (vy1 && vx0) { o[2] = (y1 * a.W + x0) * a.ldx; wgt[2] = ly * hx * mk; }
+                if (vy1 && vx1) { o[3] = (y1 * a.W + x1) * a.ldx; wgt[3] = ly * lx * mk; }
+            }
+        }
+        *reinterpret_cast<int4 *>(tab_off + it * 4) = make_int4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<f32x4 *>(tab_w + it * 4) = f32x4{wgt[0], wgt[1], wgt[2], wgt[3]};
+    }
+    __syncthreads();
+
+    // ---- gather assignment: thread -> pixel m = tid>>2, channel quad q = tid&3, both slabs ----
+    const int gm = tid >> 2, gq = tid & 3;
+    const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);   // float offset inside a slab
+    f32x4 cv[NKK][4];
+    f32x4 gw;
+    auto gather_load = [&](int chunk, int tap) {
+        const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
+        gw = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
+        const float *base = xin + chunk * 32 + gq * 4;
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            cv[kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * 16);
+            cv[kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * 16);
+            cv[kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * 16);
+            cv[kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * 16);
+        }
+    };
+    auto gather_store = [&](int buf) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const f32x4 v = gw[0] * cv[kk][0] + gw[1] * cv[kk][1] + gw[2] * cv[kk][2] + gw[3] * cv[kk][3];
+            *reinterpret_cast<f32x4 *>(lds_a + buf * BUF + kk * SLAB + lslot) = v;
+        }
+    };
+
+    const int li = lane & 15, lg = lane >> 4;
+    const int nt0 = cb * (2 * WN) + wn * WN;
+    const int NCH16 = a.Cin >> 4;
+    auto load_b = [&](f32x4 (&b)[NKK][WN], int chunk, int tap) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+                b[kk][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (nt0 + nt < a.NT)
+                    b[kk][nt] = *reinterpret_cast<const f32x4 *>(a.wp + ((slab * a.NT + nt0 + nt) << 8) + (lane << 2));
+            }
+        }
+    };
+    int aoff[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m = (wm * WM + mt) * 16 + li;
+        aoff[mt] = m * 16 + ((lg ^ ((m >> 1) & 2)) << 2);
+    }
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int nsteps = (c_end - c_begin) * 9;
+    if (nsteps > 0) {
+        gather_load(c_begin, 0);
+        gather_store(0);
+        f32x4 bcur[NKK][WN], bnext[NKK][WN];
+        load_b(bcur, c_begin, 0);
+        __syncthreads();
+        int chunk = c_begin, tap = 0;
+        for (int s = 0; s < nsteps; ++s) {
+            const int cur = s & 1;
+            int ntap = tap + 1, nchunk = chunk;
+            if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
+            const bool more = (s + 1 < nsteps);
+            if (more) {
+                gather_load(nchunk, ntap);
+                load_b(bnext, nchunk, ntap);
+            }
+            const float *buf = lds_a + cur * BUF;
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk) {
+                f32x4 af[WM];
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(buf + kk * SLAB + aoff[mt]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bcur[kk][nt][e],
+                                                                              acc[mt][nt], 0, 0, 0);
+            }
+            if (more) {
+                gather_store(cur ^ 1);
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt) bcur[kk][nt] = bnext[kk][nt];
+            }
+            __syncthreads();
+            tap = ntap; chunk = nchunk;
+        }
+    }
+
+    if (a.ws) {
+        const size_t Mtot = (size_t)a.N * a.H * a.W;
+        float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            const int oy = oy0 + wm * WM + mt;
+            if (oy >= a.H) continue;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) {
+                const int co = (nt0 + nt) * 16 + li;
+                if (co >= a.wsCout) continue;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int ox = ox0 + lg * 4 + e;
+                    if (ox < a.W) wsp[(((size_t)n * a.H + oy) * a.W + ox) * a.wsCout + co] = acc[mt][nt][e];
+                }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+                ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
+    }
+}
+
+struct DcnPlan {
+    int BN, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
+};
+
+int make_plan(const ct_dcn_desc *d, DcnPlan *p)
+{
+    if (!d || !d->x || !d->om || !d->w_packed || !d->y) CT_FAIL_ARG("ct_dcn_v2: null pointer");
+    if (d->Cin % 32 || d->Cin <= 0) CT_FAIL_ARG("ct_dcn_v2: Cin=%d must be a positive multiple of 32", d->Cin);
+    if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_dcn_v2: input view must be 16-byte aligned");
+    if (d->ldom < 27) CT_FAIL_ARG("ct_dcn_v2: offset/mask map needs >= 27 channels");
+    if (d->Cout <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) CT_FAIL_ARG("ct_dcn_v2: bad shape");
+    if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_dcn_v2: NCHW output unsupported");
+    p->NT = ct_cdiv(d->Cout, 16);
+    p->tilesX = ct_cdiv(d->W, 16);
+    p->tilesY = ct_cdiv(d->H, 4);
+    p->BN = 64;
+    if (d->Cout >= 128 && (long)d->N * p->tilesX * p->tilesY * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
+    p->coutBlocks = ct_cdiv(d->Cout, p->BN);
+    p->nchunks = d->Cin / 32;
+    const long tiles = (long)d->N * p->tilesX * p->tilesY * p->coutBlocks;
+    int splits = d->split_k;
+    if (splits <= 0) {
+        splits = 1;
+        if (d->workspace && tiles < 256) {
+            splits = (int)((512 + tiles - 1) / tiles);
+            if (splits > p->nchunks) splits = p->nchunks;
+            if (splits > 16) splits = 16;
+        }
+    }
+    if (splits > p->nchunks) splits = p->nchunks;
+    if (splits < 1) splits = 1;
+    p->chunksPerSplit = ct_cdiv(p->nchunks, splits);
+    p->splits = ct_cdiv(p->nchunks, p->chunksPerSplit);
+    return CT_OK;
+}
+
+size_t ws_bytes(const ct_dcn_desc *d, const DcnPlan &p)
+{
+    if (p.splits <= 1) return 0;
+    return (size_t)p.splits * d->N * d->H * d->W * (size_t)(p.NT * 16) * sizeof(float);
+}
+
+// defined in conv_mfma.hip's anonymous namespace -> re-declare a local copy of the reducer launch
+__global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(const float *ws, int splits, size_t Mtot, int wsCout,
+                                                                EpiArgs e)
+{
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int quads = wsCout >> 2;
+    if (idx >= Mtot * quads) return;
+    const size_t m = idx / quads;
+    const int c4 = (int)(idx - m * quads) << 2;
+    f32x4 s = *reinterpret_cast<const f32x4 *>(ws + m * wsCout + c4);
+    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(ws + ((size_t)k * Mtot + m) * wsCout + c4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = c4 + i;
+        if (co >= e.Cout) break;
+        const float sc = e.scale ? e.scale[co] : 1.0f;
+        const float sh = e.shift ? e.shift[co] : 0.0f;
+        e.y[m * e.ldy + co] = ct_epilogue_value(e, s[i], co, sc, sh, 0.0f);
+    }
+}
+
+}  // namespace
+
+extern "C" size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d)
+{
+    DcnPlan p;
+    ct_dcn_desc t = *d;
+    float dummy;
+    if (!t.workspace) t.workspace = &dummy;
+    if (!t.y) t.y = &dummy;
+    if (make_plan(&t, &p) != CT_OK) return 0;
+    return ws_bytes(&t, p);
+}
+
+extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
+{
+    DcnPlan p;
+    int rc = make_plan(d, &p);
+    if (rc != CT_OK) return rc;
+    const size_t need = ws_bytes(d, p);
+    if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
+        ct_set_error("ct_dcn_v2: split_k=%d needs %zu workspace bytes, got %zu", p.splits, need, d->workspace_bytes);
+        return CT_ERR_WORKSPACE;
+    }
+    DcnArgs a;
+    a.x = d->x; a.om = d->om; a.wp = d->w_packed;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.ldom = d->ldom;
+    a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.coutBlocks = p.coutBlocks; a.NT = p.NT;
+    a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit;
+    a.ws = p.splits > 1 ? d->workspace : nullptr;
+    a.wsCout = p.NT * 16;
+    a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = nullptr; a.epi.y = d->y;
+    a.epi.ldr = 0; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;
+    a.epi.flags = d->flags & CT_RELU; a.epi.sig_lo = a.epi.sig_hi = 0; a.epi.dep_lo = a.epi.dep_hi = 0;
+    a.epi.depth_scale = 1.0f;
+    const long blocks = (long)d->N * p.tilesX * p.tilesY * p.coutBlocks;
+    if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
+    dim3 grid((unsigned)blocks, (unsigned)p.splits);
+    hipStream_t s = (hipStream_t)stream;
+    if (p.BN == 128) hipLaunchKernelGGL(dcn_mfma_kernel<4>, grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(dcn_mfma_kernel<2>, grid, dim3(256), 0, s, a);
+    CT_CHECK_LAUNCH("ct_dcn_v2");
+    if (p.splits > 1) {
+        const size_t Mtot = (size_t)d->N * d->H * d->W;
+        const size_t nq = Mtot * (size_t)(a.wsCout / 4);
+        hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                           d->workspace, p.splits, Mtot, a.wsCout, a.epi);
+        CT_CHECK_LAUNCH("ct_dcn_v2(split-K reduce)");
+    }
+    return CT_OK;
+}

@@ -1,0 +1,143 @@
+// The three 7x7 stems of DLA (image, previous image, prior heat-map), fused:
+//   y[n,p,:] = relu(bn0(conv7x7(x)))  + relu(bn1(conv7x7(pre_img))) + relu(bn2(conv7x7(pre_hm)))
+// Inputs are the reference's NCHW planes; output is NHWC with 16 channels.
+//
+// GEMM view per stem: M = pixels, N = 16 couts, K = Cin*49 (147 / 147 / 49, padded to a
+// multiple of 4) on v_mfma_f32_16x16x4_f32.  A workgroup (4 waves) owns an 8 x 32 pixel
+// tile: all 7 input planes of the tile (+3 px halo, zero padded) and all three weight
+// matrices sit in LDS; an A operand is a single ds_read_b32 at plane[tab[k] + pixel], where
+// tab[] maps k = (ci,ky,kx) to its patch offset.  The plane pitch is 40 floats so that the
+// k -> k+1 row wrap (kx 6 -> 0) lands on a different bank.
+#include "ct_common.h"
+
+namespace {
+
+constexpr int ST_TH = 8, ST_TW = 32;
+constexpr int ST_PH = ST_TH + 6, ST_PW = 40;           // pitch 40 (38 used)
+constexpr int ST_PS = ST_PH * ST_PW;                   // floats per plane
+__host__ __device__ constexpr int st_k4(int s) { return s == 2 ? 52 : 148; }   // K padded to 4
+__host__ __device__ constexpr int st_koff(int s) { return s * 148; }            // offsets into the k tables
+constexpr int ST_KTOT = 348;
+
+struct StemArgs {
+    const float *in[3];
+    const float *w[3];
+    const float *scale;   // [3][16]
+    const float *shift;   // [3][16]
+    float *y;
+    int N, H, W, ldy, tilesX, tilesY;
+};
+
+__global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float planes[7 * ST_PS];
+    __shared__ __attribute__((aligned(16))) float wl[ST_KTOT * 16];
+    __shared__ int tab[ST_KTOT];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    int bid = blockIdx.x;
+    const int tx = bid % a.tilesX; bid /= a.tilesX;
+    const int ty = bid % a.tilesY; bid /= a.tilesY;
+    const int n = bid;
+    const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
+    const size_t HW = (size_t)a.H * a.W;
+
+    // ---- stage planes (zero padded), weights and the k -> offset table ----
+    for (int s = 0, plane = 0; s < 3; ++s) {
+        const int cin = (s == 2) ? 1 : 3;
+        if (a.in[s]) {
+            const float *src = a.in[s] + (size_t)n * cin * HW;
+            for (int it = tid; it < cin * ST_PH * 38; it += 256) {
+                const int c = it / (ST_PH * 38);
+                const int r = it - c * (ST_PH * 38);
+                const int py = r / 38, px = r - py * 38;
+                const int iy = oy0 - 3 + py, ix = ox0 - 3 + px;
+                float v = 0.0f;
+                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = src[(size_t)c * HW + (size_t)iy * a.W + ix];
+                planes[(plane + c) * ST_PS + py * ST_PW + px] = v;
+            }
+            const int K = cin * 49;
+            for (int it = tid; it < st_k4(s) * 16; it += 256) {
+                const int k = it >> 4, j = it & 15;
+                wl[(st_koff(s) + k) * 16 + j] = (k < K) ? a.w[s][j * K + k] : 0.0f;
+            }
+            for (int k = tid; k < st_k4(s); k += 256) {
+                int off = 0;
+                if (k < K) {
+                    const int c = k / 49, r = k - c * 49;
+                    off = (plane + c) * ST_PS + (r / 7) * ST_PW + (r % 7);
+                }
+                tab[st_koff(s) + k] = off;
+            }
+        }
+        plane += cin;
+    }
+    __syncthreads();
+
+    // wave -> rows 2w, 2w+1; m-tile mt -> (row 2w + mt/2, column block mt&1)
+    int pbase[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) pbase[mt] = (2 * wave + (mt >> 1)) * ST_PW + (mt & 1) * 16 + li;
+
+    f32x4 out[4];
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+        if (!a.in[s]) continue;
+        f32x4 acc[4];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int nsteps = st_k4(s) / 4;
+#pragma unroll 4
+        for (int st = 0; st < nsteps; ++st) {
+            const int k = st_koff(s) + 4 * st + lg;
+            const int off = tab[k];
+            const float b = wl[k * 16 + li];
+#pragma unroll
+            for (int mt = 0; mt < 4; ++mt)
+                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[off + pbase[mt]], b, acc[mt], 0, 0, 0);
+        }
+        const float sc = a.scale[s * 16 + li], sh = a.shift[s * 16 + li];
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) out[mt][e] += fmaxf(acc[mt][e] * sc + sh, 0.0f);
+    }
+
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt) {
+        const int oy = oy0 + 2 * wave + (mt >> 1);
+        if (oy >= a.H) continue;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int ox = ox0 + (mt & 1) * 16 + lg * 4 + e;
+            if (ox < a.W) a.y[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + li] = out[mt][e];
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int ct_stem_forward(const float *x, const float *pre_img, const float *pre_hm, int N, int H, int W,
+                               const float *w_x, const float *w_img, const float *w_hm, const float *scale3,
+                               const float *shift3, float *y, int ldy, void *stream)
+{
+    if (!x || !w_x || !scale3 || !shift3 || !y) CT_FAIL_ARG("ct_stem_forward: null pointer");
+    if ((pre_img && !w_img) || (pre_hm && !w_hm)) CT_FAIL_ARG("ct_stem_forward: input given without its weights");
+    if (N <= 0 || H <= 0 || W <= 0 || ldy < 16) CT_FAIL_ARG("ct_stem_forward: bad shape");
+    StemArgs a;
+    a.in[0] = x; a.in[1] = pre_img; a.in[2] = pre_hm;
+    a.w[0] = w_x; a.w[1] = w_img; a.w[2] = w_hm;
+    a.scale = scale3; a.shift = shift3; a.y = y;
+    a.N = N; a.H = H; a.W = W; a.ldy = ldy;
+    a.tilesX = ct_cdiv(W, ST_TW); a.tilesY = ct_cdiv(H, ST_TH);
+    const long blocks = (long)N * a.tilesX * a.tilesY;
+    if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_stem_forward: grid too large");
+    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    CT_CHECK_LAUNCH("ct_stem_forward");
+    return CT_OK;
+}

@@ -1,0 +1,319 @@
+"""Per-frame inference orchestration: the reference's ``Detector`` surface on the HIP path.
+
+``Detector(opt)`` / ``run(image_or_path_or_tensor, meta={}) -> dict`` /
+``reset_tracking()`` / ``.pre_process`` / ``.pause`` follow src/lib/detector.py:24-172,
+455-458 so the class drops in under the reference's demo.py / test.py; the returned dict
+has the same keys (``results, tot, load, pre, net, dec, post, merge, track, display``).
+What changed underneath: the whole device side of one frame -- three
+stems, DLA-34, 16 DCNv2 nodes, heads with fused sigmoid, flip merge, NMS + top-K +
+gathers -- is a fixed launch sequence of libcentertrack_hip kernels replayed from ONE HIP
+graph, and the 8-14 per-key D2H copies + 4 device syncs of detector.py:338-350 are one
+packed [B,K,F] copy + one stream sync.
+
+``StreamDetector`` is the batched extension the reference does not have (BASELINE
+configs 3-5): B independent video streams advance one frame per call, each with its own
+``Tracker`` / ``pre_images`` state; streams never mix (frames of one stream stay
+sequential).  ``Detector`` is the B = 1 case.
+"""
+import math
+import time
+
+import numpy as np
+import torch
+
+from . import _lib, ops
+from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, make_meta)
+from .model import create_model, load_model
+from .post_process import generic_post_process
+from .tracker import Tracker
+
+# mean / std every dataset class of the reference shares (generic_dataset.py:39-42)
+MEAN = np.array([0.40789654, 0.44719302, 0.47026115], dtype=np.float32).reshape(1, 1, 3)
+STD = np.array([0.28863828, 0.27408164, 0.27809835], dtype=np.float32).reshape(1, 1, 3)
+REST_FOCAL_LENGTH = {'nuscenes': 1200, 'kitti': 721.5377, 'kitti_tracking': 721.5377}
+AVERAGE_FLIPS = ('hm', 'wh', 'dep', 'dim')
+NEG_AVERAGE_FLIPS = ('amodel_offset',)
+
+
+def trans_bbox(bbox, trans, width, height):
+    """detector.py:242-251"""
+    bbox = np.array(bbox, dtype=np.float32).copy()
+    bbox[:2] = affine_transform(bbox[:2], trans)
+    bbox[2:] = affine_transform(bbox[2:], trans)
+    bbox[[0, 2]] = np.clip(bbox[[0, 2]], 0, width - 1)
+    bbox[[1, 3]] = np.clip(bbox[[1, 3]], 0, height - 1)
+    return bbox
+
+
+def render_pre_hm(tracks, meta, pre_thresh, out=None, with_hm=True):
+    """Prior heat-map from tracker state (detector.py:254-290): one max-splatted Gaussian
+    per active track with score >= pre_thresh.  Returns (hm [H,W] f32, pre_inds list)."""
+    inp_w, inp_h = meta['inp_width'], meta['inp_height']
+    out_w, out_h = meta['out_width'], meta['out_height']
+    hm = np.zeros((inp_h, inp_w), np.float32) if out is None else out
+    if out is not None:
+        hm[...] = 0
+    inds = []
+    for det in tracks:
+        if det['score'] < pre_thresh or det['active'] == 0:
+            continue
+        bbox = trans_bbox(det['bbox'], meta['trans_input'], inp_w, inp_h)
+        bbox_out = trans_bbox(det['bbox'], meta['trans_output'], out_w, out_h)
+        h, w = bbox[3] - bbox[1], bbox[2] - bbox[0]
+        if h > 0 and w > 0:
+            radius = max(0, int(gaussian_radius((math.ceil(h), math.ceil(w)))))
+            ct = np.array([(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2], dtype=np.float32)
+            if with_hm:
+                draw_umich_gaussian(hm, ct.astype(np.int32), radius)
+            ct_out = np.array([(bbox_out[0] + bbox_out[2]) / 2, (bbox_out[1] + bbox_out[3]) / 2], dtype=np.int32)
+            inds.append(int(ct_out[1] * out_w + ct_out[0]))
+    return hm, inds
+
+
+class StreamDetector(object):
+    """B independent streams, one frame each per ``step``."""
+
+    def __init__(self, opt, model=None, num_streams=1, use_graph=True):
+        if not torch.cuda.is_available():
+            raise _lib.CTError('centertrack_amd needs an MI355X (no CPU fallback)')
+        _lib.load()
+        self.opt = opt
+        self.device = torch.device('cuda', torch.cuda.current_device())
+        opt.device = self.device
+        if model is None:
+            model = create_model(opt.arch, opt.heads, opt.head_conv, opt=opt)
+            if getattr(opt, 'load_model', ''):
+                model = load_model(model, opt.load_model, opt)
+        self.model = model.to(self.device).eval()
+        self.B = num_streams
+        self.flip = bool(getattr(opt, 'flip_test', False))
+        self.use_graph = use_graph
+        self.trackers = [Tracker(opt) for _ in range(self.B)]
+        self.started = [False] * self.B
+        self.gather_fn = None      # optional hook: called with the packed device rows [B,K,F] (multi-GPU all-gather)
+        self._ctx = None
+
+    # ---- per-shape device context (static buffers + captured graph) ----------------------
+    def _context(self, H, W):
+        if self._ctx is not None and self._ctx['hw'] == (H, W):
+            return self._ctx
+        opt = self.opt
+        NB = self.B * (2 if self.flip else 1)
+        with_img = bool(getattr(opt, 'tracking', False)) and bool(getattr(opt, 'pre_img', True))
+        with_hm = bool(getattr(opt, 'tracking', False)) and bool(getattr(opt, 'pre_hm', False))
+        plan = self.model.get_plan(NB, H, W, with_img, with_hm, True)
+        x_in, img_in, hm_in = plan['inputs']
+        outs = plan['outputs']
+        ctx = {'hw': (H, W), 'plan': plan, 'NB': NB}
+        if self.flip:
+            merged = {k: torch.empty((self.B,) + tuple(v.shape[1:]), device=self.device) for k, v in outs.items()}
+        else:
+            merged = outs
+        ctx['merged'] = merged
+        if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:
+            pass
+        dec_heads = {k: v for k, v in merged.items() if k != 'hm'}
+        ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
+        ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
+        ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if with_hm else None
+        ctx['pre_img_state'] = img_in         # pre_images live in the plan's static buffer
+        ctx['graph'] = None
+
+        def device_frame():
+            self.model._run_plan(plan)
+            if self.flip:
+                self._flip_merge(outs, merged)
+            if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:
+                merged['tracking'].zero_()
+            ctx['decoder'].run()
+
+        ctx['device_frame'] = device_frame
+        if self.use_graph:
+            try:
+                torch.cuda.synchronize()
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    device_frame()            # warm-up (lazy module loads must not happen in capture)
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    device_frame()
+                ctx['graph'] = g
+            except Exception as e:             # capture is an optimisation; eager launches are the same kernels
+                print('centertrack_amd: HIP graph capture failed (%s); using eager launches' % e)
+                ctx['graph'] = None
+                torch.cuda.synchronize()
+        self._ctx = ctx
+        return ctx
+
+    def _flip_merge(self, outs, merged):
+        """detector.py:311-332 (non-pose heads), for [B originals ; B flipped]."""
+        B = self.B
+        for head, v in outs.items():
+            if head in AVERAGE_FLIPS:
+                torch.add(v[:B], torch.flip(v[B:], [3]), out=merged[head])
+                merged[head].div_(2)
+            elif head in NEG_AVERAGE_FLIPS:
+                f = torch.flip(v[B:], [3])
+                f[:, 0::2] *= -1
+                torch.add(v[:B], f, out=merged[head])
+                merged[head].div_(2)
+            else:
+                merged[head].copy_(v[:B])
+
+    # ---- one frame for every stream -------------------------------------------------------
+    def step(self, images, metas, timers=None):
+        """images: float32 [B,3,H,W] (already normalised, like PrefetchDataset hands over);
+        metas: list of B ``meta`` dicts (image.make_meta).  Returns a list of B result lists."""
+        opt = self.opt
+        t0 = time.time()
+        B = self.B
+        assert images.shape[0] == B and len(metas) == B
+        H, W = int(images.shape[2]), int(images.shape[3])
+        ctx = self._context(H, W)
+        x_in, img_in, hm_in = ctx['plan']['inputs']
+        if self.flip:
+            images = torch.cat((images, torch.flip(images, [3])), 0)
+        x_dev = images.to(self.device, non_blocking=True)
+        tracking = bool(getattr(opt, 'tracking', False))
+        if tracking:
+            for s in range(B):
+                if not self.started[s]:                        # detector.py:97-103
+                    self.trackers[s].init_track(metas[s].get('pre_dets', []))
+            if img_in is not None:
+                fresh = [s for s in range(B) if not self.started[s]]
+                if len(fresh) == B:
+                    img_in.copy_(x_dev)
+                else:
+                    for s in fresh:
+                        img_in[s].copy_(x_dev[s])
+                        if self.flip:
+                            img_in[B + s].copy_(x_dev[B + s])
+            if hm_in is not None:
+                hh = ctx['host_hm']
+                for s in range(B):
+                    render_pre_hm(self.trackers[s].tracks, metas[s], opt.pre_thresh, out=hh[s, 0].numpy(),
+                                  with_hm=not getattr(opt, 'zero_pre_hm', False))
+                    if self.flip:
+                        hh[B + s, 0].copy_(torch.flip(hh[s, 0], [1]))
+                hm_in.copy_(hh, non_blocking=True)
+            for s in range(B):
+                self.started[s] = True
+        x_in.copy_(x_dev)
+        t1 = time.time()
+        if ctx['graph'] is not None:
+            ctx['graph'].replay()
+        else:
+            ctx['device_frame']()
+        if tracking and img_in is not None:
+            img_in.copy_(x_in)                                 # self.pre_images = images (detector.py:148)
+        if self.gather_fn is not None:
+            self.gather_fn(ctx['decoder'].out)
+        ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)
+        torch.cuda.current_stream().synchronize()
+        t2 = time.time()
+        dets = ctx['decoder'].unpack(ctx['host_out'].numpy())
+        self.last_dets = dets
+        all_results = []
+        t_post = t_track = 0.0
+        for s in range(B):
+            ta = time.time()
+            meta = metas[s]
+            one = {k: v[s:s + 1] for k, v in dets.items()}
+            res = generic_post_process(opt, one, [meta['c']], [meta['s']], meta['out_height'], meta['out_width'],
+                                       opt.num_classes, [meta['calib']], meta['height'], meta['width'])[0]
+            res = [r for r in res if r['score'] > opt.out_thresh]          # merge_outputs, detector.py:371-377
+            tb = time.time()
+            if tracking:
+                public_det = meta.get('cur_dets') if getattr(opt, 'public_det', False) else None
+                res = self.trackers[s].step(res, public_det)
+            tc = time.time()
+            t_post += tb - ta
+            t_track += tc - tb
+            all_results.append(res)
+        if timers is not None:
+            timers.update({'pre': t1 - t0, 'net': t2 - t1, 'dec': 0.0, 'post': t_post, 'merge': 0.0,
+                           'track': t_track})
+        return all_results
+
+    def reset_tracking(self, stream=None):
+        for s in (range(self.B) if stream is None else [stream]):
+            self.trackers[s].reset()
+            self.started[s] = False
+
+
+class Detector(object):
+    """The reference's single-stream ``Detector`` API (src/lib/detector.py)."""
+
+    def __init__(self, opt, model=None, use_graph=True):
+        if not hasattr(opt, 'device'):
+            opt.device = torch.device('cuda')
+        self.opt = opt
+        self.impl = StreamDetector(opt, model=model, num_streams=1, use_graph=use_graph)
+        self.model = self.impl.model
+        self.mean, self.std = MEAN, STD
+        self.pause = not getattr(opt, 'no_pause', True)
+        self.rest_focal_length = (REST_FOCAL_LENGTH.get(getattr(opt, 'dataset', ''), 1200)
+                                  if getattr(opt, 'test_focal_length', -1) < 0 else opt.test_focal_length)
+        self.cnt = 0
+
+    @property
+    def tracker(self):
+        return self.impl.trackers[0]
+
+    def pre_process(self, image, scale, input_meta={}):
+        """detector.py:207-239.  The cv2 resize/warpAffine of a raw BGR frame is the step
+        *before* the hot path and is not re-implemented yet: hand over
+        the normalised tensor (as test.py's PrefetchDataset does) or a pre-processed dict."""
+        raise NotImplementedError('raw-image pre-processing (cv2 warpAffine) is outside the hot path; '
+                                  'pass a pre-processed dict or (tensor, meta)')
+
+    def run(self, image_or_path_or_tensor, meta={}):
+        start = time.time()
+        x = image_or_path_or_tensor
+        if isinstance(x, dict):                                # prefetch path, detector.py:66-70,84-92
+            scale = self.opt.test_scales[0] if hasattr(self.opt, 'test_scales') else 1.0
+            images = x['images'][scale][0]
+            m = {k: (v.numpy()[0] if torch.is_tensor(v) else v) for k, v in x['meta'][scale].items()}
+            for k in ('pre_dets', 'cur_dets'):
+                if k in x['meta']:
+                    m[k] = x['meta'][k]
+            meta = m
+        elif torch.is_tensor(x):
+            images = x
+        else:
+            return self.pre_process(x, 1.0, meta)
+        if images.shape[0] == 2 and self.impl.flip:
+            images = images[0:1]                               # the flipped copy is rebuilt on device
+        loaded = time.time()
+        timers = {}
+        results = self.impl.step(images, [meta], timers)[0]
+        self.cnt += 1
+        end = time.time()
+        ret = {'results': results, 'tot': end - start, 'load': loaded - start, 'display': 0.0}
+        ret.update(timers)
+        return ret
+
+    def reset_tracking(self):
+        self.impl.reset_tracking()
+
+
+def default_opt(heads, **kw):
+    """Namespace with the reference's flag names the hot path reads and the
+    tracking-task threshold derivation of opts.py:280-289."""
+    import types
+    o = types.SimpleNamespace(
+        arch='dla_34', heads=heads, head_conv=256, dla_node='dcn', head_kernel=3, load_model='',
+        tracking=True, pre_img=True, pre_hm=True, zero_pre_hm=False, flip_test=False, K=100,
+        track_thresh=0.3, out_thresh=-1.0, pre_thresh=-1.0, new_thresh=0.3, max_age=-1, hungarian=False,
+        public_det=False, zero_tracking=False, depth_scale=1.0, down_ratio=4, num_classes=heads['hm'],
+        test_scales=[1.0], model_output_list=False, no_pause=True, dataset='', test_focal_length=-1)
+    for k, v in kw.items():
+        setattr(o, k, v)
+    if o.tracking:
+        o.out_thresh = max(o.track_thresh, o.out_thresh)
+        o.pre_thresh = max(o.track_thresh, o.pre_thresh)
+        o.new_thresh = max(o.track_thresh, o.new_thresh)
+    return o

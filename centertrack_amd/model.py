@@ -1,0 +1,394 @@
+"""DLA-34 + DLAUp/IDAUp (DCNv2 nodes) + heads as a pre-planned sequence of HIP launches.
+
+Mirrors the reference's model boundary: ``create_model(arch, heads,
+head_conv, opt)`` / ``load_model`` (src/lib/model/model.py:24-90) and
+``model(x, pre_img, pre_hm)[-1] -> {head: [B,c,h,w]}`` (base_model.py:73-91,
+dla.py:593-640), with the reference's state-dict keys, so its ``.pth`` files load
+unchanged.  Internally nothing of torch.nn runs: weights are BN-folded and packed
+once into MFMA fragment order, activations are NHWC views, concatenations are
+channel slices of shared buffers, and each frame is ~140 launches of
+libcentertrack_hip kernels on the current stream (capturable in one HIP graph).
+"""
+import ctypes
+from collections import OrderedDict
+
+import torch
+
+from . import _lib, ops
+from .ops import View
+from .weights import CHANNELS, LEVELS, dla34_param_shapes
+
+BN_EPS = 1e-5
+
+
+def _fold_bn(sd, p):
+    """eval-mode BatchNorm -> (scale, shift): y = x*scale + shift  """
+    scale = sd[p + '.weight'].double() / torch.sqrt(sd[p + '.running_var'].double() + BN_EPS)
+    shift = sd[p + '.bias'].double() - sd[p + '.running_mean'].double() * scale
+    return scale.float().contiguous(), shift.float().contiguous()
+
+
+class _Launch(object):
+    """One pre-built C-ABI call."""
+    __slots__ = ('fn', 'args', 'name', 'keep')
+
+    def __init__(self, name, fn, args, keep=()):
+        self.name, self.fn, self.args, self.keep = name, fn, args, keep
+
+
+class DLASegHIP(torch.nn.Module):
+    """Drop-in for the reference ``DLASeg(34, heads, head_convs, opt)`` at inference."""
+
+    def __init__(self, heads, head_conv=256, pre_img=True, pre_hm=True, depth_scale=1.0,
+                 model_output_list=False):
+        super().__init__()
+        self.heads = OrderedDict(heads)
+        if isinstance(head_conv, dict):       # reference passes {head: [256]}
+            vals = {tuple(v) if isinstance(v, (list, tuple)) else (v,) for v in head_conv.values()}
+            assert len(vals) == 1 and len(next(iter(vals))) == 1, 'only one head-conv layer is supported'
+            head_conv = next(iter(vals))[0]
+        self.head_conv = head_conv
+        self.pre_img, self.pre_hm = pre_img, pre_hm
+        self.depth_scale = depth_scale
+        self.model_output_list = model_output_list
+        # parameters/buffers registered under the reference's names so state_dict() matches
+        self._names = []
+        for key, shape, kind in dla34_param_shapes(self.heads, head_conv, pre_img, pre_hm):
+            if kind == 'bn':
+                for suf, val in (('weight', 1.0), ('bias', 0.0), ('running_mean', 0.0), ('running_var', 1.0)):
+                    self._reg(key + '.' + suf, torch.full(shape, val))
+                self._reg(key + '.num_batches_tracked', torch.tensor(0, dtype=torch.long))
+            else:
+                self._reg(key, torch.zeros(shape))
+        self._prepared = None
+        self._plans = {}
+
+    def _reg(self, name, t):
+        self.register_buffer(name.replace('.', '__'), t)
+        self._names.append(name)
+
+    # --- state dict with the reference's dotted keys ---------------------------------
+    def state_dict(self, *a, **k):
+        return OrderedDict((n, getattr(self, n.replace('.', '__'))) for n in self._names)
+
+    def load_state_dict(self, sd, strict=True):
+        missing = [n for n in self._names if n not in sd]
+        unexpected = [k for k in sd if k not in set(self._names)]
+        if strict and (missing or unexpected):
+            raise RuntimeError('missing %s unexpected %s' % (missing[:5], unexpected[:5]))
+        for n in self._names:
+            if n in sd:
+                buf = getattr(self, n.replace('.', '__'))
+                if tuple(buf.shape) != tuple(sd[n].shape):
+                    raise RuntimeError('shape mismatch for %s: %s vs %s' % (n, tuple(buf.shape), tuple(sd[n].shape)))
+                buf.copy_(sd[n])
+        self._prepared = None
+        self._plans = {}
+        return missing, unexpected
+
+    # --- one-time weight preparation ----------------------------------------------------
+    def _prepare(self):
+        if self._prepared is not None:
+            return self._prepared
+        dev = next(self.buffers()).device
+        if dev.type != 'cuda':
+            raise _lib.CTError('DLASegHIP runs on an MI355X only: call .to("cuda") first (no CPU fallback)')
+        _lib.load()
+        sd = {k: v.to(dev) for k, v in self.state_dict().items()}
+        P = {}
+
+        def conv_bn(wkey, bnkey):
+            sc, sh = _fold_bn(sd, bnkey)
+            return ops.pack_weight(sd[wkey]), sc, sh
+
+        P['stem_w'] = [sd['base.base_layer.0.weight'].contiguous(),
+                       sd['base.pre_img_layer.0.weight'].contiguous() if self.pre_img else None,
+                       sd['base.pre_hm_layer.0.weight'].contiguous() if self.pre_hm else None]
+        sc3 = torch.ones(3, 16, device=dev)
+        sh3 = torch.zeros(3, 16, device=dev)
+        for i, (name, on) in enumerate((('base_layer', True), ('pre_img_layer', self.pre_img),
+                                        ('pre_hm_layer', self.pre_hm))):
+            if on:
+                sc3[i], sh3[i] = _fold_bn(sd, 'base.%s.1' % name)
+        P['stem_scale'], P['stem_shift'] = sc3.contiguous(), sh3.contiguous()
+        P['level0'] = conv_bn('base.level0.0.weight', 'base.level0.1')
+        P['level1'] = conv_bn('base.level1.0.weight', 'base.level1.1')
+
+        def leaf(p, cin, cout):
+            d = {'c11': conv_bn(p + '.tree1.conv1.weight', p + '.tree1.bn1'),
+                 'c12': conv_bn(p + '.tree1.conv2.weight', p + '.tree1.bn2'),
+                 'c21': conv_bn(p + '.tree2.conv1.weight', p + '.tree2.bn1'),
+                 'c22': conv_bn(p + '.tree2.conv2.weight', p + '.tree2.bn2'),
+                 'root': conv_bn(p + '.root.conv.weight', p + '.root.bn')}
+            if cin != cout:
+                d['proj'] = conv_bn(p + '.project.0.weight', p + '.project.1')
+            return d
+
+        for i in range(2, 6):
+            p = 'base.level%d' % i
+            if LEVELS[i] == 1:
+                P[p] = leaf(p, CHANNELS[i - 1], CHANNELS[i])
+            else:
+                P[p + '.tree1'] = leaf(p + '.tree1', CHANNELS[i - 1], CHANNELS[i])
+                P[p + '.tree2'] = leaf(p + '.tree2', CHANNELS[i], CHANNELS[i])
+
+        def deform(p):
+            sc, sh = _fold_bn(sd, p + '.actf.0')
+            sh = (sd[p + '.conv.bias'].double() * sc.double() + sh.double()).float().contiguous()
+            return {'w': ops.pack_weight(sd[p + '.conv.weight']), 'scale': sc, 'shift': sh,
+                    'w_off': ops.pack_weight(sd[p + '.conv.conv_offset_mask.weight']),
+                    'b_off': sd[p + '.conv.conv_offset_mask.bias'].contiguous()}
+
+        for p, n in (('dla_up.ida_0', 1), ('dla_up.ida_1', 2), ('dla_up.ida_2', 3), ('ida_up', 2)):
+            for k in range(1, n + 1):
+                P['%s.proj_%d' % (p, k)] = deform('%s.proj_%d' % (p, k))
+                P['%s.node_%d' % (p, k)] = deform('%s.node_%d' % (p, k))
+                P['%s.up_%d' % (p, k)] = sd['%s.up_%d.weight' % (p, k)].contiguous()
+        # heads: all first layers share their input -> one 64 -> 256*nh conv
+        w0 = torch.cat([sd[h + '.0.weight'] for h in self.heads], 0)
+        P['head0_w'] = ops.pack_weight(w0)
+        P['head0_b'] = torch.cat([sd[h + '.0.bias'] for h in self.heads], 0).contiguous()
+        for h in self.heads:
+            P[h + '.2'] = (ops.pack_weight(sd[h + '.2.weight']), sd[h + '.2.bias'].contiguous())
+        self._prepared = P
+        return P
+
+    # --- plan ---------------------------------------------------------------------------
+    def _build_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid):
+        P = self._prepare()
+        lib = _lib.load()
+        dev = next(self.buffers()).device
+        if H % 32 or W % 32:
+            raise _lib.CTError('input %dx%d must be a multiple of 32 (reference pads to 32 too, opts.py:297)' % (H, W))
+        plan = {'launches': [], 'ws_need': 0}
+        L = plan['launches']
+
+        def alloc(h, w, c):
+            return ops.new_view(N, h, w, c, dev)
+
+        def add_conv(name, x, pk, cout, ks, stride=1, relu=True, res=None, out=None, **kw):
+            wp, sc, sh = pk
+            d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out, **kw)
+            plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
+            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw'))))
+            return out
+
+        # static inputs (copied into before each replay)
+        x_in = torch.zeros((N, 3, H, W), device=dev)
+        img_in = torch.zeros((N, 3, H, W), device=dev) if with_img else None
+        hm_in = torch.zeros((N, 1, H, W), device=dev) if with_hm else None
+        plan['inputs'] = (x_in, img_in, hm_in)
+        s0 = alloc(H, W, 16)
+        L.append(_Launch('stem', 'stem', (x_in, img_in, hm_in, s0), ()))
+        l0 = add_conv('level0', s0, P['level0'], 16, 3, out=alloc(H, W, 16))
+        l1 = add_conv('level1', l0, P['level1'], 32, 3, stride=2, out=alloc(H // 2, W // 2, 32))
+
+        def leaf(name, x, pk, cin, cout, stride, R, out, bottom=None, level_root=False):
+            """Tree(levels=1).forward (dla.py:215-228) over the concat buffer R = [x2 | x1 | children]."""
+            h, w = x.H // stride, x.W // stride
+            if stride > 1 and bottom is None:
+                bottom = R.slice(2 * cout, cin) if level_root else alloc(h, w, cin)
+                L.append(_Launch(name + '.pool', 'pool', (x, bottom)))
+            elif stride == 1:
+                bottom = x
+            if cin != cout:
+                residual = add_conv(name + '.project', bottom, pk['proj'], cout, 1, relu=False, out=alloc(h, w, cout))
+            else:
+                residual = bottom
+            t = alloc(h, w, cout)
+            x1 = R.slice(cout, cout)
+            x2 = R.slice(0, cout)
+            add_conv(name + '.t1.conv1', x, pk['c11'], cout, 3, stride=stride, out=t)
+            add_conv(name + '.t1.conv2', t, pk['c12'], cout, 3, res=residual, out=x1)
+            add_conv(name + '.t2.conv1', x1, pk['c21'], cout, 3, out=t)
+            add_conv(name + '.t2.conv2', t, pk['c22'], cout, 3, res=x1, out=x2)
+            add_conv(name + '.root', View(R.buf, R.c0, R.C), pk['root'], cout, 1, out=out)
+            return out
+
+        feats = [l0, l1]
+        x = l1
+        for i in range(2, 6):
+            p = 'base.level%d' % i
+            cin, cout = CHANNELS[i - 1], CHANNELS[i]
+            h, w = x.H // 2, x.W // 2
+            out = alloc(h, w, cout)
+            level_root = i >= 3
+            if LEVELS[i] == 1:
+                R = alloc(h, w, 2 * cout + (cin if level_root else 0))
+                leaf(p, x, P[p], cin, cout, 2, R, out, level_root=level_root)
+            else:
+                # Tree(levels=2): R2 = [y2 | y1 | bottom | x1]; the outer project is dead code (dla.py:218)
+                R2 = alloc(h, w, 3 * cout + cin)
+                bottom = R2.slice(2 * cout, cin)
+                L.append(_Launch(p + '.pool', 'pool', (x, bottom)))
+                x1 = R2.slice(2 * cout + cin, cout)
+                R1 = alloc(h, w, 2 * cout)
+                leaf(p + '.tree1', x, P[p + '.tree1'], cin, cout, 2, R1, x1, bottom=bottom)
+                leaf(p + '.tree2', x1, P[p + '.tree2'], cout, cout, 1, R2, out)
+            feats.append(out)
+            x = out
+
+        om_bufs = {}
+
+        def deform(name, x, cout, out):
+            """DeformConv.forward (dla.py:515-518): offset/mask conv -> DCNv2 -> BN -> ReLU"""
+            pk = P[name]
+            key = (x.H, x.W)
+            if key not in om_bufs:
+                om_bufs[key] = ops.new_view(N, x.H, x.W, 32, dev)
+            om = om_bufs[key]
+            d = ops.make_conv_desc(x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
+            plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
+            L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk)))
+            dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out)
+            plan['ws_need'] = max(plan['ws_need'], lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd)))
+            L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk)))
+            return out
+
+        def ida(p, layers, startp, endp, o, up_f):
+            """IDAUp.forward (dla.py:539-545)"""
+            for i in range(startp + 1, endp):
+                k = i - startp
+                f = up_f[k]
+                xi = layers[i]
+                pr = deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o))
+                up = alloc(xi.H * f, xi.W * f, o)
+                L.append(_Launch('%s.up_%d' % (p, k), 'up', (pr, P['%s.up_%d' % (p, k)], f, layers[i - 1], up)))
+                layers[i] = deform('%s.node_%d' % (p, k), up, o, alloc(up.H, up.W, o))
+
+        layers = list(feats)                                   # DLAUp.forward, dla.py:568-574
+        outs = [layers[-1]]
+        ida('dla_up.ida_0', layers, 4, 6, 256, [1, 2]); outs.insert(0, layers[-1])
+        ida('dla_up.ida_1', layers, 3, 6, 128, [1, 2, 2]); outs.insert(0, layers[-1])
+        ida('dla_up.ida_2', layers, 2, 6, 64, [1, 2, 2, 2]); outs.insert(0, layers[-1])
+        y = [outs[0], outs[1], outs[2]]                        # DLASeg.imgpre2feats, dla.py:631-640
+        ida('ida_up', y, 0, 3, 64, [1, 2, 4])
+        feat = y[-1]
+        plan['feat'] = feat
+
+        nh = len(self.heads)
+        hc = self.head_conv
+        mid = alloc(feat.H, feat.W, hc * nh)
+        d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid)
+        L.append(_Launch('heads.0', 'conv', d, (feat, mid)))
+        outputs = OrderedDict()
+        for j, (hname, c) in enumerate(self.heads.items()):
+            o = torch.empty((N, c, feat.H, feat.W), device=dev)
+            wp, b = P[hname + '.2']
+            sig = (0, c) if (fuse_sigmoid and hname in ('hm', 'hm_hp')) else (0, 0)
+            dep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
+            d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=sig, dep=dep,
+                                   depth_scale=self.depth_scale)
+            plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
+            L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o)))
+            outputs[hname] = o
+        plan['outputs'] = outputs
+        ws = torch.empty(max(plan['ws_need'], 16) // 4, dtype=torch.float32, device=dev)
+        plan['ws'] = ws
+        for l in L:
+            if l.fn in ('conv', 'dcn'):
+                l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        return plan
+
+    def _run_plan(self, plan):
+        P = self._prepared
+        lib = _lib.load()
+        st = _lib.stream_ptr()
+        for l in plan['launches']:
+            if l.fn == 'conv':
+                rc = lib.ct_conv2d(ctypes.byref(l.args), st)
+            elif l.fn == 'dcn':
+                rc = lib.ct_dcn_v2(ctypes.byref(l.args), st)
+            elif l.fn == 'pool':
+                x, y = l.args
+                rc = lib.ct_maxpool2x2(x.ptr, x.N, x.H, x.W, x.C, x.ld, y.ptr, y.ld, st)
+            elif l.fn == 'up':
+                x, w, f, skip, y = l.args
+                rc = lib.ct_upsample_add(x.ptr, x.N, x.H, x.W, x.C, x.ld, w.data_ptr(), f, skip.ptr, skip.ld,
+                                         y.ptr, y.ld, st)
+            elif l.fn == 'stem':
+                x, img, hm, y = l.args
+                w = P['stem_w']
+                rc = lib.ct_stem_forward(x.data_ptr(), ops._p(img), ops._p(hm), x.shape[0], x.shape[2], x.shape[3],
+                                         w[0].data_ptr(), ops._p(w[1]) if img is not None else None,
+                                         ops._p(w[2]) if hm is not None else None,
+                                         P['stem_scale'].data_ptr(), P['stem_shift'].data_ptr(), y.ptr, y.ld, st)
+            else:
+                raise AssertionError(l.fn)
+            if rc != 0:
+                _lib.check(rc, l.name)
+
+    def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False):
+        key = (N, H, W, with_img, with_hm, fuse_sigmoid)
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(*key)
+        return self._plans[key]
+
+    def forward_plan(self, plan, x, pre_img=None, pre_hm=None):
+        """Copy the inputs into the plan's static buffers and enqueue all launches."""
+        xi, ii, hi = plan['inputs']
+        xi.copy_(x)
+        if ii is not None:
+            ii.copy_(pre_img)
+        if hi is not None:
+            hi.copy_(pre_hm)
+        self._run_plan(plan)
+        return plan['outputs']
+
+    @torch.no_grad()
+    def forward(self, x, pre_img=None, pre_hm=None, fuse_sigmoid=False):
+        """Reference signature (base_model.py:73): returns ``[ {head: tensor[B,c,h,w]} ]``
+        (raw logits unless ``fuse_sigmoid``, in which case hm / dep carry the transforms of
+        ``Detector._sigmoid_output``, detector.py:300-308).  Outputs are fresh tensors."""
+        if pre_img is not None and not self.pre_img:
+            raise _lib.CTError('model was built with pre_img=False')
+        if pre_hm is not None and not self.pre_hm:
+            raise _lib.CTError('model was built with pre_hm=False')
+        N, _, H, W = x.shape
+        plan = self.get_plan(N, H, W, pre_img is not None, pre_hm is not None, fuse_sigmoid)
+        out = self.forward_plan(plan, x, pre_img, pre_hm)
+        z = OrderedDict((k, v.clone()) for k, v in out.items())
+        if self.model_output_list:
+            return [[z[h] for h in sorted(self.heads)]]
+        return [z]
+
+
+def create_model(arch, head, head_conv, opt=None):
+    """reference model.py:24-29; only the published architecture ``dla_34`` exists here."""
+    if arch != 'dla_34':
+        raise ValueError('centertrack_amd implements arch "dla_34" only (got %r)' % arch)
+    if opt is not None and getattr(opt, 'dla_node', 'dcn') != 'dcn':
+        raise ValueError('only dla_node="dcn" is implemented')
+    if opt is not None and getattr(opt, 'head_kernel', 3) != 3:
+        raise ValueError('only head_kernel=3 is implemented')
+    return DLASegHIP(head, head_conv,
+                     pre_img=getattr(opt, 'pre_img', True) if opt is not None else True,
+                     pre_hm=getattr(opt, 'pre_hm', True) if opt is not None else True,
+                     depth_scale=getattr(opt, 'depth_scale', 1.0) if opt is not None else 1.0,
+                     model_output_list=getattr(opt, 'model_output_list', False) if opt is not None else False)
+
+
+def load_model(model, model_path, opt=None, optimizer=None):
+    """reference model.py:31-90 (inference part): ``{'epoch', 'state_dict'}`` checkpoint,
+    ``module.`` prefix stripped, unknown keys dropped, missing / mis-shaped keys keep init."""
+    ckpt = torch.load(model_path, map_location='cpu')
+    sd_in = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+    sd = {}
+    for k, v in sd_in.items():
+        sd[k[7:] if k.startswith('module') and not k.startswith('module_list') else k] = v
+    own = model.state_dict()
+    keep = {}
+    for k, v in sd.items():
+        if k in own:
+            if tuple(v.shape) == tuple(own[k].shape):
+                keep[k] = v
+            else:
+                print('Skip loading parameter {}, required shape{}, loaded shape{}.'.format(
+                    k, tuple(own[k].shape), tuple(v.shape)))
+        else:
+            print('Drop parameter {}.'.format(k))
+    for k in own:
+        if k not in keep:
+            print('No param {}.'.format(k))
+    model.load_state_dict(keep, strict=False)
+    return model

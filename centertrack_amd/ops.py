@@ -1,0 +1,231 @@
+"""Tensor-level wrappers over the C ABI (torch is only the allocator / stream owner).
+
+``View`` = an NHWC fp32 activation living in (a channel slice of) a contiguous
+``[N,H,W,ld]`` buffer; every op reads / writes views so concatenations
+(reference ``Root.forward``, dla.py:164-166) never copy."""
+import ctypes
+
+import torch
+
+from . import _lib
+from ._lib import CT_OUT_NCHW, CT_RELU, ConvDesc, DcnDesc, DecodeDesc
+
+
+class View(object):
+    __slots__ = ('buf', 'c0', 'C')
+
+    def __init__(self, buf, c0=0, C=None):
+        assert buf.dim() == 4 and buf.is_contiguous() and buf.dtype == torch.float32
+        self.buf = buf
+        self.c0 = c0
+        self.C = buf.shape[3] - c0 if C is None else C
+        assert 0 <= c0 and c0 + self.C <= buf.shape[3]
+
+    N = property(lambda s: s.buf.shape[0])
+    H = property(lambda s: s.buf.shape[1])
+    W = property(lambda s: s.buf.shape[2])
+    ld = property(lambda s: s.buf.shape[3])
+    ptr = property(lambda s: s.buf.data_ptr() + 4 * s.c0)
+
+    def slice(self, c0, C):
+        return View(self.buf, self.c0 + c0, C)
+
+    def to_nchw(self):
+        """torch view (no copy) of the slice as [N,C,H,W] -- for tests / debugging."""
+        return self.buf[..., self.c0:self.c0 + self.C].permute(0, 3, 1, 2)
+
+
+def new_view(N, H, W, C, device, ld=None):
+    return View(torch.empty((N, H, W, ld or C), dtype=torch.float32, device=device), 0, C)
+
+
+def view_from_nchw(x):
+    """NCHW torch tensor -> fresh NHWC view via the HIP converter."""
+    N, C, H, W = x.shape
+    x = x.contiguous().float()
+    ld = (C + 3) // 4 * 4
+    v = View(torch.zeros((N, H, W, ld), dtype=torch.float32, device=x.device), 0, C)
+    _lib.check(_lib.load().ct_nchw_to_nhwc(x.data_ptr(), N, C, H, W, v.ptr, v.ld, _lib.stream_ptr()),
+               'ct_nchw_to_nhwc')
+    return v
+
+
+def view_to_nchw(v):
+    out = torch.empty((v.N, v.C, v.H, v.W), dtype=torch.float32, device=v.buf.device)
+    _lib.check(_lib.load().ct_nhwc_to_nchw(v.ptr, v.N, v.C, v.H, v.W, v.ld, out.data_ptr(), _lib.stream_ptr()),
+               'ct_nhwc_to_nchw')
+    return out
+
+
+def pack_weight(w):
+    """OIHW conv weight (cuda, fp32) -> MFMA fragment layout (see centertrack_hip.h)."""
+    lib = _lib.load()
+    w = w.contiguous().float()
+    Cout, Cin, ks, ks2 = w.shape
+    assert ks == ks2 and Cin % 16 == 0, 'Cin must be a multiple of 16'
+    out = torch.empty(lib.ct_packed_weight_elems(Cout, Cin, ks), dtype=torch.float32, device=w.device)
+    _lib.check(lib.ct_pack_conv_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, ks, _lib.stream_ptr()),
+               'ct_pack_conv_weight')
+    return out
+
+
+def _p(t):
+    return None if t is None else t.data_ptr()
+
+
+def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, relu=False, out=None,
+                   out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0):
+    d = ConvDesc()
+    d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
+    d.w_packed, d.Cout, d.ks, d.stride = wp.data_ptr(), Cout, ks, stride
+    d.scale, d.shift = _p(scale), _p(shift)
+    if res is not None:
+        d.res, d.ldr = res.ptr, res.ld
+    flags = CT_RELU if relu else 0
+    if out_nchw is not None:
+        assert out is None and out_nchw.is_contiguous()
+        d.y, d.ldy = out_nchw.data_ptr(), 0
+        flags |= CT_OUT_NCHW
+    else:
+        d.y, d.ldy = out.ptr, out.ld
+    d.flags = flags
+    d.sig_lo, d.sig_hi = sig
+    d.dep_lo, d.dep_hi = dep
+    d.depth_scale = depth_scale
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    d.split_k = split_k
+    return d
+
+
+def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
+    """y = act(conv(x) * scale + shift + res); allocates the output view if not given."""
+    lib = _lib.load()
+    pad = ks // 2
+    Ho = (x.H + 2 * pad - ks) // stride + 1
+    Wo = (x.W + 2 * pad - ks) // stride + 1
+    if out is None and kw.get('out_nchw') is None:
+        out = new_view(x.N, Ho, Wo, Cout, x.buf.device, ld=(Cout + 3) // 4 * 4)
+    d = make_conv_desc(x, wp, Cout, ks, stride, out=out, **kw)
+    if d.workspace is None and kw.get('split_k', 0) != 1:
+        need = lib.ct_conv2d_workspace_bytes(ctypes.byref(d))
+        if need:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=x.buf.device)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), need
+            kw['_keep'] = ws
+    _lib.check(lib.ct_conv2d(ctypes.byref(d), _lib.stream_ptr()), 'ct_conv2d')
+    return out if out is not None else kw['out_nchw']
+
+
+def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0):
+    d = DcnDesc()
+    d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
+    d.om, d.ldom = om.ptr, om.ld
+    d.w_packed, d.Cout = wp.data_ptr(), Cout
+    d.scale, d.shift = _p(scale), _p(shift)
+    d.y, d.ldy = out.ptr, out.ld
+    d.flags = CT_RELU if relu else 0
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    d.split_k = split_k
+    return d
+
+
+def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0):
+    lib = _lib.load()
+    if out is None:
+        out = new_view(x.N, x.H, x.W, Cout, x.buf.device)
+    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k)
+    ws = None
+    if split_k != 1:
+        need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))
+        if need:
+            ws = torch.empty(need // 4, dtype=torch.float32, device=x.buf.device)
+            d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    _lib.check(lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()), 'ct_dcn_v2')
+    return out
+
+
+def stem(x, pre_img, pre_hm, w_x, w_img, w_hm, scale3, shift3, out=None):
+    N, _, H, W = x.shape
+    if out is None:
+        out = new_view(N, H, W, 16, x.device)
+    _lib.check(_lib.load().ct_stem_forward(
+        x.data_ptr(), _p(pre_img), _p(pre_hm), N, H, W, w_x.data_ptr(), _p(w_img), _p(w_hm),
+        scale3.data_ptr(), shift3.data_ptr(), out.ptr, out.ld, _lib.stream_ptr()), 'ct_stem_forward')
+    return out
+
+
+def maxpool2x2(x, out=None):
+    if out is None:
+        out = new_view(x.N, x.H // 2, x.W // 2, x.C, x.buf.device)
+    _lib.check(_lib.load().ct_maxpool2x2(x.ptr, x.N, x.H, x.W, x.C, x.ld, out.ptr, out.ld, _lib.stream_ptr()),
+               'ct_maxpool2x2')
+    return out
+
+
+def upsample_add(x, w, f, skip, out=None):
+    if out is None:
+        out = new_view(x.N, x.H * f, x.W * f, x.C, x.buf.device)
+    _lib.check(_lib.load().ct_upsample_add(x.ptr, x.N, x.H, x.W, x.C, x.ld, w.data_ptr(), f, skip.ptr, skip.ld,
+                                           out.ptr, out.ld, _lib.stream_ptr()), 'ct_upsample_add')
+    return out
+
+
+# field order of a packed decode row after (score, cls, xs0, ys0)
+_DECODE_REST = ['tracking', 'dep', 'rot', 'dim', 'amodel_offset', 'nuscenes_att', 'velocity']
+
+
+def decode_layout(head_names):
+    """[(field, start, width)] of one packed row, mirroring ct_decode_row_floats."""
+    names = set(head_names)
+    lay = [('scores', 0, 1), ('clses', 1, 1), ('xs', 2, 1), ('ys', 3, 1)]
+    f = 4
+    if names & {'wh', 'ltrb', 'ltrb_amodal'}:
+        lay.append(('bboxes', f, 4)); f += 4
+    if 'ltrb_amodal' in names:
+        lay.append(('bboxes_amodal', f, 4)); f += 4
+    for n in _DECODE_REST:
+        if n in names:
+            lay.append((n, f, _lib.HEAD_CH[n])); f += _lib.HEAD_CH[n]
+    return lay, f
+
+
+class Decoder(object):
+    """Pre-built ct_decode call for fixed shapes (graph-capture friendly)."""
+
+    def __init__(self, hm, heads, K):
+        lib = _lib.load()
+        self.K = K
+        B, C, h, w = hm.shape
+        self.hm, self.heads = hm, dict(heads)
+        d = DecodeDesc()
+        d.hm, d.B, d.C, d.h, d.w, d.K = hm.data_ptr(), B, C, h, w, K
+        for name, t in heads.items():
+            if name in _lib.HEAD_INDEX:
+                assert t.is_contiguous() and t.shape[1] == _lib.HEAD_CH[name], name
+                d.heads[_lib.HEAD_INDEX[name]] = t.data_ptr()
+        self.layout, self.F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX])
+        assert lib.ct_decode_row_floats(ctypes.byref(d)) == self.F
+        self.out = torch.empty((B, K, self.F), dtype=torch.float32, device=hm.device)
+        self.inds = torch.empty((B, K), dtype=torch.int64, device=hm.device)
+        nbytes = lib.ct_decode_workspace_bytes(ctypes.byref(d))
+        if nbytes == 0:
+            _lib.check(1, 'ct_decode_workspace_bytes')
+        self.ws = torch.empty(nbytes // 8, dtype=torch.int64, device=hm.device)
+        d.out, d.inds = self.out.data_ptr(), self.inds.data_ptr()
+        d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        self.desc = d
+
+    def run(self):
+        _lib.check(_lib.load().ct_decode(ctypes.byref(self.desc), _lib.stream_ptr()), 'ct_decode')
+        return self.out
+
+    def unpack(self, packed):
+        """packed [B,K,F] (torch or numpy) -> the reference's ``dets`` dict (decode.py:99-180)."""
+        ret = {}
+        for name, s, wd in self.layout:
+            v = packed[..., s:s + wd]
+            ret[name] = v[..., 0] if name in ('scores', 'clses', 'xs', 'ys') else v
+        ret['cts'] = packed[..., 2:4]
+        return ret

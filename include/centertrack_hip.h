@@ -1,0 +1,143 @@
+/*
+ * centertrack_hip.h -- C ABI of libcentertrack_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary B5 of SURVEY.md section 8(b): these entry points are what the reference's
+ * Python hot path binds instead of its PyTorch/cuDNN ops and the un-vendored DCNv2
+ * CUDA extension.  Each function cites the reference interface it replaces
+ * (paths relative to xingyizhou/CenterTrack).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (torch's allocator); the
+ *     library never allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream); graph-capture safe.
+ *   - return 0 on success, non-zero (CT_ERR_*) on error; ct_last_error() describes it.
+ *   - activations inside the pipeline are fp32 NHWC "views": base pointer already
+ *     offset to the first channel, `ld` = channel pitch in floats (>= C), so a
+ *     layer can read/write a channel slice of a wider concat buffer in place
+ *     (replaces torch.cat in Root.forward, dla.py:166).  Model inputs/outputs at the
+ *     boundary are the reference's NCHW fp32 tensors.
+ */
+#ifndef CENTERTRACK_HIP_H
+#define CENTERTRACK_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CT_OK 0
+#define CT_ERR_ARG 1      /* bad shape / alignment / unsupported configuration */
+#define CT_ERR_LAUNCH 2   /* hipLaunch failure (message holds hipGetErrorString) */
+#define CT_ERR_WORKSPACE 3
+
+/* epilogue flags */
+#define CT_RELU 1
+#define CT_OUT_NCHW 2      /* write y as NCHW [N,Cout,Ho,Wo] instead of an NHWC view */
+
+const char *ct_last_error(void);
+int ct_version(void);
+
+/* ---- weight packing ---------------------------------------------------------------
+ * MFMA-ready layout [tap][Cin/16][CoutPad/16][4][16][4] (CoutPad = Cout rounded up to
+ * 16, zero filled): for one (tap, 16-channel slab, 16-cout tile) the 64 lanes of a wave
+ * read one contiguous 1 KiB block, lane l holding cout (l&15), channels 4*(l>>4)..+3.
+ * Source: the reference's OIHW conv weight (nn.Conv2d.weight / DCN.weight,
+ * dla.py:38-66,154-172,506-518; base_model.py:24-40).  Cin must be a multiple of 16. */
+size_t ct_packed_weight_elems(int Cout, int Cin, int ks);
+int ct_pack_conv_weight(const float *w_oihw, float *packed, int Cout, int Cin, int ks, void *stream);
+
+/* ---- dense convolution (implicit GEMM on fp32 MFMA) -------------------------------
+ * Replaces nn.Conv2d + eval-mode nn.BatchNorm2d (+ residual add) (+ ReLU) of BasicBlock /
+ * Root / Tree.project / _make_conv_level (dla.py:38-66,154-172,206-213,293-303), the
+ * DCN offset/mask conv (upstream dcn_v2.py DCN.conv_offset_mask) and the head convs
+ * (base_model.py:24-65,86-90; sigmoid / depth transform of detector.py:300-308 fused).
+ *   y = act( conv(x, w) * scale[c] + shift[c] + res )   ks in {1,3}, stride in {1,2},
+ *   pad = ks/2; scale/shift NULL => 1/0.  Channels [sig_lo,sig_hi) get a sigmoid,
+ *   channels [dep_lo,dep_hi) get 1/(sigmoid(v)+1e-6)-1 times depth_scale.  */
+typedef struct ct_conv_desc {
+    const float *x; int N, H, W, Cin, ldx;
+    const float *w_packed; int Cout, ks, stride;
+    const float *scale; const float *shift;
+    const float *res; int ldr;
+    float *y; int ldy;
+    int flags;
+    int sig_lo, sig_hi;
+    int dep_lo, dep_hi; float depth_scale;
+    float *workspace; size_t workspace_bytes;   /* split-K partials; may be NULL (no split) */
+    int split_k;                                /* 0 = choose automatically */
+} ct_conv_desc;
+int ct_conv2d(const ct_conv_desc *d, void *stream);
+size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);
+
+/* ---- modulated deformable convolution v2 (3x3, stride 1, pad 1, dil 1, dg 1) -------
+ * Replaces DCNv2's _ext.dcn_v2_forward (modulated_deformable_im2col + SGEMM; upstream
+ * src/cuda/dcn_v2_cuda.cu, dcn_v2_im2col_cuda.cu) as called from DeformConv.forward,
+ * dla.py:513-518, with the following BatchNorm + ReLU fused:
+ *   y[p,co] = act( (sum_{k,ci} W[co,ci,k] * m_k(p) * bilinear(x[.,ci], p + tap_k + d_k(p)))
+ *                  * scale[co] + shift[co] )      (DCN bias folded into shift by the caller)
+ * `om` is the NHWC offset/mask map [N,H,W,>=27] (ld = ldom): channels 2k,2k+1 = (dy,dx)
+ * of tap k, channel 18+k = mask AFTER sigmoid (produced by ct_conv2d with sig_lo=18). */
+typedef struct ct_dcn_desc {
+    const float *x; int N, H, W, Cin, ldx;
+    const float *om; int ldom;
+    const float *w_packed; int Cout;
+    const float *scale; const float *shift;
+    float *y; int ldy;
+    int flags;                                  /* CT_RELU */
+    float *workspace; size_t workspace_bytes;
+    int split_k;
+} ct_dcn_desc;
+int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
+size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
+
+/* ---- the three 7x7 stems, fused --------------------------------------------------
+ * Replaces DLA.forward's base_layer / pre_img_layer / pre_hm_layer and their sum
+ * (dla.py:238-267,305-311): y = sum_s relu(bn_s(conv7x7_s(in_s))), inputs NCHW
+ * ([N,3,H,W], [N,3,H,W] or NULL, [N,1,H,W] or NULL), output NHWC [N,H,W,16] (ld = ldy).
+ * w_s: OIHW [16,Cin_s,7,7]; scale_s/shift_s: folded BN [16]. */
+int ct_stem_forward(const float *x, const float *pre_img, const float *pre_hm, int N, int H, int W,
+                    const float *w_x, const float *w_img, const float *w_hm,
+                    const float *scale3, const float *shift3,   /* [3][16] each */
+                    float *y, int ldy, void *stream);
+
+/* ---- glue ops ---------------------------------------------------------------------- */
+/* nn.MaxPool2d(2,2) of Tree.downsample (dla.py:207-208,216), NHWC views */
+int ct_maxpool2x2(const float *x, int N, int H, int W, int C, int ldx, float *y, int ldy, void *stream);
+/* IDAUp step `up(proj) + skip` (dla.py:529-532,543-545): depth-wise ConvTranspose2d
+ * (kernel 2f, stride f, padding f/2, groups=C, no bias; w = [C,1,2f,2f]) of x [N,H,W,C]
+ * plus skip [N,fH,fW,C] -> y [N,fH,fW,C] */
+int ct_upsample_add(const float *x, int N, int H, int W, int C, int ldx, const float *w, int f,
+                    const float *skip, int lds, float *y, int ldy, void *stream);
+/* layout converters for the NCHW drop-in ops */
+int ct_nchw_to_nhwc(const float *x, int N, int C, int H, int W, float *y, int ldy, void *stream);
+int ct_nhwc_to_nchw(const float *x, int N, int C, int H, int W, int ldx, float *y, void *stream);
+
+/* ---- heat-map decode ----------------------------------------------------------------
+ * Replaces generic_decode (src/lib/model/decode.py:83-182, non-pose heads) with its
+ * helpers _nms / _topk / _tranpose_and_gather_feat (src/lib/model/utils.py:16-87):
+ * 3x3 max-pool pseudo-NMS, exact top-K over all classes/pixels (ties: lower class, then
+ * lower pixel index first), gathers of every regression head, box assembly, into ONE
+ * packed buffer (replaces the 8-14 D2H copies of detector.py:349-350).
+ * hm: NCHW [B,C,h,w] post-sigmoid.  heads[i]: NCHW [B,head_ch[i],h,w] or NULL.
+ * Head order / packed layout: see ct_decode_layout(). */
+enum { CT_HEAD_REG = 0, CT_HEAD_WH, CT_HEAD_TRACKING, CT_HEAD_LTRB, CT_HEAD_LTRB_AMODAL,
+       CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET, CT_HEAD_NUSCENES_ATT,
+       CT_HEAD_VELOCITY, CT_NUM_HEADS };
+typedef struct ct_decode_desc {
+    const float *hm; int B, C, h, w, K;
+    const float *heads[CT_NUM_HEADS];
+    float *out;                /* [B,K,F] floats, F = ct_decode_row_floats(heads present) */
+    int64_t *inds;             /* [B,K] flat pixel indices (may be NULL) */
+    void *workspace; size_t workspace_bytes;
+} ct_decode_desc;
+/* row layout: score, cls, xs0, ys0, then for each present field in this order:
+ * bbox[4] (if wh|ltrb|ltrb_amodal), bbox_amodal[4] (if ltrb_amodal), tracking[2], dep[1],
+ * rot[8], dim[3], amodel_offset[2], nuscenes_att[8], velocity[3] */
+int ct_decode_row_floats(const ct_decode_desc *d);
+size_t ct_decode_workspace_bytes(const ct_decode_desc *d);
+int ct_decode(const ct_decode_desc *d, void *stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,111 @@
+"""GPU end-to-end: the drop-in Detector over a synthetic stream reproduces the reference's
+results (golden e2e_mot.json = reference Detector.run; oracle detector run live):
+track IDs / classes bit-exact, scores / boxes within 1e-3."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_frame(res, ref, t, tag):
+    ids, rids = [int(r['tracking_id']) for r in res], [int(r['tracking_id']) for r in ref]
+    assert ids == rids, '%s frame %d: track ids differ\n got %s\nwant %s' % (tag, t, ids, rids)
+    assert [int(r['class']) for r in res] == [int(r['class']) for r in ref]
+    for a, b in zip(res, ref):
+        assert int(a['age']) == int(b['age']) and int(a['active']) == int(b['active'])
+        np.testing.assert_allclose(float(a['score']), float(np.asarray(b['score'])), atol=1e-3)
+        for k in ('ct', 'bbox', 'tracking'):
+            np.testing.assert_allclose(np.asarray(a[k], np.float64), np.asarray(b[k], np.float64), atol=2e-2,
+                                       err_msg='%s frame %d %s' % (tag, t, k))
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_detector_stream_matches_reference(device, golden_dir, use_graph):
+    from centertrack_amd import scenarios as S
+    from centertrack_amd.detector import Detector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    from oracle import detector as odet
+    g = json.load(open(os.path.join(golden_dir, 'e2e_mot.json')))
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    det = Detector(opt, model=model, use_graph=use_graph)
+    oopt = odet.default_opt(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
+                            input_h=cfg['H'], input_w=cfg['W'])
+    oracle = odet.Detector(oopt, sd, cfg['heads'])
+    for t, (images, meta) in enumerate(S.e2e_frames(cfg)):
+        ret = det.run(images, dict(meta))
+        for key in ('results', 'tot', 'load', 'pre', 'net', 'dec', 'post', 'merge', 'track', 'display'):
+            assert key in ret
+        want = oracle.run(images, dict(meta))
+        # decode-level: top-K indices above threshold bit-exact vs the oracle
+        od = oracle.last_dets
+        n = int((od['scores'][0] >= oopt.out_thresh).sum())
+        gd = det.impl.last_dets
+        np.testing.assert_array_equal(gd['xs'][0, :n], od['xs'][0, :n])
+        np.testing.assert_array_equal(gd['ys'][0, :n], od['ys'][0, :n])
+        np.testing.assert_array_equal(gd['clses'][0, :n], od['clses'][0, :n])
+        np.testing.assert_allclose(gd['scores'][0, :n], od['scores'][0, :n], atol=1e-3)
+        _check_frame(ret['results'], want, t, 'oracle')
+        _check_frame(ret['results'], g['frames'][t], t, 'golden')
+    det.reset_tracking()
+    assert det.tracker.id_count == 0 and det.tracker.tracks == []
+
+
+def test_batched_streams_equal_single_streams(device):
+    """3 streams advanced together give, per stream, what a lone detector gives (IDs exact)."""
+    from centertrack_amd import scenarios as S
+    from centertrack_amd.detector import StreamDetector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    frames = list(S.e2e_frames(cfg))
+    B = 2
+    multi = StreamDetector(opt, model=model, num_streams=B)
+    singles = [StreamDetector(opt, model=model, num_streams=1) for _ in range(B)]
+    for t in range(len(frames) - B + 1):
+        imgs = torch.cat([frames[t + s][0] for s in range(B)], 0)
+        metas = [dict(frames[t + s][1]) for s in range(B)]
+        got = multi.step(imgs, metas)
+        for s in range(B):
+            want = singles[s].step(frames[t + s][0], [dict(frames[t + s][1])])[0]
+            assert [int(r['tracking_id']) for r in got[s]] == [int(r['tracking_id']) for r in want]
+            for a, b in zip(got[s], want):
+                np.testing.assert_allclose(np.asarray(a['bbox']), np.asarray(b['bbox']), atol=1e-2)
+
+
+def test_flip_test_runs_and_matches_oracle(device):
+    from centertrack_amd import weights as W
+    from centertrack_amd.detector import Detector, default_opt
+    from centertrack_amd.image import make_meta
+    from centertrack_amd.model import DLASegHIP
+    from oracle import detector as odet
+    heads = W.KITTI_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=9, hm_gain=14.0)
+    opt = default_opt(heads, track_thresh=0.4, flip_test=True)
+    model = DLASegHIP(heads)
+    model.load_state_dict(sd)
+    det = Detector(opt, model=model)
+    oopt = odet.default_opt(track_thresh=0.4, flip_test=True, input_h=64, input_w=160, num_classes=3)
+    oracle = odet.Detector(oopt, sd, heads)
+    meta = make_meta(64, 160, 375, 1242)
+    g = torch.Generator().manual_seed(3)
+    for t in range(2):
+        img = torch.randn((1, 3, 64, 160), generator=g)
+        ret = det.run(img, dict(meta))
+        both = torch.cat((img, torch.flip(img, [3])), 0)
+        want = oracle.run(both, dict(meta))
+        od, gd = oracle.last_dets, det.impl.last_dets
+        n = int((od['scores'][0] >= oopt.out_thresh).sum())
+        np.testing.assert_array_equal(gd['xs'][0, :n], od['xs'][0, :n])
+        np.testing.assert_array_equal(gd['clses'][0, :n], od['clses'][0, :n])
+        assert [int(r['tracking_id']) for r in ret['results']] == [int(r['tracking_id']) for r in want]

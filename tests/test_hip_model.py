@@ -1,0 +1,112 @@
+"""GPU parity of the whole HIP forward (stems -> DLA-34 -> DCN neck -> heads) against the
+CPU oracle (oracle/dla34.py, itself pinned to the reference by tests/golden) and against
+the reference golden vectors directly."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _report(name, got, want):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    err = (got - want).abs()
+    return '%-28s max_abs_err %.3e  (ref absmax %.3f)' % (name, float(err.max()), float(want.abs().max()))
+
+
+@pytest.mark.parametrize('name,shape,off_std', [('mot', (1, 64, 96), 0.01), ('nusc', (2, 64, 64), 0.01),
+                                                ('mot', (1, 128, 160), 0.1)])
+def test_forward_matches_oracle(device, golden_dir, name, shape, off_std):
+    from centertrack_amd import weights as W
+    from centertrack_amd.model import DLASegHIP
+    from oracle import dla34
+    heads = W.MOT_HEADS if name == 'mot' else W.NUSC_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=317, off_std=off_std)
+    x, pre, hm = W.synthetic_inputs(*shape, seed=317)
+    model = DLASegHIP(heads)
+    assert set(model.state_dict().keys()) == set(sd.keys())
+    model.load_state_dict(sd)
+    model = model.to(device)
+    got = model(x.to(device), pre.to(device), hm.to(device))[-1]
+    torch.cuda.synchronize()
+    with torch.no_grad():
+        feat = dla34.dla_seg_features(x, pre, hm, sd)
+        want = dla34.apply_heads(feat, heads, sd)
+    # intermediate report first (so a failure localises itself)
+    plan = model.get_plan(shape[0], shape[1], shape[2], True, True, False)
+    lines = [_report('feature', plan['feat'].to_nchw(), feat)]
+    for k in heads:
+        lines.append(_report('head ' + k, got[k], want[k]))
+    print('\n'.join(lines))
+    np.testing.assert_allclose(plan['feat'].to_nchw().cpu().numpy(), feat.numpy(), atol=1e-3, rtol=1e-3)
+    for k in heads:
+        np.testing.assert_allclose(got[k].cpu().numpy(), want[k].numpy(), atol=1e-3, rtol=1e-3, err_msg=k)
+    if off_std == 0.01 and shape[1] == 64:
+        g = np.load(os.path.join(golden_dir, 'model_forward.npz'))
+        for k in heads:
+            np.testing.assert_allclose(got[k].cpu().numpy(), g['%s.%s' % (name, k)], atol=1e-3, rtol=1e-3,
+                                       err_msg='golden ' + k)
+        got2 = model(x.to(device), pre.to(device), None)[-1]
+        np.testing.assert_allclose(got2['hm'].cpu().numpy(), g[name + '_nohm.hm'], atol=1e-3, rtol=1e-3)
+
+
+def test_backbone_levels_match_oracle(device):
+    """level-by-level check of the DLA backbone outputs (localises a bad layer)."""
+    from centertrack_amd import weights as W
+    from centertrack_amd.model import DLASegHIP
+    from oracle import dla34
+    heads = W.MOT_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=11)
+    x, pre, hm = W.synthetic_inputs(1, 64, 96, seed=11)
+    model = DLASegHIP(heads)
+    model.load_state_dict(sd)
+    model = model.to(device)
+    model(x.to(device), pre.to(device), hm.to(device))
+    torch.cuda.synchronize()
+    plan = model.get_plan(1, 64, 96, True, True, False)
+    with torch.no_grad():
+        base = dla34.dla_base(x, pre, hm, sd)
+        ups = dla34.dla_up(base, sd)
+    outs = {}
+    for l in plan['launches']:
+        if l.fn == 'conv' and len(l.keep) > 2 and hasattr(l.keep[2], 'to_nchw'):
+            outs[l.name] = l.keep[2]
+        if l.fn == 'dcn':
+            outs[l.name] = l.keep[2]
+    names = ['level0', 'level1', 'base.level2.root', 'base.level3.tree2.root', 'base.level4.tree2.root',
+             'base.level5.root']
+    refs = list(base) + [ups[2], ups[1], ups[0]]
+    names += ['dla_up.ida_0.node_1.dcn', 'dla_up.ida_1.node_2.dcn', 'dla_up.ida_2.node_3.dcn']
+    msgs = []
+    worst = 0.0
+    for n, ref in zip(names, refs):
+        e = float((outs[n].to_nchw().cpu() - ref).abs().max())
+        worst = max(worst, e / max(1.0, float(ref.abs().max())))
+        msgs.append('%-26s err %.3e (absmax %.2f)' % (n, e, float(ref.abs().max())))
+    print('\n'.join(msgs))
+    assert worst < 2e-4, '\n'.join(msgs)
+
+
+def test_fused_sigmoid_and_batch_consistency(device):
+    """fuse_sigmoid == sigmoid(raw); a batch of 3 equals three batch-1 runs (streams do not mix)."""
+    from centertrack_amd import weights as W
+    from centertrack_amd.model import DLASegHIP
+    heads = W.NUSC_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=5, hm_gain=8.0)
+    model = DLASegHIP(heads, depth_scale=2.0)
+    model.load_state_dict(sd)
+    model = model.to(device)
+    x, pre, hm = W.synthetic_inputs(3, 64, 64, seed=5)
+    x, pre, hm = x.to(device), pre.to(device), hm.to(device)
+    raw = model(x, pre, hm)[-1]
+    fused = model(x, pre, hm, fuse_sigmoid=True)[-1]
+    np.testing.assert_allclose(fused['hm'].cpu().numpy(), torch.sigmoid(raw['hm']).cpu().numpy(), atol=2e-6)
+    dep = (1. / (torch.sigmoid(raw['dep']) + 1e-6) - 1.) * 2.0
+    np.testing.assert_allclose(fused['dep'].cpu().numpy(), dep.cpu().numpy(), rtol=1e-4, atol=1e-4)
+    for b in range(3):
+        one = model(x[b:b + 1], pre[b:b + 1], hm[b:b + 1])[-1]
+        for k in heads:
+            np.testing.assert_allclose(one[k].cpu().numpy(), raw[k][b:b + 1].cpu().numpy(), atol=1e-4, err_msg=k)

@@ -1,0 +1,289 @@
+"""GPU parity tests of the individual HIP ops (through the C ABI) against CPU oracles:
+dense convs vs torch fp32 F.conv2d, DCNv2 vs oracle/dcn_v2 (+ KATs), stems / pool /
+up-sample vs torch fp32, decode vs oracle/decode + the reference golden vectors.
+Tolerance: fp32 with a different summation order -> 2e-4 abs on O(1) values (north_star
+allows 1e-3); indices / classes bit-exact."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+ATOL = 2e-4
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g, dtype=torch.float64) * scale).float()
+
+
+def _close(a, b, atol=ATOL, rtol=1e-4, msg=''):
+    a = a.detach().cpu().double().numpy() if torch.is_tensor(a) else np.asarray(a, np.float64)
+    b = b.detach().cpu().double().numpy() if torch.is_tensor(b) else np.asarray(b, np.float64)
+    assert a.shape == b.shape, (a.shape, b.shape)
+    err = np.abs(a - b)
+    tol = atol + rtol * np.abs(b)
+    bad = err > tol
+    assert not bad.any(), '%s: %d/%d mismatches, max err %.3e at %s (got %r want %r)' % (
+        msg, bad.sum(), bad.size, err.max(), np.unravel_index(err.argmax(), err.shape),
+        a.flat[err.argmax()], b.flat[err.argmax()])
+
+
+def test_library_loads_on_gpu(device):
+    from centertrack_amd import _lib
+    lib = _lib.load()
+    assert lib.ct_version() >= 100
+
+
+def test_pack_weight_layout(device):
+    from centertrack_amd import ops
+    w = _rand(20, 32, 3, 3, seed=1)
+    p = ops.pack_weight(w.to(device)).cpu()
+    NT, C16 = 2, 2
+    p = p.view(9, C16, NT, 4, 16, 4)
+    for tap, c16, nt, g, j, e in [(0, 0, 0, 0, 0, 0), (4, 1, 1, 3, 3, 2), (8, 0, 0, 2, 15, 1), (3, 1, 1, 1, 4, 3)]:
+        co, ci = nt * 16 + j, c16 * 16 + 4 * g + e
+        want = w[co, ci, tap // 3, tap % 3] if co < 20 else 0.0
+        assert float(p[tap, c16, nt, g, j, e]) == float(want)
+    assert float(p[:, :, 1, :, 4:, :].abs().max()) == 0.0      # couts 20..31 are zero padding
+
+
+CONV_CASES = [
+    # N, H, W, Cin, Cout, ks, stride, relu, res, affine, split_k
+    (1, 16, 16, 16, 16, 3, 1, True, False, True, 0),      # cfg0 (BN16, TH16)
+    (2, 13, 37, 16, 16, 3, 1, False, True, True, 0),      # ragged tile edges
+    (1, 32, 48, 16, 32, 3, 2, True, False, True, 0),      # cfg1 stride 2 (level1)
+    (1, 16, 24, 64, 27, 3, 1, False, False, False, 0),    # offset conv shape (Cout 27 -> pad 32)
+    (1, 16, 16, 32, 64, 3, 2, True, False, True, 0),      # cfg2 stride 2
+    (1, 12, 20, 64, 64, 3, 1, True, True, True, 0),       # cfg2 nkk=2, residual
+    (1, 8, 8, 128, 128, 3, 1, True, True, True, 0),       # auto split-K (few tiles)
+    (1, 8, 8, 128, 128, 3, 1, True, True, True, 1),       # same, no split
+    (4, 32, 32, 64, 128, 3, 1, True, False, True, 1),     # cfg3 (BN128) when tiles >= 512
+    (1, 8, 12, 448, 128, 1, 1, True, False, True, 0),     # root 1x1, nkk=4
+    (1, 8, 8, 32, 64, 1, 1, False, False, True, 0),       # project 1x1, nkk=2, no relu
+    (1, 4, 4, 512, 512, 3, 1, True, True, True, 0),       # level5-like, heavy split-K
+    (1, 6, 10, 16, 80, 3, 1, False, False, False, 3),     # Cout 80 (5 n-tiles), forced split 3... clipped to nchunks
+    (1, 2, 2, 256, 512, 3, 2, True, False, True, 0),      # tiny map
+]
+
+
+@pytest.mark.parametrize('case', CONV_CASES, ids=lambda c: 'N%d_%dx%d_%d-%d_k%ds%d_r%d_res%d_a%d_sk%d' % c)
+def test_conv2d_matches_torch(device, case):
+    from centertrack_amd import ops
+    N, H, W, Cin, Cout, ks, stride, relu, use_res, affine, split_k = case
+    x = _rand(N, Cin, H, W, seed=3)
+    w = _rand(Cout, Cin, ks, ks, seed=4, scale=(Cin * ks * ks) ** -0.5)
+    scale = (torch.rand(Cout, generator=torch.Generator().manual_seed(5)) + 0.5) if affine else None
+    shift = _rand(Cout, seed=6) if affine else None
+    y = F.conv2d(x, w, None, stride=stride, padding=ks // 2)
+    if affine:
+        y = y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = _rand(*y.shape, seed=7) if use_res else None
+    if use_res:
+        y = y + res
+    if relu:
+        y = F.relu(y)
+    # input as a channel slice of a wider buffer (exercises ld != C), output likewise
+    xb = torch.zeros(N, H, W, Cin + 16)
+    xb[..., 16:] = x.permute(0, 2, 3, 1)
+    xv = ops.View(xb.to(device), 16, Cin)
+    rv = ops.view_from_nchw(res.to(device)) if use_res else None
+    ob = torch.full((N, y.shape[2], y.shape[3], (Cout + 3) // 4 * 4 + 8), -7.0).to(device)
+    ov = ops.View(ob, 4, Cout)
+    ops.conv2d(xv, ops.pack_weight(w.to(device)), Cout, ks, stride, out=ov,
+               scale=None if scale is None else scale.to(device),
+               shift=None if shift is None else shift.to(device), res=rv, relu=relu, split_k=split_k)
+    torch.cuda.synchronize()
+    _close(ov.to_nchw(), y, msg='conv')
+    assert float(ob[..., :4].min()) == -7.0 and float(ob[..., 4 + Cout:].min()) == -7.0, 'wrote outside its slice'
+
+
+def test_conv2d_nchw_output_sigmoid_dep(device):
+    from centertrack_amd import ops
+    N, H, W, Cin = 2, 8, 12, 256
+    x = _rand(N, Cin, H, W, seed=8)
+    for Cout, sig, dep in [(1, (0, 1), (0, 0)), (10, (0, 10), (0, 0)), (1, (0, 0), (0, 1)), (8, (0, 0), (0, 0)),
+                           (80, (0, 80), (0, 0))]:
+        w = _rand(Cout, Cin, 1, 1, seed=9, scale=Cin ** -0.5)
+        b = _rand(Cout, seed=10)
+        y = F.conv2d(x, w, b)
+        if sig[1] > 0:
+            y = torch.sigmoid(y)
+        if dep[1] > 0:
+            y = (1. / (torch.sigmoid(y) + 1e-6) - 1.) * 2.0
+        out = torch.empty(N, Cout, H, W, device=device)
+        ops.conv2d(ops.view_from_nchw(x.to(device)), ops.pack_weight(w.to(device)), Cout, 1, 1, out_nchw=out,
+                   shift=b.to(device), sig=sig, dep=dep, depth_scale=2.0)
+        _close(out, y, rtol=2e-4, msg='head Cout=%d' % Cout)
+
+
+DCN_CASES = [
+    # N, H, W, Cin, Cout, off_scale, split_k
+    (1, 8, 16, 64, 64, 0.5, 1),
+    (2, 7, 19, 64, 64, 3.0, 1),       # ragged, big offsets (out-of-range taps)
+    (1, 8, 8, 128, 64, 1.0, 0),
+    (1, 4, 4, 512, 256, 1.0, 0),      # split-K
+    (1, 16, 16, 128, 128, 1.0, 1),
+    (6, 32, 32, 64, 128, 1.0, 1),     # BN=128 config (>= 512 tiles)
+    (1, 8, 8, 256, 64, 1.0, 4),
+]
+
+
+@pytest.mark.parametrize('case', DCN_CASES, ids=lambda c: 'N%d_%dx%d_%d-%d_o%s_sk%d' % c)
+def test_dcn_v2_matches_oracle(device, case):
+    from centertrack_amd import ops
+    from oracle import dcn_v2 as odcn
+    N, H, W, Cin, Cout, osc, split_k = case
+    x = _rand(N, Cin, H, W, seed=11)
+    w = _rand(Cout, Cin, 3, 3, seed=12, scale=(Cin * 9) ** -0.5)
+    off = _rand(N, 18, H, W, seed=13, scale=osc)
+    mask = torch.sigmoid(_rand(N, 9, H, W, seed=14))
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(15)) + 0.5
+    shift = _rand(Cout, seed=16)
+    y = odcn.dcn_v2_conv(x, off, mask, w, None)
+    y = F.relu(y * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1))
+    om = torch.zeros(N, H, W, 32)
+    om[..., :18] = off.permute(0, 2, 3, 1)
+    om[..., 18:27] = mask.permute(0, 2, 3, 1)
+    out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), ops.View(om.to(device), 0, 27), ops.pack_weight(w.to(device)),
+                     Cout, scale.to(device), shift.to(device), relu=True, split_k=split_k)
+    _close(out.to_nchw(), y, msg='dcn')
+
+
+def test_dcn_v2_kat_zero_offset_is_conv(device):
+    from centertrack_amd import ops
+    x, w = _rand(1, 64, 9, 17, seed=17), _rand(64, 64, 3, 3, seed=18, scale=1 / 24.)
+    om = torch.zeros(1, 9, 17, 32)
+    om[..., 18:27] = 1.0
+    out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), ops.View(om.to(device), 0, 27), ops.pack_weight(w.to(device)), 64)
+    _close(out.to_nchw(), F.conv2d(x, w, padding=1), msg='KAT-1')
+    om[..., 18:27] = 0.0                                  # KAT-3: mask 0 -> shift only
+    sh = _rand(64, seed=19)
+    out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), ops.View(om.to(device), 0, 27), ops.pack_weight(w.to(device)), 64,
+                     shift=sh.to(device))
+    _close(out.to_nchw(), sh.view(1, 64, 1, 1).expand(1, 64, 9, 17), msg='KAT-3')
+
+
+def test_offset_conv_plus_dcn_is_DCN_module(device):
+    """conv_offset_mask -> sigmoid(mask) -> DCN == upstream DCN.forward (oracle.dcn_forward)"""
+    from centertrack_amd import ops
+    from oracle import dcn_v2 as odcn
+    x = F.relu(_rand(2, 128, 12, 20, seed=20))
+    w, b = _rand(64, 128, 3, 3, seed=21, scale=1 / 34.), _rand(64, seed=22)
+    wo, bo = _rand(27, 128, 3, 3, seed=23, scale=0.02), _rand(27, seed=24, scale=0.2)
+    y = odcn.dcn_forward(x, w, b, wo, bo)
+    xv = ops.view_from_nchw(x.to(device))
+    om = ops.conv2d(xv, ops.pack_weight(wo.to(device)), 27, 3, 1, shift=bo.to(device), sig=(18, 27),
+                    out=ops.new_view(2, 12, 20, 32, device))
+    out = ops.dcn_v2(xv, om, ops.pack_weight(w.to(device)), 64, shift=b.to(device))
+    _close(out.to_nchw(), y, msg='DCN module')
+
+
+@pytest.mark.parametrize('with_img,with_hm,shape', [(True, True, (2, 24, 40)), (True, False, (1, 16, 32)),
+                                                   (False, False, (1, 9, 33)), (True, True, (1, 64, 96))])
+def test_stem_matches_torch(device, with_img, with_hm, shape):
+    from centertrack_amd import ops
+    N, H, W = shape
+    x, pi, ph = _rand(N, 3, H, W, seed=25), _rand(N, 3, H, W, seed=26), torch.rand(N, 1, H, W)
+    ws = [_rand(16, 3, 7, 7, seed=27, scale=0.1), _rand(16, 3, 7, 7, seed=28, scale=0.1),
+          _rand(16, 1, 7, 7, seed=29, scale=0.2)]
+    sc = torch.rand(3, 16) + 0.5
+    sh = _rand(3, 16, seed=30, scale=0.3)
+
+    def st(inp, i):
+        return F.relu(F.conv2d(inp, ws[i], padding=3) * sc[i].view(1, 16, 1, 1) + sh[i].view(1, 16, 1, 1))
+    y = st(x, 0)
+    if with_img:
+        y = y + st(pi, 1)
+    if with_hm:
+        y = y + st(ph, 2)
+    out = ops.stem(x.to(device), pi.to(device) if with_img else None, ph.to(device) if with_hm else None,
+                   ws[0].to(device), ws[1].to(device), ws[2].to(device), sc.to(device), sh.to(device))
+    _close(out.to_nchw(), y, msg='stem')
+
+
+def test_maxpool_and_upsample_add(device):
+    from centertrack_amd import ops
+    x = _rand(2, 32, 12, 20, seed=31)
+    out = ops.maxpool2x2(ops.view_from_nchw(x.to(device)))
+    assert torch.equal(out.to_nchw().cpu(), F.max_pool2d(x, 2, 2))
+    for f, (h, w) in [(2, (6, 10)), (4, (3, 5)), (2, (1, 1))]:
+        xs = _rand(2, 64, h, w, seed=32)
+        wt = _rand(64, 1, 2 * f, 2 * f, seed=33)
+        skip = _rand(2, 64, h * f, w * f, seed=34)
+        y = F.conv_transpose2d(xs, wt, None, stride=f, padding=f // 2, groups=64) + skip
+        o = ops.upsample_add(ops.view_from_nchw(xs.to(device)), wt.to(device), f, ops.view_from_nchw(skip.to(device)))
+        _close(o.to_nchw(), y, atol=1e-5, msg='upsample f=%d' % f)
+
+
+def test_layout_roundtrip(device):
+    from centertrack_amd import ops
+    x = _rand(2, 27, 5, 7, seed=35)
+    v = ops.view_from_nchw(x.to(device))
+    assert torch.equal(v.to_nchw().cpu(), x)
+    assert torch.equal(ops.view_to_nchw(v).cpu(), x)
+
+
+def _decode_case(device, case, maps):
+    from centertrack_amd import ops
+    dev = {k: v.to(device).contiguous() for k, v in maps.items()}
+    dec = ops.Decoder(dev['hm'], {k: v for k, v in dev.items() if k != 'hm'}, case['K'])
+    packed = dec.run()
+    torch.cuda.synchronize()
+    return dec, dec.unpack(packed.cpu().numpy()), dec.inds.cpu().numpy()
+
+
+def test_decode_matches_oracle_and_golden(device, golden_dir):
+    from centertrack_amd import scenarios as S
+    from oracle import decode as odecode
+    g = np.load(os.path.join(golden_dir, 'decode.npz'))
+    for case in S.decode_cases():
+        maps = S.make_head_maps(case)
+        dec, got, inds = _decode_case(device, case, maps)
+        want = odecode.generic_decode({k: v.clone() for k, v in maps.items()}, K=case['K'], return_inds=True)
+        np.testing.assert_array_equal(inds, want['inds'].numpy(), err_msg=case['name'] + ' inds')
+        for k, v in want.items():
+            if k == 'inds':
+                continue
+            np.testing.assert_array_equal(got[k], v.numpy(), err_msg='%s.%s' % (case['name'], k))
+            np.testing.assert_array_equal(got[k], g['%s.%s' % (case['name'], k)], err_msg='golden %s.%s' % (case['name'], k))
+
+
+def test_decode_nms_plateau_and_ties(device):
+    """KAT-5: equal neighbours are both kept by the 3x3 NMS; exact ties order by lower
+    class, then lower pixel (documented tie rule; torch leaves it unspecified)."""
+    from centertrack_amd import ops
+    hm = torch.full((1, 2, 12, 12), 0.01)
+    hm[0, 1, 3, 3] = 0.9
+    hm[0, 1, 3, 4] = 0.9                       # plateau: both survive
+    hm[0, 0, 8, 8] = 0.9                       # same score in a lower class -> ranks first
+    hm[0, 0, 5, 5] = 0.5
+    hm[0, 0, 5, 6] = 0.4                       # suppressed by its neighbour
+    dec = ops.Decoder(hm.to(device), {}, 8)
+    out = dec.unpack(dec.run().cpu().numpy())
+    assert out['scores'][0, :4].tolist() == pytest.approx([0.9, 0.9, 0.9, 0.5])
+    assert out['clses'][0, :4].tolist() == [0, 1, 1, 0]
+    assert out['xs'][0, :4].tolist() == [8, 3, 4, 5] and out['ys'][0, :4].tolist() == [8, 3, 3, 5]
+    assert 0.4 not in [round(float(v), 3) for v in out['scores'][0]]
+
+
+def test_decode_full_size_properties(device):
+    """BASELINE-size maps (COCO 80x128x128, KITTI 3x96x320 batch 8): scores sorted, every
+    index a 3x3 local maximum, k-th score == torch.topk of the NMS'd map."""
+    from centertrack_amd import ops
+    for (B, C, h, w) in [(2, 80, 128, 128), (8, 3, 96, 320), (1, 10, 112, 200)]:
+        g = torch.Generator().manual_seed(B * C)
+        hm = torch.rand((B, C, h, w), generator=g)
+        dec = ops.Decoder(hm.to(device), {}, 100)
+        out = dec.unpack(dec.run().cpu().numpy())
+        sc = out['scores']
+        assert (np.diff(sc, axis=1) <= 0).all()
+        nms = hm * (F.max_pool2d(hm, 3, 1, 1) == hm).float()
+        ref = torch.topk(nms.view(B, -1), 100)[0].numpy()
+        np.testing.assert_array_equal(sc, ref)
+        cls, ys, xs = out['clses'].astype(int), out['ys'].astype(int), out['xs'].astype(int)
+        for b in range(B):
+            np.testing.assert_array_equal(nms[b].numpy()[cls[b], ys[b], xs[b]], sc[b])
