@@ -116,7 +116,8 @@ class StreamDetector(object):
         ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
         ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
         ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if with_hm else None
-        ctx['pre_img_state'] = img_in         # pre_images live in the plan's static buffer
+        # tracking state owned by THIS detector (the plan's buffers are shared by every detector of the model)
+        ctx['pre_images'] = torch.zeros_like(img_in) if img_in is not None else None
         ctx['graph'] = None
 
         def device_frame():
@@ -183,14 +184,16 @@ class StreamDetector(object):
                 if not self.started[s]:                        # detector.py:97-103
                     self.trackers[s].init_track(metas[s].get('pre_dets', []))
             if img_in is not None:
+                pre = ctx['pre_images']
                 fresh = [s for s in range(B) if not self.started[s]]
                 if len(fresh) == B:
-                    img_in.copy_(x_dev)
+                    pre.copy_(x_dev)
                 else:
                     for s in fresh:
-                        img_in[s].copy_(x_dev[s])
+                        pre[s].copy_(x_dev[s])
                         if self.flip:
-                            img_in[B + s].copy_(x_dev[B + s])
+                            pre[B + s].copy_(x_dev[B + s])
+                img_in.copy_(pre)
             if hm_in is not None:
                 hh = ctx['host_hm']
                 for s in range(B):
@@ -208,7 +211,7 @@ class StreamDetector(object):
         else:
             ctx['device_frame']()
         if tracking and img_in is not None:
-            img_in.copy_(x_in)                                 # self.pre_images = images (detector.py:148)
+            ctx['pre_images'].copy_(x_dev)                     # self.pre_images = images (detector.py:148)
         if self.gather_fn is not None:
             self.gather_fn(ctx['decoder'].out)
         ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)
