@@ -59,10 +59,23 @@ class DecodeDesc(ctypes.Structure):
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
+class RowLayout(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_int) for n in ('score', 'cls', 'cts', 'tracking', 'bbox', 'amodel_offset')]
+
+
+class Track(ctypes.Structure):
+    _fields_ = [('score', ctypes.c_float), ('cls', ctypes.c_int), ('ct', ctypes.c_float * 2),
+                ('tracking', ctypes.c_float * 2), ('bbox', ctypes.c_float * 4),
+                ('tracking_id', ctypes.c_int), ('age', ctypes.c_int), ('active', ctypes.c_int),
+                ('row', ctypes.c_int)]
+
+
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_packed_weight_elems', 'ct_pack_conv_weight', 'ct_conv2d',
            'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
-           'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode']
+           'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_render_pre_hm',
+           'ct_tracker_create', 'ct_tracker_destroy', 'ct_tracker_reset', 'ct_tracker_num_tracks',
+           'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params']
 
 _lib = None
 
@@ -102,6 +115,18 @@ def load():
     lib.ct_decode_workspace_bytes.restype = sz
     lib.ct_decode_workspace_bytes.argtypes = [ctypes.POINTER(DecodeDesc)]
     lib.ct_decode.argtypes = [ctypes.POINTER(DecodeDesc), p]
+    lib.ct_render_pre_hm.argtypes = [p, p, i, i, i, i, p, i, p]
+    lib.ct_tracker_create.restype = p
+    lib.ct_tracker_create.argtypes = [ctypes.c_float, i]
+    lib.ct_tracker_destroy.restype = None
+    lib.ct_tracker_destroy.argtypes = [p]
+    lib.ct_tracker_reset.restype = None
+    lib.ct_tracker_reset.argtypes = [p]
+    lib.ct_tracker_num_tracks.argtypes = [p]
+    lib.ct_tracker_id_count.argtypes = [p]
+    lib.ct_tracker_get_tracks.argtypes = [p, p, i]
+    lib.ct_tracker_step.argtypes = [p, p, i, i, ctypes.POINTER(RowLayout), ctypes.c_float, p, p, i]
+    lib.ct_tracker_prehm_params.argtypes = [p, ctypes.c_float, p, i, i, p, i]
     _lib = lib
     return lib
 

@@ -34,7 +34,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, src.rsplit('.', 1)[0] + '.o')
         objs.append(obj)
         if force or _stale(obj, [sp] + headers):
-            cmd = [hipcc] + FLAGS + (['-x', 'hip'] if src.endswith('.hip') else []) + ['-c', sp, '-o', obj]
+            extra = ['-x', 'hip'] if src.endswith('.hip') else ['-ffp-contract=off']
+            cmd = [hipcc] + FLAGS + extra + ['-c', sp, '-o', obj]
             if verbose:
                 print(' '.join(cmd))
             procs.append((src, subprocess.Popen(cmd)))

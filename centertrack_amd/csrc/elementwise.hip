@@ -102,6 +102,31 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *x, int C
     }
 }
 
+// prior heat-map: max-splat of (2r+1)^2 Gaussians, sigma = (2r+1)/6, evaluated in float64
+__global__ __launch_bounds__(256) void render_pre_hm_kernel(const int *params, const int *counts, int cap, int B,
+                                                            int H, int W, float *out, int also_flipped)
+{
+    const size_t total = (size_t)B * H * W;
+    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
+        const int x = (int)(idx % W);
+        const int y = (int)((idx / W) % H);
+        const int b = (int)(idx / ((size_t)W * H));
+        const int n = min(counts[b], cap);
+        const int *p = params + (size_t)b * cap * 3;
+        float v = 0.0f;
+        for (int i = 0; i < n; ++i) {
+            const int cx = p[3 * i], cy = p[3 * i + 1], r = p[3 * i + 2];
+            const int dx = x - cx, dy = y - cy;
+            if (dx < -r || dx > r || dy < -r || dy > r) continue;
+            const double sigma = (double)(2 * r + 1) / 6.0;
+            const double g = exp(-(double)(dx * dx + dy * dy) / (2.0 * sigma * sigma));
+            v = fmaxf(v, (float)g);
+        }
+        out[idx] = v;
+        if (also_flipped) out[((size_t)(B + b) * H + y) * W + (W - 1 - x)] = v;
+    }
+}
+
 unsigned grid_for(size_t total)
 {
     size_t b = (total + 255) / 256;
@@ -156,5 +181,16 @@ extern "C" int ct_nhwc_to_nchw(const float *x, int N, int C, int H, int W, int l
     hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(ct_cdiv(HW, 32), ct_cdiv(C, 32), N), dim3(256), 0,
                        (hipStream_t)stream, x, C, HW, ldx, y);
     CT_CHECK_LAUNCH("ct_nhwc_to_nchw");
+    return CT_OK;
+}
+
+extern "C" int ct_render_pre_hm(const int *params, const int *counts, int cap, int B, int H, int W, float *out,
+                                int also_flipped, void *stream)
+{
+    if (!params || !counts || !out || cap <= 0 || B <= 0 || H <= 0 || W <= 0) CT_FAIL_ARG("ct_render_pre_hm: bad arguments");
+    const size_t total = (size_t)B * H * W;
+    hipLaunchKernelGGL(render_pre_hm_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, params, counts,
+                       cap, B, H, W, out, also_flipped);
+    CT_CHECK_LAUNCH("ct_render_pre_hm");
     return CT_OK;
 }

@@ -21,8 +21,8 @@ import time
 import numpy as np
 import torch
 
-from . import _lib, ops
-from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, make_meta)
+from . import _lib, fast_track, ops
+from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, get_affine_transform, make_meta)
 from .model import create_model, load_model
 from .post_process import generic_post_process
 from .tracker import Tracker
@@ -73,7 +73,7 @@ def render_pre_hm(tracks, meta, pre_thresh, out=None, with_hm=True):
 class StreamDetector(object):
     """B independent streams, one frame each per ``step``."""
 
-    def __init__(self, opt, model=None, num_streams=1, use_graph=True):
+    def __init__(self, opt, model=None, num_streams=1, use_graph=True, native_host=True):
         if not torch.cuda.is_available():
             raise _lib.CTError('centertrack_amd needs an MI355X (no CPU fallback)')
         _lib.load()
@@ -89,6 +89,14 @@ class StreamDetector(object):
         self.flip = bool(getattr(opt, 'flip_test', False))
         self.use_graph = use_graph
         self.trackers = [Tracker(opt) for _ in range(self.B)]
+        # native host path (C++ post-process + greedy association + device-rendered prior heat-map);
+        # the reference-shaped Python path serves the Hungarian / public-detection / pre_dets branches
+        self.native = bool(native_host and getattr(opt, 'tracking', False) and 'tracking' in opt.heads
+                           and not getattr(opt, 'hungarian', False) and not getattr(opt, 'public_det', False)
+                           and not getattr(opt, 'zero_pre_hm', False))
+        self.fast = [fast_track.FastTracker(opt.new_thresh, getattr(opt, 'max_age', -1), opt.K)
+                     for _ in range(self.B)] if self.native else None
+        self._trans_cache = {}
         self.started = [False] * self.B
         self.gather_fn = None      # optional hook: called with the packed device rows [B,K,F] (multi-GPU all-gather)
         self._ctx = None
@@ -115,12 +123,24 @@ class StreamDetector(object):
         dec_heads = {k: v for k, v in merged.items() if k != 'hm'}
         ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
         ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
-        ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if with_hm else None
+        ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if (with_hm and not self.native) else None
+        render = self.native and with_hm
+        if render:
+            ctx['prm_host'] = torch.zeros((self.B, fast_track.MAX_BLOBS, 3), dtype=torch.int32).pin_memory()
+            ctx['cnt_host'] = torch.zeros((self.B,), dtype=torch.int32).pin_memory()
+            ctx['prm_dev'] = torch.zeros((self.B, fast_track.MAX_BLOBS, 3), dtype=torch.int32, device=self.device)
+            ctx['cnt_dev'] = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
+        if self.native:
+            ctx['row_layout'] = fast_track.row_layout(ctx['decoder'].layout)
         # tracking state owned by THIS detector (the plan's buffers are shared by every detector of the model)
         ctx['pre_images'] = torch.zeros_like(img_in) if img_in is not None else None
         ctx['graph'] = None
 
         def device_frame():
+            if render:
+                _lib.check(_lib.load().ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
+                                                        fast_track.MAX_BLOBS, self.B, H, W, hm_in.data_ptr(),
+                                                        1 if self.flip else 0, _lib.stream_ptr()), 'ct_render_pre_hm')
             self.model._run_plan(plan)
             if self.flip:
                 self._flip_merge(outs, merged)
@@ -182,7 +202,15 @@ class StreamDetector(object):
         if tracking:
             for s in range(B):
                 if not self.started[s]:                        # detector.py:97-103
-                    self.trackers[s].init_track(metas[s].get('pre_dets', []))
+                    pre_dets = metas[s].get('pre_dets', [])
+                    if self.native and len(pre_dets) > 0:
+                        if any(self.started):
+                            raise _lib.CTError('pre_dets need the Python host path: build the detector with native_host=False')
+                        self.native, self.fast = False, None
+                        self._ctx = None
+                        return self.step(images[:B], metas, timers)
+                    if not self.native:
+                        self.trackers[s].init_track(pre_dets)
             if img_in is not None:
                 pre = ctx['pre_images']
                 fresh = [s for s in range(B) if not self.started[s]]
@@ -194,7 +222,15 @@ class StreamDetector(object):
                         if self.flip:
                             pre[B + s].copy_(x_dev[B + s])
                 img_in.copy_(pre)
-            if hm_in is not None:
+            if hm_in is not None and self.native:
+                ph, ch = ctx['prm_host'].numpy(), ctx['cnt_host'].numpy()
+                for s in range(B):
+                    m = metas[s]
+                    ch[s], _ = self.fast[s].prehm_params(opt.pre_thresh, m['trans_input'], m['inp_width'],
+                                                         m['inp_height'], out=ph[s])
+                ctx['prm_dev'].copy_(ctx['prm_host'], non_blocking=True)
+                ctx['cnt_dev'].copy_(ctx['cnt_host'], non_blocking=True)
+            elif hm_in is not None:
                 hh = ctx['host_hm']
                 for s in range(B):
                     render_pre_hm(self.trackers[s].tracks, metas[s], opt.pre_thresh, out=hh[s, 0].numpy(),
@@ -217,11 +253,25 @@ class StreamDetector(object):
         ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)
         torch.cuda.current_stream().synchronize()
         t2 = time.time()
-        dets = ctx['decoder'].unpack(ctx['host_out'].numpy())
+        rows = ctx['host_out'].numpy()
+        dets = ctx['decoder'].unpack(rows)
         self.last_dets = dets
         all_results = []
         t_post = t_track = 0.0
-        for s in range(B):
+        if self.native:
+            ta = time.time()
+            for s in range(B):
+                m = metas[s]
+                key = (float(m['c'][0]), float(m['c'][1]), tuple(np.atleast_1d(m['s']).tolist()),
+                       m['out_width'], m['out_height'])
+                tinv = self._trans_cache.get(key)
+                if tinv is None:
+                    tinv = np.ascontiguousarray(get_affine_transform(
+                        m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1).astype(np.float32))
+                    self._trans_cache[key] = tinv
+                all_results.append(self.fast[s].step(rows[s], ctx['row_layout'], opt.out_thresh, tinv).copy())
+            t_track = time.time() - ta
+        for s in (range(B) if not self.native else []):
             ta = time.time()
             meta = metas[s]
             one = {k: v[s:s + 1] for k, v in dets.items()}
@@ -244,17 +294,25 @@ class StreamDetector(object):
     def reset_tracking(self, stream=None):
         for s in (range(self.B) if stream is None else [stream]):
             self.trackers[s].reset()
+            if self.fast is not None:
+                self.fast[s].reset()
             self.started[s] = False
+
+    def results_as_dicts(self, results, stream=0):
+        """one stream's result of ``step`` as the reference's list of dicts"""
+        if isinstance(results, np.ndarray):
+            return fast_track.as_dicts(results, self.last_dets, stream)
+        return results
 
 
 class Detector(object):
     """The reference's single-stream ``Detector`` API (src/lib/detector.py)."""
 
-    def __init__(self, opt, model=None, use_graph=True):
+    def __init__(self, opt, model=None, use_graph=True, native_host=True):
         if not hasattr(opt, 'device'):
             opt.device = torch.device('cuda')
         self.opt = opt
-        self.impl = StreamDetector(opt, model=model, num_streams=1, use_graph=use_graph)
+        self.impl = StreamDetector(opt, model=model, num_streams=1, use_graph=use_graph, native_host=native_host)
         self.model = self.impl.model
         self.mean, self.std = MEAN, STD
         self.pause = not getattr(opt, 'no_pause', True)
@@ -264,7 +322,8 @@ class Detector(object):
 
     @property
     def tracker(self):
-        return self.impl.trackers[0]
+        """the stream's tracker (``.id_count``, ``.tracks`` / ``.reset()`` like the reference's)"""
+        return self.impl.fast[0] if self.impl.native else self.impl.trackers[0]
 
     def pre_process(self, image, scale, input_meta={}):
         """detector.py:207-239.  The cv2 resize/warpAffine of a raw BGR frame is the step
@@ -292,7 +351,7 @@ class Detector(object):
             images = images[0:1]                               # the flipped copy is rebuilt on device
         loaded = time.time()
         timers = {}
-        results = self.impl.step(images, [meta], timers)[0]
+        results = self.impl.results_as_dicts(self.impl.step(images, [meta], timers)[0], 0)
         self.cnt += 1
         end = time.time()
         ret = {'results': results, 'tot': end - start, 'load': loaded - start, 'display': 0.0}

@@ -137,6 +137,44 @@ int ct_decode_row_floats(const ct_decode_desc *d);
 size_t ct_decode_workspace_bytes(const ct_decode_desc *d);
 int ct_decode(const ct_decode_desc *d, void *stream);
 
+/* ---- prior heat-map rendering on device ------------------------------------------------
+ * Replaces the numpy Gaussian splatting + full-map H2D of Detector._get_additional_inputs
+ * (src/lib/detector.py:254-290; draw_umich_gaussian / gaussian2D, src/lib/utils/image.py:
+ * 130-154): out[b,0,y,x] = max over the stream's blobs (cx, cy, r) with |x-cx|<=r, |y-cy|<=r
+ * of float32(exp(-(dx^2+dy^2) / (2*((2r+1)/6)^2))) (evaluated in float64 like numpy).
+ * params: device int32 [B][cap][3]; counts: device int32 [B]; out: [B(*2),1,H,W] fp32; with
+ * also_flipped the W-mirrored map of stream b is written to out[B+b] (flip_test). */
+int ct_render_pre_hm(const int *params, const int *counts, int cap, int B, int H, int W, float *out,
+                     int also_flipped, void *stream);
+
+/* ---- host side of a frame (CPU, no device work) ----------------------------------------
+ * Replaces generic_post_process (src/lib/utils/post_process.py:21-91), Detector.merge_outputs
+ * (src/lib/detector.py:371-377) and Tracker.step with greedy_assignment
+ * (src/lib/utils/tracker.py:28-138, private detections) for the packed rows of ct_decode, and
+ * the per-track part of Detector._get_additional_inputs (detector.py:254-290). */
+typedef struct ct_row_layout {      /* float offsets inside one packed row; -1 = field absent */
+    int score, cls, cts, tracking, bbox, amodel_offset;
+} ct_row_layout;
+typedef struct ct_track {
+    float score; int cls;           /* class is 1-based like the reference's item['class'] */
+    float ct[2], tracking[2], bbox[4];
+    int tracking_id, age, active;
+    int row;                        /* source row in the packed decode buffer (-1: carried-over track) */
+} ct_track;
+void *ct_tracker_create(float new_thresh, int max_age);
+void ct_tracker_destroy(void *tracker);
+void ct_tracker_reset(void *tracker);
+int ct_tracker_num_tracks(void *tracker);
+int ct_tracker_id_count(void *tracker);
+int ct_tracker_get_tracks(void *tracker, ct_track *out, int cap);
+/* rows: HOST pointer [K,F]; trans_inv: float32 [2,3] output-grid -> image affine; returns the
+ * number of tracks written to out (<= cap) or -1 */
+int ct_tracker_step(void *tracker, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
+                    const float *trans_inv, ct_track *out, int cap);
+/* (cx, cy, radius) int32 triples of the next frame's prior heat-map; trans_input float64 [2,3] */
+int ct_tracker_prehm_params(void *tracker, float pre_thresh, const double *trans_input, int inp_w, int inp_h,
+                            int *params, int cap);
+
 #ifdef __cplusplus
 }
 #endif

@@ -23,8 +23,8 @@ def _check_frame(res, ref, t, tag):
                                        err_msg='%s frame %d %s' % (tag, t, k))
 
 
-@pytest.mark.parametrize('use_graph', [False, True])
-def test_detector_stream_matches_reference(device, golden_dir, use_graph):
+@pytest.mark.parametrize('use_graph,native_host', [(False, True), (True, True), (True, False)])
+def test_detector_stream_matches_reference(device, golden_dir, use_graph, native_host):
     from centertrack_amd import scenarios as S
     from centertrack_amd.detector import Detector, default_opt
     from centertrack_amd.model import DLASegHIP
@@ -35,7 +35,7 @@ def test_detector_stream_matches_reference(device, golden_dir, use_graph):
     opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'])
     model = DLASegHIP(cfg['heads'])
     model.load_state_dict(sd)
-    det = Detector(opt, model=model, use_graph=use_graph)
+    det = Detector(opt, model=model, use_graph=use_graph, native_host=native_host)
     oopt = odet.default_opt(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
                             input_h=cfg['H'], input_w=cfg['W'])
     oracle = odet.Detector(oopt, sd, cfg['heads'])
@@ -55,7 +55,7 @@ def test_detector_stream_matches_reference(device, golden_dir, use_graph):
         _check_frame(ret['results'], want, t, 'oracle')
         _check_frame(ret['results'], g['frames'][t], t, 'golden')
     det.reset_tracking()
-    assert det.tracker.id_count == 0 and det.tracker.tracks == []
+    assert det.tracker.id_count == 0 and len(det.tracker.tracks) == 0
 
 
 def test_batched_streams_equal_single_streams(device):

@@ -287,3 +287,35 @@ def test_decode_full_size_properties(device):
         cls, ys, xs = out['clses'].astype(int), out['ys'].astype(int), out['xs'].astype(int)
         for b in range(B):
             np.testing.assert_array_equal(nms[b].numpy()[cls[b], ys[b], xs[b]], sc[b])
+
+
+def test_render_pre_hm_matches_reference_golden(device, golden_dir):
+    """device Gaussian splatting from the native tracker's blob list == the reference's
+    _get_additional_inputs output (golden pre_hm.npz), incl. the flipped copy."""
+    import ctypes
+    from centertrack_amd import _lib, fast_track as FT, ops, scenarios as S
+    g = np.load(os.path.join(golden_dir, 'pre_hm.npz'))
+    lay = FT.row_layout(ops.decode_layout(['reg', 'wh', 'tracking', 'ltrb_amodal'])[0])
+    ident = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    for case in S.pre_hm_cases():
+        meta = case['meta']
+        tracks = [t for t in case['tracks'] if t['active'] != 0]     # native tracks are always active
+        ft = FT.FastTracker(-1.0, -1, 100)
+        rows = np.zeros((len(tracks), 14), np.float32)
+        for j, t in enumerate(sorted(tracks, key=lambda t: -t['score'])):
+            rows[j, 0] = t['score']
+            rows[j, 4:8] = t['bbox']
+        ft.step(rows, lay, -1.0, ident)
+        H, W = meta['inp_height'], meta['inp_width']
+        prm = torch.zeros((1, FT.MAX_BLOBS, 3), dtype=torch.int32)
+        n, _ = ft.prehm_params(case['pre_thresh'], meta['trans_input'], W, H, out=prm[0].numpy())
+        cnt = torch.tensor([n], dtype=torch.int32)
+        flip = case['flip_test']
+        out = torch.full((2 if flip else 1, 1, H, W), -1.0, device=device)
+        _lib.check(_lib.load().ct_render_pre_hm(prm.to(device).data_ptr(), cnt.to(device).data_ptr(), FT.MAX_BLOBS, 1,
+                                                H, W, out.data_ptr(), 1 if flip else 0, _lib.stream_ptr()))
+        torch.cuda.synchronize()
+        ref = g[case['name'] + '.hm']
+        got = out.cpu().numpy()
+        assert np.abs(got - ref).max() <= 1e-6, case['name']
+        assert (got != ref).mean() < 1e-4

@@ -1,0 +1,97 @@
+"""CPU: the native (C++) host path -- post-process + score cut + greedy association + prior
+heat-map blob parameters -- is identical to the reference-shaped Python path and to the
+oracle on random multi-frame streams (IDs / age / active exact, values bitwise here)."""
+import types
+
+import numpy as np
+import pytest
+
+from centertrack_amd import fast_track as FT
+from centertrack_amd import image as IM
+from centertrack_amd import ops
+from centertrack_amd import post_process as PP
+from centertrack_amd import tracker as TR
+from centertrack_amd.detector import render_pre_hm
+from oracle import post_process as OPP
+from oracle import tracker as OTR
+
+
+def _stream(rs, K, F, nobj=60):
+    objs = [dict(p=rs.uniform(5, 120, 2), v=rs.normal(0, 1.5, 2), s=rs.uniform(2, 10)) for _ in range(nobj)]
+    while True:
+        rows = np.zeros((K, F), np.float32)
+        rows[:, 0] = np.sort(rs.uniform(0.05, 1, K).astype(np.float32))[::-1]
+        rows[:, 1] = rs.randint(0, 2, K)
+        for j in range(K):
+            o = objs[j % nobj]
+            if j < nobj:
+                o['p'] = o['p'] + o['v']
+            c = np.floor(o['p'] + (0 if j < nobj else rs.normal(0, 20, 2)))
+            rows[j, 2:4] = c
+            rows[j, 4:8] = [c[0] - o['s'], c[1] - o['s'], c[0] + o['s'], c[1] + o['s']]
+            rows[j, 8:12] = rows[j, 4:8]
+            rows[j, 12:14] = -o['v'] + rs.normal(0, 0.3, 2)
+        rows[:, 1:] = rows[rs.permutation(K), 1:]
+        yield rows
+
+
+@pytest.mark.parametrize('max_age', [-1, 2])
+def test_native_host_path_equals_python_and_oracle(max_age):
+    rs = np.random.RandomState(3)
+    lay_list, F = ops.decode_layout(['reg', 'wh', 'tracking', 'ltrb_amodal'])
+    lay = FT.row_layout(lay_list)
+    K = 100
+    meta = IM.make_meta(512, 512, 1080, 1920)
+    trans = np.ascontiguousarray(IM.get_affine_transform(
+        meta['c'], meta['s'], 0, (meta['out_width'], meta['out_height']), inv=1).astype(np.float32))
+    opt = types.SimpleNamespace(out_thresh=0.4, new_thresh=0.4, max_age=max_age, hungarian=False, public_det=False)
+    ft, pt, ot = FT.FastTracker(0.4, max_age, K), TR.Tracker(opt), OTR.Tracker(0.4, max_age)
+    matched = 0
+    for t, rows in zip(range(25), _stream(rs, K, F)):
+        dec = {n: (rows[None, :, s] if n in ('scores', 'clses', 'xs', 'ys') else rows[None, :, s:s + w])
+               for n, s, w in lay_list}
+        dec['cts'] = rows[None, :, 2:4]
+        got = ft.step(rows, lay, 0.4, trans).copy()
+        res = PP.generic_post_process(opt, dec, [meta['c']], [meta['s']], meta['out_height'], meta['out_width'])[0]
+        want = pt.step([r for r in res if r['score'] > 0.4])
+        ores = OPP.generic_post_process(0.4, dec, [meta['c']], [meta['s']], meta['out_height'], meta['out_width'])[0]
+        owant = ot.step([r for r in ores if r['score'] > 0.4])
+        ids = [int(x['tracking_id']) for x in want]
+        assert ids == [int(x['tracking_id']) for x in owant]
+        assert [int(x) for x in got['tracking_id']] == ids, t
+        assert [int(x) for x in got['active']] == [int(x['active']) for x in want]
+        assert [int(x) for x in got['age']] == [int(x['age']) for x in want]
+        assert [int(x) for x in got['class']] == [int(x['class']) for x in want]
+        for w, g in zip(want, got):
+            np.testing.assert_allclose(g['bbox'], np.asarray(w['bbox']), rtol=1e-6, atol=1e-4)
+            np.testing.assert_allclose(g['ct'], np.asarray(w['ct']), rtol=1e-6, atol=1e-4)
+            np.testing.assert_allclose(g['tracking'], np.asarray(w['tracking']), rtol=1e-5, atol=1e-4)
+        matched += sum(int(x['active']) > 1 for x in want)
+        # prior heat-map of the next frame: blob list rendered with numpy == python rendering
+        n, prm = ft.prehm_params(0.5, meta['trans_input'], 512, 512)
+        hm_py, _ = render_pre_hm(pt.tracks, meta, 0.5)
+        out = np.zeros((512, 512), np.float32)
+        ys, xs = np.mgrid[0:512, 0:512]
+        for cx, cy, r in prm[:n]:
+            sig = (2 * r + 1) / 6.0
+            y0, y1, x0, x1 = max(0, cy - r), min(512, cy + r + 1), max(0, cx - r), min(512, cx + r + 1)
+            gg = np.exp(-((xs[y0:y1, x0:x1] - cx) ** 2 + (ys[y0:y1, x0:x1] - cy) ** 2) / (2 * sig * sig))
+            out[y0:y1, x0:x1] = np.maximum(out[y0:y1, x0:x1], gg.astype(np.float32))
+        if t % 6 == 0:
+            np.testing.assert_array_equal(out, hm_py)
+    assert matched > 20, 'the synthetic stream should exercise association'
+    assert ft.id_count == pt.id_count
+
+
+def test_native_tracker_reset_and_empty_frames():
+    lay = FT.row_layout(ops.decode_layout(['reg', 'wh', 'tracking'])[0])
+    ft = FT.FastTracker(0.3, -1, 10)
+    ident = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
+    rows = np.zeros((10, 10), np.float32)            # all scores 0 < out_thresh -> no detections
+    assert len(ft.step(rows, lay, 0.3, ident)) == 0
+    rows[0] = [0.9, 0, 5, 5, 3, 3, 7, 7, 0, 0]
+    rows[1] = [0.3, 0, 9, 9, 8, 8, 10, 10, 0, 0]     # score == thresh: cut by the strict '>' of merge_outputs
+    r = ft.step(rows, lay, 0.3, ident)
+    assert len(r) == 1 and int(r['tracking_id'][0]) == 1 and ft.id_count == 1
+    ft.reset()
+    assert ft.id_count == 0 and len(ft.tracks) == 0
