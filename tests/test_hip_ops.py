@@ -312,7 +312,8 @@ def test_render_pre_hm_matches_reference_golden(device, golden_dir):
         cnt = torch.tensor([n], dtype=torch.int32)
         flip = case['flip_test']
         out = torch.full((2 if flip else 1, 1, H, W), -1.0, device=device)
-        _lib.check(_lib.load().ct_render_pre_hm(prm.to(device).data_ptr(), cnt.to(device).data_ptr(), FT.MAX_BLOBS, 1,
+        prm_d, cnt_d = prm.to(device), cnt.to(device)       # keep both alive across the launch
+        _lib.check(_lib.load().ct_render_pre_hm(prm_d.data_ptr(), cnt_d.data_ptr(), FT.MAX_BLOBS, 1,
                                                 H, W, out.data_ptr(), 1 if flip else 0, _lib.stream_ptr()))
         torch.cuda.synchronize()
         ref = g[case['name'] + '.hm']
