@@ -70,7 +70,7 @@ class Track(ctypes.Structure):
                 ('row', ctypes.c_int)]
 
 
-EXPORTS = ['ct_last_error', 'ct_version', 'ct_packed_weight_elems', 'ct_pack_conv_weight', 'ct_conv2d',
+EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight', 'ct_conv2d',
            'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_render_pre_hm',
@@ -97,6 +97,7 @@ def load():
     i, p, sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     lib.ct_last_error.restype = ctypes.c_char_p
     lib.ct_version.restype = i
+    lib.ct_set_tuning.argtypes = [ctypes.c_char_p, i]
     lib.ct_packed_weight_elems.restype = sz
     lib.ct_packed_weight_elems.argtypes = [i, i, i]
     lib.ct_pack_conv_weight.argtypes = [p, p, i, i, i, p]

@@ -17,3 +17,22 @@ void ct_set_error(const char *fmt, ...)
 
 extern "C" const char *ct_last_error(void) { return g_err; }
 extern "C" int ct_version(void) { return 100; }
+
+// ---- tuning knobs -------------------------------------------------------------------------
+enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,
+       CT_TUNE_COUNT };
+static int g_tune[CT_TUNE_COUNT] = {-1, 1, 256, 512, 0};
+static const char *g_tune_names[CT_TUNE_COUNT] = {"conv_cfg", "conv_pipe", "conv_small_tiles", "splitk_target", "dcn_bn"};
+
+int ct_tune_get(int key) { return g_tune[key]; }
+
+extern "C" int ct_set_tuning(const char *key, int value)
+{
+    for (int i = 0; i < CT_TUNE_COUNT; ++i)
+        if (key && strcmp(key, g_tune_names[i]) == 0) {
+            g_tune[i] = value;
+            return CT_OK;
+        }
+    ct_set_error("ct_set_tuning: unknown key '%s'", key ? key : "(null)");
+    return CT_ERR_ARG;
+}

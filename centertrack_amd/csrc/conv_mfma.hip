@@ -50,7 +50,7 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = 2ull * BUF * sizeof(float);
 };
 
-template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK>
+template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 {
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
@@ -100,12 +100,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         }
     }
     f32x4 stage[C::NR];
+    // Branch-free staging: out-of-image / padding items read element 0 and are zeroed by a
+    // select, so the compiler can count outstanding loads exactly (no vmcnt(0) drains).
     auto stage_load = [&](int chunk) {
         const int coff = chunk * (16 * NKK);
 #pragma unroll
         for (int r = 0; r < C::NR; ++r) {
-            stage[r] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (goff[r] >= 0) stage[r] = *reinterpret_cast<const f32x4 *>(xin + goff[r] + coff);
+            const bool ok = goff[r] >= 0;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
+            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
     auto stage_store = [&](int buf) {
@@ -123,14 +126,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
     const int nt0 = cb * (C::BN / 16) + wn * WN;    // first n-tile of this wave
     const int NCH16 = a.Cin >> 4;
+    // B fragments: one contiguous 1 KiB block per (tap, 16-ch slab, n-tile); n-tiles past the
+    // padded Cout are clamped to the last valid tile (their results are never stored).
+    const float *bptr[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
+    const size_t slab_stride = (size_t)a.NT << 8;      // floats between consecutive 16-ch slabs
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int kk, int tap) {
         const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            b[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (nt0 + nt < a.NT)
-                b[nt] = *reinterpret_cast<const f32x4 *>(a.wp + ((slab * a.NT + nt0 + nt) << 8) + (lane << 2));
-        }
+        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
     };
 
     f32x4 acc[WM][WN];
@@ -139,49 +144,55 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // Software pipeline over steps (kk, tap): B fragments are fetched RING-1 steps ahead of
+    // their MFMAs into a static register ring; the next chunk's patch is fetched into
+    // registers at the top of a chunk and written to the other LDS buffer at its end.
+    constexpr int S = NKK * KS * KS;                   // steps per chunk
+    constexpr int RING = (S % 3 == 0) ? 3 : ((S % 2 == 0) ? 2 : 1);
     if (c_begin < c_end) {
         stage_load(c_begin);
         stage_store(0);
+        f32x4 breg[RING][WN];
+#pragma unroll
+        for (int p = 0; p < RING - 1; ++p) load_b(breg[p], c_begin, p / (KS * KS), p % (KS * KS));   // S >= RING
         __syncthreads();
-        f32x4 bcur[WN], bnext[WN];
-        load_b(bcur, c_begin, 0, 0);
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
-            const bool more = (c + 1 < c_end);
-            if (more) stage_load(c + 1);
+            const int cnext = min(c + 1, c_end - 1);   // clamped: the last chunk re-fetches itself (unused)
+            stage_load(cnext);
+            if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x38E);
             const float *buf = lds + cur * C::BUF;
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-#pragma unroll
-                for (int tap = 0; tap < KS * KS; ++tap) {
-                    // prefetch the next step's B fragments (possibly of the next chunk)
-                    {
-                        int ntap = tap + 1, nkk = kk, nc = c;
-                        if (ntap == KS * KS) { ntap = 0; nkk = kk + 1; }
-                        if (nkk == NKK) { nkk = 0; nc = c + 1; }
-                        if (nc < c_end) load_b(bnext, nc, nkk, ntap);
-                    }
-                    const int ky = tap / KS, kx = tap % KS;
-                    f32x4 af[WM];
-#pragma unroll
-                    for (int mt = 0; mt < WM; ++mt) {
-                        const int P = pbase[mt] + ky * C::PW + kx;
-                        af[mt] = *reinterpret_cast<const f32x4 *>(buf + kk * C::SLAB + P * 16 +
-                                                                  ((lg ^ ((P >> 1) & 2)) << 2));
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-#pragma unroll
-                        for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < WN; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bcur[nt][e],
-                                                                                  acc[mt][nt], 0, 0, 0);
-#pragma unroll
-                    for (int nt = 0; nt < WN; ++nt) bcur[nt] = bnext[nt];
+            for (int s = 0; s < S; ++s) {
+                const int kk = s / (KS * KS), tap = s % (KS * KS);
+                {   // prefetch step s + RING - 1 (static position in the ring)
+                    constexpr int dummy = 0; (void)dummy;
+                    const int sp = s + RING - 1;
+                    const int pc = (sp >= S) ? cnext : c;
+                    const int ps = (sp >= S) ? sp - S : sp;
+                    if (RING > 1) load_b(breg[sp % RING], pc, ps / (KS * KS), ps % (KS * KS));
                 }
+                if (RING == 1) load_b(breg[0], c, kk, tap);
+                // pin the prefetch loads here (hipcc otherwise sinks them towards their use)
+                if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x38E);
+                const int ky = tap / KS, kx = tap % KS;
+                f32x4 af[WM];
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt) {
+                    const int P = pbase[mt] + ky * C::PW + kx;
+                    af[mt] = *reinterpret_cast<const f32x4 *>(buf + kk * C::SLAB + P * 16 +
+                                                              ((lg ^ ((P >> 1) & 2)) << 2));
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], breg[s % RING][nt][e],
+                                                                              acc[mt][nt], 0, 0, 0);
             }
-            if (more) stage_store(cur ^ 1);
+            stage_store(cur ^ 1);
             __syncthreads();
         }
     }
@@ -265,7 +276,8 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, float 
 }
 
 struct Plan {
-    int cfg;       // 0: BN16 (TH16), 1: BN32 (TH8), 2: BN64 (TH4), 3: BN128 (TH4)
+    int pipe;
+    int cfg;       // see launch_tile2
     int TH, BN, nkk;
     int tilesX, tilesY, coutBlocks, nchunks, splits, chunksPerSplit;
     int Ho, Wo, NT;
@@ -284,18 +296,29 @@ int make_plan(const ct_conv_desc *d, Plan *p)
     p->Ho = (d->H + 2 * pad - d->ks) / d->stride + 1;
     p->Wo = (d->W + 2 * pad - d->ks) / d->stride + 1;
     p->NT = ct_cdiv(d->Cout, 16);
-    if (d->Cout <= 16) { p->cfg = 0; p->TH = 16; p->BN = 16; }
-    else if (d->Cout <= 32) { p->cfg = 1; p->TH = 8; p->BN = 32; }
-    else { p->cfg = 2; p->TH = 4; p->BN = 64; }
+    static const int kTH[6] = {16, 8, 4, 4, 2, 4}, kBN[6] = {16, 32, 64, 128, 64, 32};
     p->tilesX = ct_cdiv(p->Wo, 16);
-    p->tilesY = ct_cdiv(p->Ho, p->TH);
-    if (p->cfg == 2 && d->Cout >= 128) {
-        const long tiles128 = (long)d->N * p->tilesX * p->tilesY * ct_cdiv(d->Cout, 128);
-        if (tiles128 >= 512) { p->cfg = 3; p->BN = 128; }
+    auto tiles_of = [&](int cfg) {
+        return (long)d->N * p->tilesX * ct_cdiv(p->Ho, kTH[cfg]) * ct_cdiv(d->Cout, kBN[cfg]);
+    };
+    if (d->Cout <= 16) p->cfg = 0;
+    else if (d->Cout <= 32) p->cfg = (tiles_of(1) >= ct_tune_get(CT_TUNE_CONV_SMALL_TILES)) ? 1 : 5;
+    else {
+        p->cfg = 2;
+        if (d->Cout >= 128 && tiles_of(3) >= 512) p->cfg = 3;
+        else if (tiles_of(2) < ct_tune_get(CT_TUNE_CONV_SMALL_TILES)) p->cfg = 4;
     }
+    if (ct_tune_get(CT_TUNE_CONV_CFG) >= 0) p->cfg = ct_tune_get(CT_TUNE_CONV_CFG);
+    p->pipe = ct_tune_get(CT_TUNE_CONV_PIPE);
+    p->TH = kTH[p->cfg];
+    p->BN = kBN[p->cfg];
+    p->tilesY = ct_cdiv(p->Ho, p->TH);
     p->coutBlocks = ct_cdiv(d->Cout, p->BN);
     const int c16 = d->Cin / 16;
-    if (d->ks == 1) p->nkk = (c16 % 4 == 0) ? 4 : ((c16 % 2 == 0) ? 2 : 1);
+    if (d->ks == 1) {
+        p->nkk = (c16 % 4 == 0) ? 4 : ((c16 % 2 == 0) ? 2 : 1);
+        if (p->cfg <= 1 && p->nkk > 2) p->nkk = 2;      // big pixel tiles: keep the LDS patch <= 64 KiB
+    }
     else if (d->stride == 2) p->nkk = 1;
     else p->nkk = (c16 % 2 == 0) ? 2 : 1;
     p->nchunks = c16 / p->nkk;
@@ -304,7 +327,7 @@ int make_plan(const ct_conv_desc *d, Plan *p)
     if (splits <= 0) {
         splits = 1;
         if (d->workspace && tiles < 256) {
-            splits = (int)((512 + tiles - 1) / tiles);
+            splits = (int)((ct_tune_get(CT_TUNE_SPLITK_TARGET) + tiles - 1) / tiles);
             // keep at least ~2 chunks (>= 18 MFMA steps for 3x3) per split
             const int maxs = p->nchunks >= 2 ? p->nchunks / 2 : 1;
             if (splits > maxs) splits = maxs;
@@ -324,11 +347,11 @@ size_t ws_bytes(const ct_conv_desc *d, const Plan &p)
     return (size_t)p.splits * d->N * p.Ho * p.Wo * (size_t)(p.NT * 16) * sizeof(float);
 }
 
-template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK>
+template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE>
 int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
-    auto k = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
+    auto k = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE>;
     static bool attr_set = false;   // > 64 KiB dynamic LDS needs the opt-in attribute
     if (!attr_set && C::LDS_BYTES > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -339,15 +362,24 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
     return CT_OK;
 }
 
-template <int KS, int STRIDE, int NKK>
-int launch_tile(int cfg, const ConvArgs &a, dim3 grid, hipStream_t s)
+// tile configurations: {WGM, WGN, WM, WN} -> TH = WGM*WM rows x 16 px, BN = 16*WGN*WN couts
+//   0: 256 px x 16   1: 128 px x 32   2: 64 px x 64   3: 64 px x 128   4: 32 px x 64   5: 64 px x 32
+template <int KS, int STRIDE, int NKK, int PIPE>
+int launch_tile2(int cfg, const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     switch (cfg) {
-    case 0: return launch_cfg<KS, STRIDE, 4, 1, 4, 1, NKK>(a, grid, s);
-    case 1: return launch_cfg<KS, STRIDE, 4, 1, 2, 2, NKK>(a, grid, s);
-    case 2: return launch_cfg<KS, STRIDE, 2, 2, 2, 2, NKK>(a, grid, s);
-    default: return launch_cfg<KS, STRIDE, 2, 2, 2, 4, NKK>(a, grid, s);
+    case 0: return launch_cfg<KS, STRIDE, 4, 1, 4, 1, NKK, PIPE>(a, grid, s);
+    case 1: return launch_cfg<KS, STRIDE, 4, 1, 2, 2, NKK, PIPE>(a, grid, s);
+    case 2: return launch_cfg<KS, STRIDE, 2, 2, 2, 2, NKK, PIPE>(a, grid, s);
+    case 3: return launch_cfg<KS, STRIDE, 2, 2, 2, 4, NKK, PIPE>(a, grid, s);
+    case 4: return launch_cfg<KS, STRIDE, 1, 4, 2, 1, NKK, PIPE>(a, grid, s);
+    default: return launch_cfg<KS, STRIDE, 2, 2, 2, 1, NKK, PIPE>(a, grid, s);
     }
+}
+template <int KS, int STRIDE, int NKK>
+int launch_tile(int cfg, int pipe, const ConvArgs &a, dim3 grid, hipStream_t s)
+{
+    return pipe ? launch_tile2<KS, STRIDE, NKK, 1>(cfg, a, grid, s) : launch_tile2<KS, STRIDE, NKK, 0>(cfg, a, grid, s);
 }
 
 }  // namespace
@@ -406,14 +438,14 @@ extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
     dim3 grid((unsigned)blocks, (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
     if (d->ks == 1) {
-        if (p.nkk == 4) rc = launch_tile<1, 1, 4>(p.cfg, a, grid, s);
-        else if (p.nkk == 2) rc = launch_tile<1, 1, 2>(p.cfg, a, grid, s);
-        else rc = launch_tile<1, 1, 1>(p.cfg, a, grid, s);
+        if (p.nkk == 4) rc = launch_tile<1, 1, 4>(p.cfg, p.pipe, a, grid, s);
+        else if (p.nkk == 2) rc = launch_tile<1, 1, 2>(p.cfg, p.pipe, a, grid, s);
+        else rc = launch_tile<1, 1, 1>(p.cfg, p.pipe, a, grid, s);
     } else if (d->stride == 2) {
-        rc = launch_tile<3, 2, 1>(p.cfg, a, grid, s);
+        rc = launch_tile<3, 2, 1>(p.cfg, p.pipe, a, grid, s);
     } else {
-        if (p.nkk == 2) rc = launch_tile<3, 1, 2>(p.cfg, a, grid, s);
-        else rc = launch_tile<3, 1, 1>(p.cfg, a, grid, s);
+        if (p.nkk == 2) rc = launch_tile<3, 1, 2>(p.cfg, p.pipe, a, grid, s);
+        else rc = launch_tile<3, 1, 1>(p.cfg, p.pipe, a, grid, s);
     }
     CT_CHECK_LAUNCH("ct_conv2d");
     if (p.splits > 1) {

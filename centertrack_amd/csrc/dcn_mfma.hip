@@ -118,16 +118,18 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     const int li = lane & 15, lg = lane >> 4;
     const int nt0 = cb * (2 * WN) + wn * WN;
     const int NCH16 = a.Cin >> 4;
+    // branch-free B fragment loads (n-tiles past the padded Cout clamp to the last valid tile)
+    const float *bptr[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
+    const size_t slab_stride = (size_t)a.NT << 8;
     auto load_b = [&](f32x4 (&b)[NKK][WN], int chunk, int tap) {
 #pragma unroll
         for (int kk = 0; kk < NKK; ++kk) {
             const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt) {
-                b[kk][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-                if (nt0 + nt < a.NT)
-                    b[kk][nt] = *reinterpret_cast<const f32x4 *>(a.wp + ((slab * a.NT + nt0 + nt) << 8) + (lane << 2));
-            }
+            for (int nt = 0; nt < WN; ++nt)
+                b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
         }
     };
     int aoff[WM];
@@ -155,11 +157,12 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
             const int cur = s & 1;
             int ntap = tap + 1, nchunk = chunk;
             if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
-            const bool more = (s + 1 < nsteps);
-            if (more) {
-                gather_load(nchunk, ntap);
-                load_b(bnext, nchunk, ntap);
-            }
+            nchunk = min(nchunk, c_end - 1);         // last step re-fetches valid (unused) data: no branch
+            gather_load(nchunk, ntap);
+            load_b(bnext, nchunk, ntap);
+            // keep the next step's 12 global loads ahead of this step's MFMAs (hipcc otherwise sinks
+            // them to their first use and exposes the full latency): neither VMEM nor MFMA may cross
+            __builtin_amdgcn_sched_barrier(0x386);
             const float *buf = lds_a + cur * BUF;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
@@ -175,13 +178,11 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bcur[kk][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
             }
-            if (more) {
-                gather_store(cur ^ 1);
+            gather_store(cur ^ 1);
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk)
+            for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-                    for (int nt = 0; nt < WN; ++nt) bcur[kk][nt] = bnext[kk][nt];
-            }
+                for (int nt = 0; nt < WN; ++nt) bcur[kk][nt] = bnext[kk][nt];
             __syncthreads();
             tap = ntap; chunk = nchunk;
         }
@@ -230,7 +231,9 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     p->tilesX = ct_cdiv(d->W, 16);
     p->tilesY = ct_cdiv(d->H, 4);
     p->BN = 64;
-    if (d->Cout >= 128 && (long)d->N * p->tilesX * p->tilesY * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
+    if (ct_tune_get(CT_TUNE_DCN_BN) == 128 && d->Cout >= 128) p->BN = 128;
+    else if (ct_tune_get(CT_TUNE_DCN_BN) == 64) p->BN = 64;
+    else if (d->Cout >= 128 && (long)d->N * p->tilesX * p->tilesY * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
     p->coutBlocks = ct_cdiv(d->Cout, p->BN);
     p->nchunks = d->Cin / 32;
     const long tiles = (long)d->N * p->tilesX * p->tilesY * p->coutBlocks;

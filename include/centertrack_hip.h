@@ -36,6 +36,11 @@ extern "C" {
 
 const char *ct_last_error(void);
 int ct_version(void);
+/* Experiment knobs of the launch heuristics (process-global; not part of the reference's
+ * interface): "conv_cfg" (-1 auto, 0..5 force a tile shape), "conv_pipe" (0/1 pinned B prefetch),
+ * "conv_small_tiles" (below this many workgroups pick the smaller tile), "splitk_target"
+ * (workgroups aimed at when splitting K), "dcn_bn" (0 auto, 64, 128). */
+int ct_set_tuning(const char *key, int value);
 
 /* ---- weight packing ---------------------------------------------------------------
  * MFMA-ready layout [tap][Cin/16][CoutPad/16][4][16][4] (CoutPad = Cout rounded up to

@@ -1,0 +1,123 @@
+#!/usr/bin/env python
+"""Micro-benchmark of the conv / DCN launches of one DLA-34 frame under the tuning knobs of
+ct_set_tuning (tile shape, pinned prefetch, split-K target).  Times each distinct layer shape
+in isolation with HIP events (back-to-back launches on the torch stream).
+
+    python tools/kbench.py [--batch 1] [--size 512] [--reps 30]
+"""
+import argparse
+import ctypes
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch  # noqa: E402
+
+from centertrack_amd import _lib, ops  # noqa: E402
+
+
+def time_call(fn, reps):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / reps      # us
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--batch', type=int, default=1)
+    ap.add_argument('--size', type=int, default=512)
+    ap.add_argument('--reps', type=int, default=30)
+    args = ap.parse_args()
+    lib = _lib.load()
+    dev = torch.device('cuda:0')
+    N, S = args.batch, args.size
+    ws = torch.empty(64 << 20, dtype=torch.float32, device=dev)
+
+    def tune(**kw):
+        for k, v in kw.items():
+            _lib.check(lib.ct_set_tuning(k.encode(), v))
+
+    # (name, count per frame, H(in), Cin, Cout, ks, stride)
+    convs = [('level0 3x3 16-16', 1, S, 16, 16, 3, 1), ('level1 3x3s2 16-32', 1, S, 16, 32, 3, 2),
+             ('l2 3x3s2 32-64', 1, S // 2, 32, 64, 3, 2), ('l2 3x3 64-64', 3, S // 4, 64, 64, 3, 1),
+             ('l2 root 1x1 128-64', 1, S // 4, 128, 64, 1, 1),
+             ('l3 3x3s2 64-128', 1, S // 4, 64, 128, 3, 2), ('l3 3x3 128-128', 7, S // 8, 128, 128, 3, 1),
+             ('l3 root 1x1 448-128', 1, S // 8, 448, 128, 1, 1),
+             ('l4 3x3s2 128-256', 1, S // 8, 128, 256, 3, 2), ('l4 3x3 256-256', 7, S // 16, 256, 256, 3, 1),
+             ('l4 root 1x1 896-256', 1, S // 16, 896, 256, 1, 1),
+             ('l5 3x3s2 256-512', 1, S // 16, 256, 512, 3, 2), ('l5 3x3 512-512', 3, S // 32, 512, 512, 3, 1),
+             ('l5 root 1x1 1280-512', 1, S // 32, 1280, 512, 1, 1),
+             ('off 3x3 64-27 @128', 5, S // 4, 64, 27, 3, 1), ('off 3x3 128-27 @64', 6, S // 8, 128, 27, 3, 1),
+             ('off 3x3 256-27 @32', 4, S // 16, 256, 27, 3, 1), ('off 3x3 512-27 @16', 1, S // 32, 512, 27, 3, 1),
+             ('heads.0 3x3 64-1280', 1, S // 4, 64, 1280, 3, 1), ('head.2 1x1 256-2', 5, S // 4, 256, 2, 1, 1)]
+    variants = [('auto', {}), ('pipe0', dict(conv_pipe=0)), ('cfg2', dict(conv_cfg=2)), ('cfg4', dict(conv_cfg=4)),
+                ('cfg5', dict(conv_cfg=5)), ('cfg3', dict(conv_cfg=3)), ('cfg2/sk256', dict(conv_cfg=2, splitk_target=256)),
+                ('cfg4/sk256', dict(conv_cfg=4, splitk_target=256)), ('cfg4/sk1024', dict(conv_cfg=4, splitk_target=1024)),
+                ('nosplit', dict(splitk_target=1)), ('cfg4/nosplit', dict(conv_cfg=4, splitk_target=1))]
+    print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
+    tot = {v[0]: 0.0 for v in variants}
+    for name, cnt, H, Cin, Cout, ks, stride in convs:
+        x = ops.new_view(N, H, H, Cin, dev)
+        x.buf.normal_()
+        w = ops.pack_weight(torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05)
+        Ho = H // stride
+        out = ops.new_view(N, Ho, Ho, Cout, dev, ld=(Cout + 3) // 4 * 4)
+        gf = 2.0 * ks * ks * Cin * Cout * N * Ho * Ho / 1e9
+        line = '%-24s %3d %8.3f |' % (name, cnt, gf)
+        for vname, kw in variants:
+            tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512)
+            tune(**kw)
+            if kw.get('conv_cfg', -1) in (0, 1, 5) and Cout > 32 * 8:
+                line += ' %12s' % '-'
+                continue
+            d = ops.make_conv_desc(x, w, Cout, ks, stride, out=out, relu=True, workspace=ws)
+            try:
+                t = time_call(lambda: _lib.check(lib.ct_conv2d(ctypes.byref(d), _lib.stream_ptr())), args.reps)
+                line += ' %7.1f/%4.0f' % (t, gf / t * 1e3)      # us / TFLOP/s
+                tot[vname] += t * cnt
+            except _lib.CTError:
+                line += ' %12s' % 'err'
+        print(line)
+        sys.stdout.flush()
+    print('%-24s %3s %8s |' % ('SUM(us per frame)', '', '') + ''.join(' %12.1f' % tot[v[0]] for v in variants))
+    tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512)
+
+    dcns = [('dcn 512-256 @16', 1, S // 32, 512, 256), ('dcn 256-256 @32', 1, S // 16, 256, 256),
+            ('dcn 256-128 @32', 2, S // 16, 256, 128), ('dcn 128-128 @64', 2, S // 8, 128, 128),
+            ('dcn 128-64 @64', 4, S // 8, 128, 64), ('dcn 256-64 @32', 1, S // 16, 256, 64),
+            ('dcn 64-64 @128', 5, S // 4, 64, 64)]
+    dvars = [('auto', {}), ('bn64', dict(dcn_bn=64)), ('bn128', dict(dcn_bn=128)), ('nosplit', dict(split=1)),
+             ('split2', dict(split=2)), ('split4', dict(split=4)), ('split8', dict(split=8))]
+    print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in dvars))
+    dtot = {v[0]: 0.0 for v in dvars}
+    for name, cnt, H, Cin, Cout in dcns:
+        x = ops.new_view(N, H, H, Cin, dev)
+        x.buf.normal_()
+        om = ops.new_view(N, H, H, 32, dev)
+        om.buf.normal_()
+        om.buf[..., 18:].sigmoid_()
+        w = ops.pack_weight(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05)
+        out = ops.new_view(N, H, H, Cout, dev)
+        gf = 2.0 * 9 * Cin * Cout * N * H * H / 1e9
+        line = '%-24s %3d %8.3f |' % (name, cnt, gf)
+        for vname, kw in dvars:
+            tune(dcn_bn=kw.get('dcn_bn', 0))
+            d = ops.make_dcn_desc(x, om, w, Cout, None, None, True, out, workspace=ws, split_k=kw.get('split', 0))
+            t = time_call(lambda: _lib.check(lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr())), args.reps)
+            line += ' %7.1f/%4.0f' % (t, gf / t * 1e3)
+            dtot[vname] += t * cnt
+        print(line)
+        sys.stdout.flush()
+    print('%-24s %3s %8s |' % ('SUM(us per frame)', '', '') + ''.join(' %12.1f' % dtot[v[0]] for v in dvars))
+    tune(dcn_bn=0)
+
+
+if __name__ == '__main__':
+    main()
