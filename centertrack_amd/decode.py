@@ -1,0 +1,43 @@
+"""Drop-in for ``generic_decode`` (SURVEY.md boundary B3).
+
+``generic_decode(output, K=100, opt=None) -> dict`` follows src/lib/model/decode.py:83-182
+(non-pose branches) with its helpers ``_nms`` / ``_topk`` / ``_tranpose_and_gather_feat``
+(src/lib/model/utils.py:16-87): same keys, shapes and dtypes (``clses`` is float32,
+decode.py:100), ``output['tracking'] *= 0`` in place under ``opt.zero_tracking``, ``{}``
+when there is no ``'hm'``.  Underneath it is ONE ``ct_decode`` call (3x3 max NMS + exact
+top-K over classes x pixels + all head gathers + box assembly into a packed [B,K,F]
+buffer); the dict entries are views of that buffer.
+
+Exact-tie order (unspecified by ``torch.topk``): lower class first, then lower pixel index.
+CUDA fp32 NCHW tensors only; no CPU fallback.
+"""
+import torch
+
+from . import _lib, ops
+
+_UNSUPPORTED = ('hps', 'hm_hp', 'hp_offset')      # multi_pose branch, decode.py:161-171
+
+
+def generic_decode(output, K=100, opt=None):
+    if 'hm' not in output:
+        return {}
+    for k in _UNSUPPORTED:
+        if k in output:
+            raise _lib.CTError('generic_decode: the pose head %r is not implemented on the HIP path' % k)
+    if opt is not None and getattr(opt, 'zero_tracking', False):
+        output['tracking'] *= 0
+    hm = output['hm']
+    if not hm.is_cuda or hm.dtype != torch.float32:
+        raise _lib.CTError('generic_decode runs on an MI355X (cuda fp32 tensors); no CPU fallback')
+    heads = {k: v.contiguous() for k, v in output.items() if k in _lib.HEAD_INDEX}
+    dec = ops.Decoder(hm.contiguous(), heads, K)
+    packed = dec.run()
+    ret = dec.unpack(packed)
+    # (decode.py:159: with an ltrb_amodal head the kernel already writes the amodal box into 'bboxes')
+    if output.get('pre_inds', None) is not None:       # decode.py:173-180
+        width = hm.shape[3]
+        pre_inds = output['pre_inds']
+        pre_ys = (pre_inds / width).int().float()
+        pre_xs = (pre_inds % width).int().float()
+        ret['pre_cts'] = torch.cat([pre_xs.unsqueeze(2), pre_ys.unsqueeze(2)], dim=2)
+    return ret
