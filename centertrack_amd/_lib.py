@@ -36,7 +36,7 @@ class ConvDesc(ctypes.Structure):
                 ('sig_lo', ctypes.c_int), ('sig_hi', ctypes.c_int),
                 ('dep_lo', ctypes.c_int), ('dep_hi', ctypes.c_int), ('depth_scale', ctypes.c_float),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-                ('split_k', ctypes.c_int)]
+                ('split_k', ctypes.c_int), ('algo', ctypes.c_int)]
 
 
 class DcnDesc(ctypes.Structure):
@@ -48,7 +48,7 @@ class DcnDesc(ctypes.Structure):
                 ('y', ctypes.c_void_p), ('ldy', ctypes.c_int),
                 ('flags', ctypes.c_int),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-                ('split_k', ctypes.c_int)]
+                ('split_k', ctypes.c_int), ('algo', ctypes.c_int)]
 
 
 class DecodeDesc(ctypes.Structure):

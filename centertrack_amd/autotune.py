@@ -1,0 +1,178 @@
+"""Per-layer launch-shape selection by measurement ("measure, don't guess").
+
+Every dense conv / DCNv2 launch of a plan can run with several tile shapes (row-tiled
+workgroups of 256px x 16 .. 32px x 64 couts with optional split-K, or the K-split-in-
+workgroup kernel, see csrc/conv_mfma.hip; 64 / 128 couts per workgroup and split-K for
+csrc/dcn_mfma.hip).  Which one is fastest depends on (map size, channels, batch) in ways a
+static rule gets wrong at the extremes (16x16 maps with 1280 channels, 27-cout offset convs),
+so the first time a (shape) key is seen its candidates are timed on the device -- a HIP graph
+of back-to-back launches of the real descriptor, i.e. device time incl. the kernel boundary,
+free of host launch cost -- and the winner is cached for the process (optionally in a JSON
+file named by ``CENTERTRACK_TUNE_CACHE`` so that a deployment replays identical choices: the
+choice fixes the fp32 summation order, hence the last bits of the results).
+
+``CENTERTRACK_AUTOTUNE=0`` keeps the built-in heuristics (``algo = 0``).
+"""
+import ctypes
+import json
+import os
+
+import torch
+
+from . import _lib
+
+_CACHE = {}
+_LOADED = False
+_SCRATCH = {}
+REPS = 12
+
+
+def enabled():
+    return os.environ.get('CENTERTRACK_AUTOTUNE', '1') != '0'
+
+
+def _cache_path():
+    return os.environ.get('CENTERTRACK_TUNE_CACHE', '')
+
+
+def _load_file():
+    global _LOADED
+    if _LOADED:
+        return
+    _LOADED = True
+    p = _cache_path()
+    if p and os.path.exists(p):
+        with open(p) as f:
+            for k, v in json.load(f).items():
+                _CACHE[k] = tuple(v)
+
+
+def _save_file():
+    p = _cache_path()
+    if p:
+        with open(p, 'w') as f:
+            json.dump({k: list(v) for k, v in sorted(_CACHE.items())}, f, indent=0)
+
+
+def _scratch(nbytes, device):
+    key = str(device)
+    t = _SCRATCH.get(key)
+    if t is None or t.numel() * 4 < nbytes:
+        t = torch.empty(max(nbytes, 1 << 20) // 4 + 4, dtype=torch.float32, device=device)
+        _SCRATCH[key] = t
+    return t
+
+
+def _time_graph(fn, reps=REPS):
+    """us per launch of ``fn`` (a C-ABI call on the current stream), via graph replay."""
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        if fn() != 0:
+            torch.cuda.current_stream().wait_stream(side)
+            return None
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    best = None
+    for _ in range(2):
+        e0.record()
+        g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        t = e0.elapsed_time(e1) * 1e3 / reps
+        best = t if best is None else min(best, t)
+    del g
+    return best
+
+
+def _conv_key(d):
+    return 'conv:%d,%d,%d,%d,%d,%d,%d,%d,%d' % (d.N, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride,
+                                                 1 if d.res else 0, 1 if (d.flags & _lib.CT_OUT_NCHW) else 0)
+
+
+def _dcn_key(d):
+    return 'dcn:%d,%d,%d,%d,%d' % (d.N, d.H, d.W, d.Cin, d.Cout)
+
+
+_REG_BN = [16, 32, 64, 128, 64, 32]          # couts per workgroup of the row-tiled shapes 0..5
+_KS = [(2, 2, 4), (1, 2, 4), (1, 2, 8), (2, 4, 4), (2, 2, 8)]
+
+
+def _conv_candidates(d):
+    cout_pad = (d.Cout + 15) // 16 * 16
+    cands = [(0, 0)]
+    for cfg, bn in enumerate(_REG_BN):
+        if bn > max(32, cout_pad) or (cout_pad + bn - 1) // bn > 24 or cfg == 3:
+            continue
+        cands.append((cfg + 1, 0))
+        cands.append((cfg + 1, 1))
+    for i, (wm, wn, wk) in enumerate(_KS):
+        if d.Cin % (16 * wk) or (d.stride == 2 and wm == 2 and wk == 8):
+            continue
+        if 16 * wn > max(32, cout_pad):
+            continue
+        cands.append((101 + i, 1))
+    return cands
+
+
+def _dcn_candidates(d):
+    cands = [(0, 0)]
+    nchunks = d.Cin // 32
+    for bn in ([64, 128] if d.Cout >= 128 else [64]):
+        for sk in (1, 2, 4, 8, 16):
+            if sk <= nchunks:
+                cands.append((bn, sk))
+    return cands
+
+
+def _tune(d, key, cands, call, ws_bytes_fn, device):
+    _load_file()
+    if key in _CACHE:
+        return _CACHE[key]
+    saved = (d.algo, d.split_k, d.workspace, d.workspace_bytes)
+    results = []
+    for algo, sk in cands:
+        d.algo, d.split_k = algo, sk
+        d.workspace, d.workspace_bytes = None, 0
+        need = ws_bytes_fn(ctypes.byref(d))
+        ws = _scratch(need, device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        t = _time_graph(lambda: call(ctypes.byref(d), _lib.stream_ptr()))
+        if t is not None:
+            results.append((t, algo, sk))
+    d.algo, d.split_k, d.workspace, d.workspace_bytes = saved
+    if not results:
+        best = (0, 0, 0.0)
+    else:
+        results.sort()
+        best = (results[0][1], results[0][2], round(results[0][0], 2))
+    _CACHE[key] = best
+    _save_file()
+    return best
+
+
+def tune_conv(d, device):
+    """Pick (algo, split_k) for a ct_conv_desc; sets them on ``d`` and returns them."""
+    lib = _lib.load()
+    algo, sk, _ = _tune(d, _conv_key(d), _conv_candidates(d), lib.ct_conv2d, lib.ct_conv2d_workspace_bytes, device)
+    d.algo, d.split_k = algo, sk
+    return algo, sk
+
+
+def tune_dcn(d, device):
+    lib = _lib.load()
+    algo, sk, _ = _tune(d, _dcn_key(d), _dcn_candidates(d), lib.ct_dcn_v2, lib.ct_dcn_v2_workspace_bytes, device)
+    d.algo, d.split_k = algo, sk
+    return algo, sk
+
+
+def report():
+    """{key: (algo, split_k, us)} of everything tuned so far (for DESIGN.md / debugging)."""
+    return dict(_CACHE)

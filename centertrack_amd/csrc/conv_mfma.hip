@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], breg[s % RING][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
             }
-            stage_store(cur ^ 1);
+            if (c + 1 < c_end) stage_store(cur ^ 1);   // (a single-chunk launch allocates one buffer only)
             __syncthreads();
         }
     }
@@ -224,6 +224,196 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
                 ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// K-split variant for layers with few output tiles (deep levels: 16x16 .. 64x64 maps with
+// 128..1280 input channels).  ALL waves of a workgroup own the SAME small output tile
+// (WM rows x 16 px  x  16*WN couts) and split the reduction: wave k contracts the k-th
+// 16-channel slab of every 16*WK-channel chunk (all taps); the WK partial tiles are summed
+// through LDS in wave order (deterministic) and the epilogue runs once.  This replaces the
+// global split-K (partials through HBM + a second reduce launch) for these layers and gives
+// every SIMD >= 1-2 waves even when M x N is only 256 x 512.
+template <int KS, int STRIDE, int WM, int WN, int WK>
+struct KsCfg {
+    static constexpr int NTHR = 64 * WK;
+    static constexpr int BN = 16 * WN;
+    static constexpr int PH = (WM - 1) * STRIDE + KS;
+    static constexpr int PW = 15 * STRIDE + KS;
+    static constexpr int PP = PH * PW;
+    static constexpr int SLAB = PP * 16;
+    static constexpr int BUF = WK * SLAB;
+    static constexpr int ITEMS = WK * PP * 4;
+    static constexpr int NR = (ITEMS + NTHR - 1) / NTHR;
+    static constexpr int RED = WK * WM * WN * 256;
+    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)((2 * BUF > RED) ? 2 * BUF : RED);
+};
+
+template <int KS, int STRIDE, int WM, int WN, int WK>
+__global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
+{
+    using C = KsCfg<KS, STRIDE, WM, WN, WK>;
+    constexpr int PAD = KS / 2;
+    constexpr int S = KS * KS;                       // steps (taps) per chunk and wave
+    constexpr int D = 2;                             // B prefetch distance (steps)
+    constexpr int R = D + 1;                         // register ring
+    constexpr int U = (S % R == 0) ? 1 : R;          // chunk unroll so that ring slots stay static
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = tid >> 6;                       // = K slab inside a chunk
+
+    int bid = blockIdx.x;
+    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int tx = bid % a.tilesX; bid /= a.tilesX;
+    const int ty = bid % a.tilesY; bid /= a.tilesY;
+    const int n = bid;
+    const int oy0 = ty * WM, ox0 = tx * 16;
+    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
+    const int split = blockIdx.y;
+    const int c_begin = split * a.chunksPerSplit;
+    const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
+    const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
+
+    int goff[C::NR], loff[C::NR];
+#pragma unroll
+    for (int r = 0; r < C::NR; ++r) {
+        const int it = tid + C::NTHR * r;
+        if (it < C::ITEMS) {
+            const int q = it & 3;
+            const int pp = it >> 2;
+            const int kk = pp / C::PP;
+            const int P = pp - kk * C::PP;
+            const int py = P / C::PW, px = P - py * C::PW;
+            const int iy = iy0 + py, ix = ix0 + px;
+            loff[r] = kk * C::SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
+            goff[r] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4) : -1;
+        } else {
+            loff[r] = -1;
+            goff[r] = -1;
+        }
+    }
+    f32x4 stage[C::NR];
+    auto stage_load = [&](int chunk) {
+        const int coff = chunk * (16 * WK);
+#pragma unroll
+        for (int r = 0; r < C::NR; ++r) {
+            const bool ok = goff[r] >= 0;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
+            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float *dst = lds + buf * C::BUF;
+#pragma unroll
+        for (int r = 0; r < C::NR; ++r)
+            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
+    };
+
+    const int li = lane & 15, lg = lane >> 4;
+    int pbase[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) pbase[mt] = (mt * STRIDE) * C::PW + li * STRIDE;
+    const int nt0 = cb * WN;
+    const int NCH16 = a.Cin >> 4;
+    const float *bptr[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
+    const size_t slab_stride = (size_t)a.NT << 8;
+    // B fragment of (chunk, tap) for THIS wave's slab; chunks past the end clamp (loaded, never used)
+    auto load_b = [&](f32x4 (&b)[WN], int chunk, int tap) {
+        const size_t slab = (size_t)tap * NCH16 + (size_t)min(chunk, c_end - 1) * WK + wave;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
+    };
+
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (c_begin < c_end) {
+        stage_load(c_begin);
+        stage_store(0);
+        f32x4 breg[R][WN];
+#pragma unroll
+        for (int p = 0; p < D; ++p) load_b(breg[p % R], c_begin + p / S, p % S);
+        __syncthreads();
+        for (int c0 = c_begin; c0 < c_end; c0 += U) {
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int c = c0 + u;
+                if (c < c_end) {
+                    const int cur = (c - c_begin) & 1;
+                    stage_load(min(c + 1, c_end - 1));
+                    __builtin_amdgcn_sched_barrier(0x38E);
+                    const float *buf = lds + cur * C::BUF + wave * C::SLAB;
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        const int g = u * S + s;                    // static position in the unrolled body
+                        const int sp = s + D;
+                        load_b(breg[(g + D) % R], c + sp / S, sp % S);
+                        __builtin_amdgcn_sched_barrier(0x38E);
+                        const int ky = s / KS, kx = s % KS;
+                        f32x4 af[WM];
+#pragma unroll
+                        for (int mt = 0; mt < WM; ++mt) {
+                            const int P = pbase[mt] + ky * C::PW + kx;
+                            af[mt] = *reinterpret_cast<const f32x4 *>(buf + P * 16 + ((lg ^ ((P >> 1) & 2)) << 2));
+                        }
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < WN; ++nt)
+                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], breg[g % R][nt][e],
+                                                                                      acc[mt][nt], 0, 0, 0);
+                    }
+                    if (c + 1 < c_end) stage_store(cur ^ 1);
+                    __syncthreads();
+                }
+            }
+        }
+    }
+
+    // ---- cross-wave reduction through LDS (wave order 0..WK-1), then the epilogue ------------
+    constexpr int T = WM * WN;
+    float *red = lds;
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt)
+            *reinterpret_cast<f32x4 *>(red + ((wave * T + mt * WN + nt) * 64 + lane) * 4) = acc[mt][nt];
+    __syncthreads();
+#pragma unroll
+    for (int t0 = 0; t0 < T; t0 += WK) {
+        const int t = t0 + wave;
+        if (t < T) {
+            f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (t * 64 + lane) * 4);
+#pragma unroll
+            for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
+            const int mt = t / WN, nt = t - mt * WN;
+            const int oy = oy0 + mt;
+            if (a.ws) {
+                const size_t Mtot = (size_t)a.N * a.epi.Ho * a.epi.Wo;
+                float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
+                const int co = (nt0 + nt) * 16 + li;
+                if (oy < a.epi.Ho && co < a.wsCout) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int ox = ox0 + lg * 4 + e;
+                        if (ox < a.epi.Wo) wsp[(((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox) * a.wsCout + co] = sum[e];
+                    }
+                }
+            } else {
+                ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane);
+            }
+        }
     }
 }
 
@@ -277,11 +467,16 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, float 
 
 struct Plan {
     int pipe;
+    int ks;        // >= 0: K-split kernel configuration (kKs table), -1: regular kernel
     int cfg;       // see launch_tile2
     int TH, BN, nkk;
     int tilesX, tilesY, coutBlocks, nchunks, splits, chunksPerSplit;
     int Ho, Wo, NT;
 };
+
+// K-split configurations {WM, WN, WK}: tile = WM rows x 16 px x 16*WN couts, WK waves split K
+constexpr int kNumKs = 5;
+const int kKs[kNumKs][3] = {{2, 2, 4}, {1, 2, 4}, {1, 2, 8}, {2, 4, 4}, {2, 2, 8}};
 
 int make_plan(const ct_conv_desc *d, Plan *p)
 {
@@ -305,10 +500,11 @@ int make_plan(const ct_conv_desc *d, Plan *p)
     else if (d->Cout <= 32) p->cfg = (tiles_of(1) >= ct_tune_get(CT_TUNE_CONV_SMALL_TILES)) ? 1 : 5;
     else {
         p->cfg = 2;
-        if (d->Cout >= 128 && tiles_of(3) >= 512) p->cfg = 3;
-        else if (tiles_of(2) < ct_tune_get(CT_TUNE_CONV_SMALL_TILES)) p->cfg = 4;
+        if (tiles_of(2) < ct_tune_get(CT_TUNE_CONV_SMALL_TILES) || tiles_of(2) >= 2048) p->cfg = 4;
     }
     if (ct_tune_get(CT_TUNE_CONV_CFG) >= 0) p->cfg = ct_tune_get(CT_TUNE_CONV_CFG);
+    if (d->algo >= 1 && d->algo <= 6) p->cfg = d->algo - 1;
+    else if (d->algo != 0 && !(d->algo >= 101 && d->algo < 101 + kNumKs)) CT_FAIL_ARG("ct_conv2d: unknown algo %d", d->algo);
     p->pipe = ct_tune_get(CT_TUNE_CONV_PIPE);
     p->TH = kTH[p->cfg];
     p->BN = kBN[p->cfg];
@@ -322,8 +518,49 @@ int make_plan(const ct_conv_desc *d, Plan *p)
     else if (d->stride == 2) p->nkk = 1;
     else p->nkk = (c16 % 2 == 0) ? 2 : 1;
     p->nchunks = c16 / p->nkk;
-    const long tiles = (long)d->N * p->tilesX * p->tilesY * p->coutBlocks;
+    long tiles = (long)d->N * p->tilesX * p->tilesY * p->coutBlocks;
+    // ---- K-split kernel for layers with few tiles (see conv_ksplit_kernel) -------------------
+    p->ks = -1;
+    {
+        auto ks_ok = [&](int id) {
+            if (id < 0 || id >= kNumKs) return false;
+            if (d->Cin % (16 * kKs[id][2])) return false;
+            if (d->stride == 2 && kKs[id][0] == 2 && kKs[id][2] == 8) return false;      // LDS patch too large
+            return true;
+        };
+        auto ks_wgs = [&](int id) {
+            return (long)d->N * p->tilesX * ct_cdiv(p->Ho, kKs[id][0]) * ct_cdiv(d->Cout, 16 * kKs[id][1]);
+        };
+        int want = ct_tune_get(CT_TUNE_CONV_KS);
+        if (d->algo >= 101) {
+            want = d->algo - 101;
+            if (!ks_ok(want)) CT_FAIL_ARG("ct_conv2d: algo %d cannot run Cin=%d stride=%d", d->algo, d->Cin, d->stride);
+        } else if (d->algo >= 1) want = -2;
+        if (want >= 0) {
+            if (ks_ok(want)) p->ks = want;
+        } else if (want == -1 && d->split_k <= 0 && tiles_of(2) < ct_tune_get(CT_TUNE_CONV_KS_BELOW)) {
+            static const int order[5] = {3, 0, 1, 4, 2};           // largest tile first
+            long best_waves = 0;
+            for (int i = 0; i < 5; ++i) {
+                const int id = order[i];
+                if (!ks_ok(id)) continue;
+                if (16 * kKs[id][1] > p->NT * 16 && kKs[id][1] > 2) continue;     // tile wider than the layer
+                const long waves = ks_wgs(id) * kKs[id][2];
+                if (waves >= ct_tune_get(CT_TUNE_CONV_KS_WAVES)) { p->ks = id; break; }
+                if (waves > best_waves) { best_waves = waves; p->ks = id; }
+            }
+        }
+        if (p->ks >= 0) {
+            p->TH = kKs[p->ks][0];
+            p->BN = 16 * kKs[p->ks][1];
+            p->tilesY = ct_cdiv(p->Ho, p->TH);
+            p->coutBlocks = ct_cdiv(d->Cout, p->BN);
+            p->nchunks = d->Cin / (16 * kKs[p->ks][2]);
+            tiles = (long)d->N * p->tilesX * p->tilesY * p->coutBlocks;
+        }
+    }
     int splits = d->split_k;
+    if (p->ks >= 0 && splits <= 0) splits = 1;
     if (splits <= 0) {
         splits = 1;
         if (d->workspace && tiles < 256) {
@@ -358,7 +595,8 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
                                   (int)C::LDS_BYTES);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), C::LDS_BYTES, s, a);
+    const size_t lds = (a.chunksPerSplit == 1) ? C::LDS_BYTES / 2 : C::LDS_BYTES;
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
     return CT_OK;
 }
 
@@ -380,6 +618,39 @@ template <int KS, int STRIDE, int NKK>
 int launch_tile(int cfg, int pipe, const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     return pipe ? launch_tile2<KS, STRIDE, NKK, 1>(cfg, a, grid, s) : launch_tile2<KS, STRIDE, NKK, 0>(cfg, a, grid, s);
+}
+
+template <int KS, int STRIDE, int WM, int WN, int WK>
+int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
+{
+    using C = KsCfg<KS, STRIDE, WM, WN, WK>;
+    static_assert(C::LDS_BYTES <= 160 * 1024, "LDS patch too large");
+    auto k = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK>;
+    static bool attr_set = false;
+    if (!attr_set && C::LDS_BYTES > 48 * 1024) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)C::LDS_BYTES);
+        attr_set = true;
+    }
+    size_t lds = C::LDS_BYTES;
+    if (a.chunksPerSplit == 1) {
+        lds = sizeof(float) * (size_t)((C::BUF > C::RED) ? C::BUF : C::RED);
+    }
+    hipLaunchKernelGGL(k, grid, dim3(64 * WK), lds, s, a);
+    return CT_OK;
+}
+template <int KS, int STRIDE>
+int launch_ks(int id, const ConvArgs &a, dim3 grid, hipStream_t s)
+{
+    switch (id) {
+    case 0: return launch_ks_cfg<KS, STRIDE, 2, 2, 4>(a, grid, s);
+    case 1: return launch_ks_cfg<KS, STRIDE, 1, 2, 4>(a, grid, s);
+    case 2: return launch_ks_cfg<KS, STRIDE, 1, 2, 8>(a, grid, s);
+    case 3: return launch_ks_cfg<KS, STRIDE, 2, 4, 4>(a, grid, s);
+    default:
+        if constexpr (STRIDE == 1) return launch_ks_cfg<KS, STRIDE, 2, 2, 8>(a, grid, s);
+        else return CT_ERR_ARG;
+    }
 }
 
 }  // namespace
@@ -437,7 +708,11 @@ extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_conv2d: grid too large");
     dim3 grid((unsigned)blocks, (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
-    if (d->ks == 1) {
+    if (p.ks >= 0) {
+        if (d->ks == 1) rc = launch_ks<1, 1>(p.ks, a, grid, s);
+        else if (d->stride == 2) rc = launch_ks<3, 2>(p.ks, a, grid, s);
+        else rc = launch_ks<3, 1>(p.ks, a, grid, s);
+    } else if (d->ks == 1) {
         if (p.nkk == 4) rc = launch_tile<1, 1, 4>(p.cfg, p.pipe, a, grid, s);
         else if (p.nkk == 2) rc = launch_tile<1, 1, 2>(p.cfg, p.pipe, a, grid, s);
         else rc = launch_tile<1, 1, 1>(p.cfg, p.pipe, a, grid, s);

@@ -231,7 +231,10 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     p->tilesX = ct_cdiv(d->W, 16);
     p->tilesY = ct_cdiv(d->H, 4);
     p->BN = 64;
-    if (ct_tune_get(CT_TUNE_DCN_BN) == 128 && d->Cout >= 128) p->BN = 128;
+    if (d->algo != 0 && d->algo != 64 && d->algo != 128) CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
+    if (d->algo == 128) p->BN = 128;
+    else if (d->algo == 64) p->BN = 64;
+    else if (ct_tune_get(CT_TUNE_DCN_BN) == 128 && d->Cout >= 128) p->BN = 128;
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 64) p->BN = 64;
     else if (d->Cout >= 128 && (long)d->N * p->tilesX * p->tilesY * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
     p->coutBlocks = ct_cdiv(d->Cout, p->BN);

@@ -14,7 +14,7 @@ from collections import OrderedDict
 
 import torch
 
-from . import _lib, ops
+from . import _lib, autotune, ops
 from .ops import View
 from .weights import CHANNELS, LEVELS, dla34_param_shapes
 
@@ -162,6 +162,7 @@ class DLASegHIP(torch.nn.Module):
             raise _lib.CTError('input %dx%d must be a multiple of 32 (reference pads to 32 too, opts.py:297)' % (H, W))
         plan = {'launches': [], 'ws_need': 0}
         L = plan['launches']
+        tune = autotune.enabled()
 
         def alloc(h, w, c):
             return ops.new_view(N, h, w, c, dev)
@@ -169,6 +170,8 @@ class DLASegHIP(torch.nn.Module):
         def add_conv(name, x, pk, cout, ks, stride=1, relu=True, res=None, out=None, **kw):
             wp, sc, sh = pk
             d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out, **kw)
+            if tune:
+                autotune.tune_conv(d, dev)
             plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
             L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw'))))
             return out
@@ -238,9 +241,13 @@ class DLASegHIP(torch.nn.Module):
                 om_bufs[key] = ops.new_view(N, x.H, x.W, 32, dev)
             om = om_bufs[key]
             d = ops.make_conv_desc(x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
+            if tune:
+                autotune.tune_conv(d, dev)
             plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
             L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk)))
             dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out)
+            if tune:
+                autotune.tune_dcn(dd, dev)
             plan['ws_need'] = max(plan['ws_need'], lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd)))
             L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk)))
             return out
@@ -270,6 +277,9 @@ class DLASegHIP(torch.nn.Module):
         hc = self.head_conv
         mid = alloc(feat.H, feat.W, hc * nh)
         d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid)
+        if tune:
+            autotune.tune_conv(d, dev)
+        plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
         L.append(_Launch('heads.0', 'conv', d, (feat, mid)))
         outputs = OrderedDict()
         for j, (hname, c) in enumerate(self.heads.items()):
@@ -279,6 +289,8 @@ class DLASegHIP(torch.nn.Module):
             dep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
             d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=sig, dep=dep,
                                    depth_scale=self.depth_scale)
+            if tune:
+                autotune.tune_conv(d, dev)
             plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
             L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o)))
             outputs[hname] = o

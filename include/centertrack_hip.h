@@ -39,7 +39,9 @@ int ct_version(void);
 /* Experiment knobs of the launch heuristics (process-global; not part of the reference's
  * interface): "conv_cfg" (-1 auto, 0..5 force a tile shape), "conv_pipe" (0/1 pinned B prefetch),
  * "conv_small_tiles" (below this many workgroups pick the smaller tile), "splitk_target"
- * (workgroups aimed at when splitting K), "dcn_bn" (0 auto, 64, 128). */
+ * (workgroups aimed at when splitting K), "dcn_bn" (0 auto, 64, 128), "conv_ks" (-1 auto, -2 never,
+ * 0..4 force a K-split-in-workgroup tile), "conv_ks_below" / "conv_ks_waves" (K-split kernel is
+ * used below this many 64x64 tiles / sized to reach this many waves). */
 int ct_set_tuning(const char *key, int value);
 
 /* ---- weight packing ---------------------------------------------------------------
@@ -70,6 +72,10 @@ typedef struct ct_conv_desc {
     int dep_lo, dep_hi; float depth_scale;
     float *workspace; size_t workspace_bytes;   /* split-K partials; may be NULL (no split) */
     int split_k;                                /* 0 = choose automatically */
+    int algo;                                   /* 0 = heuristic; 1..6 = tile shape 0..5 of the row-tiled
+                                                   kernel; 101..105 = K-split-in-workgroup shape 0..4
+                                                   (CT_ERR_ARG if the shape cannot run this layer); picked
+                                                   per layer by the host-side autotuner */
 } ct_conv_desc;
 int ct_conv2d(const ct_conv_desc *d, void *stream);
 size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);
@@ -91,6 +97,7 @@ typedef struct ct_dcn_desc {
     int flags;                                  /* CT_RELU */
     float *workspace; size_t workspace_bytes;
     int split_k;
+    int algo;                                   /* 0 = heuristic; 64 / 128 = couts per workgroup */
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);

@@ -101,6 +101,47 @@ def test_conv2d_matches_torch(device, case):
     assert float(ob[..., :4].min()) == -7.0 and float(ob[..., 4 + Cout:].min()) == -7.0, 'wrote outside its slice'
 
 
+KS_CASES = [
+    # ks-config id, N, H, W, Cin, Cout, ks, stride, split_k
+    (0, 1, 9, 21, 128, 128, 3, 1, 0),      # 32px x 32co, 4 waves; ragged edges
+    (1, 2, 5, 16, 256, 96, 3, 1, 0),       # 16px x 32co; Cout not a multiple of the tile
+    (2, 1, 4, 4, 512, 512, 3, 1, 0),       # 8 waves split K (level5)
+    (3, 1, 16, 16, 64, 64, 3, 1, 0),       # 32px x 64co (level2-like)
+    (4, 1, 8, 8, 256, 256, 3, 1, 0),       # 32px x 32co, 8 waves
+    (0, 1, 8, 12, 448, 128, 1, 1, 0),      # root 1x1 (chunk loop unrolled by 3, 7 chunks)
+    (2, 1, 4, 4, 1280, 512, 1, 1, 0),      # level5 root 1x1, 8 waves (10 chunks)
+    (1, 1, 8, 8, 64, 128, 1, 1, 0),        # project 1x1, a single chunk
+    (0, 1, 16, 16, 64, 128, 3, 2, 0),      # stride 2 (level3 entry)
+    (1, 1, 8, 8, 128, 256, 3, 2, 0),
+    (3, 1, 10, 18, 128, 64, 3, 2, 0),
+    (1, 1, 8, 8, 256, 64, 3, 1, 2),        # K-split kernel + global split-K on top
+]
+
+
+@pytest.mark.parametrize('case', KS_CASES, ids=lambda c: 'ks%d_N%d_%dx%d_%d-%d_k%ds%d_sk%d' % c)
+def test_conv2d_ksplit_kernel_matches_torch(device, case):
+    """the K-split-in-workgroup conv kernel (forced through ct_set_tuning) == torch fp32"""
+    from centertrack_amd import _lib, ops
+    ksid, N, H, W, Cin, Cout, ks, stride, split_k = case
+    x = F.relu(_rand(N, Cin, H, W, seed=30))
+    w = _rand(Cout, Cin, ks, ks, seed=31, scale=(Cin * ks * ks) ** -0.5)
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(32)) + 0.5
+    shift = _rand(Cout, seed=33)
+    y = F.conv2d(x, w, None, stride=stride, padding=ks // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1)
+    res = _rand(*y.shape, seed=34)
+    y = F.relu(y + res)
+    lib = _lib.load()
+    try:
+        _lib.check(lib.ct_set_tuning(b'conv_ks', ksid))
+        out = ops.conv2d(ops.view_from_nchw(x.to(device)), ops.pack_weight(w.to(device)), Cout, ks, stride,
+                         scale=scale.to(device), shift=shift.to(device), res=ops.view_from_nchw(res.to(device)),
+                         relu=True, split_k=split_k)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(lib.ct_set_tuning(b'conv_ks', -1))
+    _close(out.to_nchw(), y, msg='ksplit conv')
+
+
 def test_conv2d_nchw_output_sigmoid_dep(device):
     from centertrack_amd import ops
     N, H, W, Cin = 2, 8, 12, 256

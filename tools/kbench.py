@@ -17,16 +17,29 @@ from centertrack_amd import _lib, ops  # noqa: E402
 
 
 def time_call(fn, reps):
-    for _ in range(3):
+    """us per launch, measured as the replay time of a HIP graph holding `reps` back-to-back launches
+    (device time incl. the inter-kernel boundary, without the host launch cost of this Python loop)."""
+    fn()
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
         fn()
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(reps):
+            fn()
+    g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
-    for _ in range(reps):
-        fn()
+    for _ in range(3):
+        g.replay()
     e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e3 / reps      # us
+    return e0.elapsed_time(e1) * 1e3 / (3 * reps)      # us
 
 
 def main():
@@ -47,7 +60,10 @@ def main():
     # (name, count per frame, H(in), Cin, Cout, ks, stride)
     convs = [('level0 3x3 16-16', 1, S, 16, 16, 3, 1), ('level1 3x3s2 16-32', 1, S, 16, 32, 3, 2),
              ('l2 3x3s2 32-64', 1, S // 2, 32, 64, 3, 2), ('l2 3x3 64-64', 3, S // 4, 64, 64, 3, 1),
-             ('l2 root 1x1 128-64', 1, S // 4, 128, 64, 1, 1),
+             ('l2 root 1x1 128-64', 1, S // 4, 128, 64, 1, 1), ('l2 proj 1x1 32-64', 1, S // 4, 32, 64, 1, 1),
+             ('l3 proj 1x1 64-128', 2, S // 8, 64, 128, 1, 1), ('l3 root 1x1 256-128', 1, S // 8, 256, 128, 1, 1),
+             ('l4 proj 1x1 128-256', 2, S // 16, 128, 256, 1, 1), ('l4 root 1x1 512-256', 1, S // 16, 512, 256, 1, 1),
+             ('l5 proj 1x1 256-512', 1, S // 32, 256, 512, 1, 1),
              ('l3 3x3s2 64-128', 1, S // 4, 64, 128, 3, 2), ('l3 3x3 128-128', 7, S // 8, 128, 128, 3, 1),
              ('l3 root 1x1 448-128', 1, S // 8, 448, 128, 1, 1),
              ('l4 3x3s2 128-256', 1, S // 8, 128, 256, 3, 2), ('l4 3x3 256-256', 7, S // 16, 256, 256, 3, 1),
@@ -57,10 +73,10 @@ def main():
              ('off 3x3 64-27 @128', 5, S // 4, 64, 27, 3, 1), ('off 3x3 128-27 @64', 6, S // 8, 128, 27, 3, 1),
              ('off 3x3 256-27 @32', 4, S // 16, 256, 27, 3, 1), ('off 3x3 512-27 @16', 1, S // 32, 512, 27, 3, 1),
              ('heads.0 3x3 64-1280', 1, S // 4, 64, 1280, 3, 1), ('head.2 1x1 256-2', 5, S // 4, 256, 2, 1, 1)]
-    variants = [('auto', {}), ('pipe0', dict(conv_pipe=0)), ('cfg2', dict(conv_cfg=2)), ('cfg4', dict(conv_cfg=4)),
-                ('cfg5', dict(conv_cfg=5)), ('cfg3', dict(conv_cfg=3)), ('cfg2/sk256', dict(conv_cfg=2, splitk_target=256)),
-                ('cfg4/sk256', dict(conv_cfg=4, splitk_target=256)), ('cfg4/sk1024', dict(conv_cfg=4, splitk_target=1024)),
-                ('nosplit', dict(splitk_target=1)), ('cfg4/nosplit', dict(conv_cfg=4, splitk_target=1))]
+    variants = [('auto', {}), ('old', dict(conv_ks=-2)), ('ks0', dict(conv_ks=0)), ('ks1', dict(conv_ks=1)),
+                ('ks2', dict(conv_ks=2)), ('ks3', dict(conv_ks=3)), ('ks4', dict(conv_ks=4)),
+                ('old/cfg2', dict(conv_ks=-2, conv_cfg=2)), ('old/cfg4', dict(conv_ks=-2, conv_cfg=4)),
+                ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('old/nosplit', dict(conv_ks=-2, splitk_target=1))]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
     tot = {v[0]: 0.0 for v in variants}
     for name, cnt, H, Cin, Cout, ks, stride in convs:
@@ -72,7 +88,7 @@ def main():
         gf = 2.0 * ks * ks * Cin * Cout * N * Ho * Ho / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in variants:
-            tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512)
+            tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1)
             tune(**kw)
             if kw.get('conv_cfg', -1) in (0, 1, 5) and Cout > 32 * 8:
                 line += ' %12s' % '-'
@@ -87,7 +103,7 @@ def main():
         print(line)
         sys.stdout.flush()
     print('%-24s %3s %8s |' % ('SUM(us per frame)', '', '') + ''.join(' %12.1f' % tot[v[0]] for v in variants))
-    tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512)
+    tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1)
 
     dcns = [('dcn 512-256 @16', 1, S // 32, 512, 256), ('dcn 256-256 @32', 1, S // 16, 256, 256),
             ('dcn 256-128 @32', 2, S // 16, 256, 128), ('dcn 128-128 @64', 2, S // 8, 128, 128),
