@@ -125,7 +125,7 @@ def _conv_candidates(d):
 def _dcn_candidates(d):
     cands = [(0, 0)]
     nchunks = d.Cin // 32
-    for bn in ([64, 128] if d.Cout >= 128 else [64]):
+    for bn in ([64, 128, 3264, 32128] if d.Cout >= 128 else [64, 3264]):
         for sk in (1, 2, 4, 8, 16):
             if sk <= nchunks:
                 cands.append((bn, sk))
@@ -159,18 +159,18 @@ def _tune(d, key, cands, call, ws_bytes_fn, device):
 
 
 def tune_conv(d, device):
-    """Pick (algo, split_k) for a ct_conv_desc; sets them on ``d`` and returns them."""
+    """Pick (algo, split_k) for a ct_conv_desc; sets them on ``d``; returns (algo, split_k, us)."""
     lib = _lib.load()
-    algo, sk, _ = _tune(d, _conv_key(d), _conv_candidates(d), lib.ct_conv2d, lib.ct_conv2d_workspace_bytes, device)
+    algo, sk, us = _tune(d, _conv_key(d), _conv_candidates(d), lib.ct_conv2d, lib.ct_conv2d_workspace_bytes, device)
     d.algo, d.split_k = algo, sk
-    return algo, sk
+    return algo, sk, us
 
 
 def tune_dcn(d, device):
     lib = _lib.load()
-    algo, sk, _ = _tune(d, _dcn_key(d), _dcn_candidates(d), lib.ct_dcn_v2, lib.ct_dcn_v2_workspace_bytes, device)
+    algo, sk, us = _tune(d, _dcn_key(d), _dcn_candidates(d), lib.ct_dcn_v2, lib.ct_dcn_v2_workspace_bytes, device)
     d.algo, d.split_k = algo, sk
-    return algo, sk
+    return algo, sk, us
 
 
 def report():

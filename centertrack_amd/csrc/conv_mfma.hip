@@ -160,7 +160,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             const int cur = (c - c_begin) & 1;
             const int cnext = min(c + 1, c_end - 1);   // clamped: the last chunk re-fetches itself (unused)
             stage_load(cnext);
-            if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x38E);
+            if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x386);
             const float *buf = lds + cur * C::BUF;
 #pragma unroll
             for (int s = 0; s < S; ++s) {
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                 }
                 if (RING == 1) load_b(breg[0], c, kk, tap);
                 // pin the prefetch loads here (hipcc otherwise sinks them towards their use)
-                if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x38E);
+                if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x386);
                 const int ky = tap / KS, kx = tap % KS;
                 f32x4 af[WM];
 #pragma unroll
@@ -350,14 +350,14 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
                 if (c < c_end) {
                     const int cur = (c - c_begin) & 1;
                     stage_load(min(c + 1, c_end - 1));
-                    __builtin_amdgcn_sched_barrier(0x38E);
+                    __builtin_amdgcn_sched_barrier(0x386);
                     const float *buf = lds + cur * C::BUF + wave * C::SLAB;
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const int g = u * S + s;                    // static position in the unrolled body
                         const int sp = s + D;
                         load_b(breg[(g + D) % R], c + sp / S, sp % S);
-                        __builtin_amdgcn_sched_barrier(0x38E);
+                        __builtin_amdgcn_sched_barrier(0x386);
                         const int ky = s / KS, kx = s % KS;
                         f32x4 af[WM];
 #pragma unroll

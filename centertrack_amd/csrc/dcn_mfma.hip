@@ -17,6 +17,8 @@
 // straight from L2 to VGPRs one step ahead; v_mfma_f32_16x16x4_f32 accumulates in fp32.
 // The gather of step s+1 is in flight while the MFMAs of step s run.  Chunk-outer /
 // tap-inner order keeps the 9 taps' footprint of one chunk in L1.
+#include <type_traits>
+
 #include "ct_common.h"
 
 namespace {
@@ -34,10 +36,14 @@ struct DcnArgs {
     EpiArgs epi;
 };
 
-template <int WN>   // wave grid is 2 (pixel rows) x 2 (couts); wave tile = 2 m-tiles x WN n-tiles
+// BM = pixels per workgroup (64 = 4 rows x 16, 32 = 2 rows x 16); wave grid is (BM/32) pixel-row
+// pairs x (128/BM) cout groups; wave tile = 2 m-tiles x WN n-tiles => BN = 16 * WN * 128 / BM couts.
+template <int BM, int WN>
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 {
-    constexpr int BM = 64, NKK = 2, WM = 2;
+    constexpr int NKK = 2, WM = 2;
+    constexpr int WGM = BM / 32, WGN = 4 / WGM;
+    constexpr int ROWS = BM / 16;
     constexpr int SLAB = BM * 16;            // floats
     constexpr int BUF = NKK * SLAB;
     // LDS: A tile double buffer | table offsets int4[BM*9] | table weights float4[BM*9]
@@ -48,14 +54,14 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     int bid = blockIdx.x;
     const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
-    const int oy0 = ty * 4, ox0 = tx * 16;
+    const int oy0 = ty * ROWS, ox0 = tx * 16;
     const int split = blockIdx.y;
     const int c_begin = split * a.chunksPerSplit;
     const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
@@ -66,7 +72,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
     for (int it = tid; it < BM * 9; it += 256) {
         const int m = it / 9, k = it - m * 9;
-        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);   // m < BM
         int o[4] = {0, 0, 0, 0};
         float wgt[4] = {0.f, 0.f, 0.f, 0.f};
         if (oy < a.H && ox < a.W) {
@@ -91,32 +97,38 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     __syncthreads();
 
     // ---- gather assignment: thread -> pixel m = tid>>2, channel quad q = tid&3, both slabs ----
-    const int gm = tid >> 2, gq = tid & 3;
+    // BM = 64: thread -> (pixel tid>>2, quad tid&3) for both slabs; BM = 32: (pixel tid>>3, slab (tid>>2)&1, quad tid&3)
+    constexpr int GK = (BM == 64) ? NKK : 1;            // slabs gathered per thread
+    const int gm = (BM == 64) ? (tid >> 2) : (tid >> 3), gq = tid & 3;
+    const int gk0 = (BM == 64) ? 0 : ((tid >> 2) & 1);
     const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);   // float offset inside a slab
-    f32x4 cv[NKK][4];
-    f32x4 gw;
-    auto gather_load = [&](int chunk, int tap) {
+    // two gather stages in flight (register slots 0/1): the corner loads of step s+2 are issued
+    // before the MFMAs of step s and consumed (blend + LDS store) after the MFMAs of step s+1
+    f32x4 cv[2][GK][4];
+    f32x4 gw[2];
+    auto gather_load = [&](int slot, int chunk, int tap) {
         const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
-        gw = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
-        const float *base = xin + chunk * 32 + gq * 4;
+        gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
+        const float *base = xin + chunk * 32 + gk0 * 16 + gq * 4;
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            cv[kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * 16);
-            cv[kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * 16);
-            cv[kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * 16);
-            cv[kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * 16);
+        for (int kk = 0; kk < GK; ++kk) {
+            cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * 16);
+            cv[slot][kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * 16);
+            cv[slot][kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * 16);
+            cv[slot][kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * 16);
         }
     };
-    auto gather_store = [&](int buf) {
+    auto gather_store = [&](int slot, int buf) {
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            const f32x4 v = gw[0] * cv[kk][0] + gw[1] * cv[kk][1] + gw[2] * cv[kk][2] + gw[3] * cv[kk][3];
-            *reinterpret_cast<f32x4 *>(lds_a + buf * BUF + kk * SLAB + lslot) = v;
+        for (int kk = 0; kk < GK; ++kk) {
+            const f32x4 v = gw[slot][0] * cv[slot][kk][0] + gw[slot][1] * cv[slot][kk][1] +
+                            gw[slot][2] * cv[slot][kk][2] + gw[slot][3] * cv[slot][kk][3];
+            *reinterpret_cast<f32x4 *>(lds_a + buf * BUF + (gk0 + kk) * SLAB + lslot) = v;
         }
     };
 
     const int li = lane & 15, lg = lane >> 4;
-    const int nt0 = cb * (2 * WN) + wn * WN;
+    const int nt0 = cb * (WGN * WN) + wn * WN;
     const int NCH16 = a.Cin >> 4;
     // branch-free B fragment loads (n-tiles past the padded Cout clamp to the last valid tile)
     const float *bptr[WN];
@@ -147,23 +159,35 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 
     const int nsteps = (c_end - c_begin) * 9;
     if (nsteps > 0) {
-        gather_load(c_begin, 0);
-        gather_store(0);
-        f32x4 bcur[NKK][WN], bnext[NKK][WN];
-        load_b(bcur, c_begin, 0);
+        // (chunk, tap) of a step index, clamped to the last valid step (extra fetches are never used)
+        auto step_ct = [&](int s, int &chunk, int &tap) {
+            s = min(s, nsteps - 1);
+            const int c = s / 9;
+            chunk = c_begin + c;
+            tap = s - c * 9;
+        };
+        f32x4 bq[2][NKK][WN];
+        int ch, tp;
+        step_ct(0, ch, tp);
+        gather_load(0, ch, tp);
+        load_b(bq[0], ch, tp);
+        step_ct(1, ch, tp);
+        gather_load(1, ch, tp);
+        gather_store(0, 0);
         __syncthreads();
-        int chunk = c_begin, tap = 0;
-        for (int s = 0; s < nsteps; ++s) {
-            const int cur = s & 1;
-            int ntap = tap + 1, nchunk = chunk;
-            if (ntap == 9) { ntap = 0; nchunk = chunk + 1; }
-            nchunk = min(nchunk, c_end - 1);         // last step re-fetches valid (unused) data: no branch
-            gather_load(nchunk, ntap);
-            load_b(bnext, nchunk, ntap);
-            // keep the next step's 12 global loads ahead of this step's MFMAs (hipcc otherwise sinks
-            // them to their first use and exposes the full latency): neither VMEM nor MFMA may cross
+        // one step: G(s+2) | M(s) | ST(s+1) | barrier; P = s & 1 is static (loop unrolled by 2)
+        auto step = [&](auto ptag, int s) {
+            constexpr int P = decltype(ptag)::value;
+            int c1, t1, c2, t2;
+            step_ct(s + 1, c1, t1);
+            step_ct(s + 2, c2, t2);
+            load_b(bq[P ^ 1], c1, t1);
+            // slot P held step s, already blended into LDS buffer P by the previous iteration
+            gather_load(P, c2, t2);
+            // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
+            // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
-            const float *buf = lds_a + cur * BUF;
+            const float *buf = lds_a + P * BUF;
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk) {
                 f32x4 af[WM];
@@ -175,16 +199,16 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
                     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
                         for (int nt = 0; nt < WN; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bcur[kk][nt][e],
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bq[P][kk][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
             }
-            gather_store(cur ^ 1);
-#pragma unroll
-            for (int kk = 0; kk < NKK; ++kk)
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt) bcur[kk][nt] = bnext[kk][nt];
+            __builtin_amdgcn_sched_barrier(0x386);
+            if (s + 1 < nsteps) gather_store(P ^ 1, P ^ 1);      // step s+1's A tile (loaded one step ago)
             __syncthreads();
-            tap = ntap; chunk = nchunk;
+        };
+        for (int s = 0; s < nsteps; s += 2) {
+            step(std::integral_constant<int, 0>{}, s);
+            if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
         }
     }
 
@@ -216,7 +240,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 }
 
 struct DcnPlan {
-    int BN, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
+    int BM, BN, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
 };
 
 int make_plan(const ct_dcn_desc *d, DcnPlan *p)
@@ -229,14 +253,19 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_dcn_v2: NCHW output unsupported");
     p->NT = ct_cdiv(d->Cout, 16);
     p->tilesX = ct_cdiv(d->W, 16);
-    p->tilesY = ct_cdiv(d->H, 4);
+    p->BM = 64;
     p->BN = 64;
-    if (d->algo != 0 && d->algo != 64 && d->algo != 128) CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
-    if (d->algo == 128) p->BN = 128;
+    // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile
+    if (d->algo != 0 && d->algo != 64 && d->algo != 128 && d->algo != 3264 && d->algo != 32128)
+        CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
+    if (d->algo == 3264) { p->BM = 32; p->BN = 64; }
+    else if (d->algo == 32128) { p->BM = 32; p->BN = 128; }
+    else if (d->algo == 128) p->BN = 128;
     else if (d->algo == 64) p->BN = 64;
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 128 && d->Cout >= 128) p->BN = 128;
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 64) p->BN = 64;
-    else if (d->Cout >= 128 && (long)d->N * p->tilesX * p->tilesY * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
+    else if (d->Cout >= 128 && (long)d->N * p->tilesX * ct_cdiv(d->H, 4) * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
+    p->tilesY = ct_cdiv(d->H, p->BM / 16);
     p->coutBlocks = ct_cdiv(d->Cout, p->BN);
     p->nchunks = d->Cin / 32;
     const long tiles = (long)d->N * p->tilesX * p->tilesY * p->coutBlocks;
@@ -321,8 +350,13 @@ extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
     dim3 grid((unsigned)blocks, (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
-    if (p.BN == 128) hipLaunchKernelGGL(dcn_mfma_kernel<4>, grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(dcn_mfma_kernel<2>, grid, dim3(256), 0, s, a);
+    if (p.BM == 32) {
+        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1>), grid, dim3(256), 0, s, a);
+    } else {
+        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2>), grid, dim3(256), 0, s, a);
+    }
     CT_CHECK_LAUNCH("ct_dcn_v2");
     if (p.splits > 1) {
         const size_t Mtot = (size_t)d->N * d->H * d->W;

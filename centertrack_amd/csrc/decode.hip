@@ -2,26 +2,26 @@
 // assembly in two launches, one packed [B,K,F] output (one D2H copy instead of 8-14).
 //
 // The reference does per-class top-K over h*w then top-K over C*K (utils.py:71-87); the
-// result is the global top-K of all (class, pixel) scores, which is what is computed here:
-//   stage 1  one workgroup per (image, class, 4096-pixel segment): rows of the segment
-//            (+1 halo row each side) -> LDS, NMS from LDS, order-preserving 64-bit keys
-//            (score bits : ~pixel index) -> exact radix select of the segment's top-K.
-//   stage 2  one workgroup per image: radix select of the top-K over all candidates with
-//            keys (score bits : ~(class*h*w + pixel)), bitonic sort of the K winners,
-//            gathers + box arithmetic, packed row store.
-// Keys are distinct, so the order is fully deterministic: score descending, then lower
-// class, then lower pixel index (torch.topk leaves exact ties unspecified).  Byte/index
-// work: HBM/L2-bound, no matrix cores.
+// result is the global top-K of all (class, pixel) scores, which is what is computed here.
+// Keys are order-preserving 64-bit integers (score bits : ~flat index), all distinct, so
+// the order is fully deterministic: score descending, then lower class, then lower pixel
+// index (torch.topk leaves exact ties unspecified).
+//   stage 1  one workgroup per (image, class, segment of <= 1024 pixels): rows of the
+//            segment (+1 halo row each side) -> LDS, NMS from LDS, the strictly positive
+//            survivors (~10 % of the pixels) are compacted with wave ballots into an LDS
+//            list; if more than K survive, rank counting keeps the segment's top K.
+//   stage 2  one workgroup per image: exact radix select (wave-aggregated LDS histogram
+//            atomics) of the K-th key over all candidates, bitonic sort of the K winners,
+//            gathers + box arithmetic, packed row store.  If an image has fewer than K
+//            strictly positive survivors (near-empty maps) the K winners are instead selected
+//            over ALL pixels with the NMS recomputed from HBM (slow, exact, rare).
+// Byte/index work: HBM/L2-bound, no matrix cores.
 #include "ct_common.h"
 
 namespace {
 
-constexpr int SEG = 4096;          // pixels per stage-1 workgroup
+constexpr int SEG_MAX = 1024;      // pixels per stage-1 workgroup (<=)
 constexpr int MAXK = 512;
-constexpr size_t S1_BCAST = SEG * sizeof(unsigned long long);
-constexpr size_t S1_HIST = S1_BCAST + 16;
-constexpr size_t S1_SLOT = S1_HIST + 1024;
-constexpr size_t S1_ROWS = S1_SLOT + 16;
 
 __device__ __forceinline__ unsigned f2ord(float f)
 {
@@ -33,13 +33,32 @@ __device__ __forceinline__ float ord2f(unsigned o)
     return __uint_as_float((o & 0x80000000u) ? (o & 0x7fffffffu) : ~o);
 }
 
-// Exact K-th largest of n distinct 64-bit keys read through `get(i)`; returns the
-// threshold T such that exactly min(K, n) keys are >= T.  All threads of the block call it.
+// histogram increment with same-digit lanes of a wave combined into one LDS atomic (scores of a
+// heat map share their exponent bits, so plain per-lane atomics serialise on a few bins)
+__device__ __forceinline__ void hist_add(unsigned *hist, unsigned digit, bool active)
+{
+    unsigned long long todo = __ballot(active);
+    const int lane = threadIdx.x & 63;
+#pragma unroll 1
+    for (int it = 0; it < 4 && todo; ++it) {
+        const int leader = __ffsll((long long)todo) - 1;
+        const unsigned d0 = __shfl(digit, leader);
+        const unsigned long long same = __ballot(active && digit == d0) & todo;
+        if (lane == leader) atomicAdd(&hist[d0], (unsigned)__popcll(same));
+        todo &= ~same;
+    }
+    if (active && ((todo >> lane) & 1ull)) atomicAdd(&hist[digit], 1u);
+}
+
+// Exact K-th largest of the n keys read through `get(i)` (key 0 = "no candidate", skipped;
+// all other keys distinct); returns T such that exactly K keys are >= T.  The caller guarantees
+// that at least K non-zero keys exist.  All threads of the block call it.
 template <typename Get>
 __device__ unsigned long long radix_select_kth(Get get, int n, int K, unsigned *hist /*[256] LDS*/,
                                                unsigned long long *bcast /*[2] LDS*/)
 {
-    if (K >= n) return 0ull;
+    __shared__ int scan_tmp[256];
+    __shared__ int wsum[4];
     unsigned long long prefix = 0ull;
     int need = K;
     for (int d = 7; d >= 0; --d) {
@@ -47,52 +66,68 @@ __device__ unsigned long long radix_select_kth(Get get, int n, int K, unsigned *
         __syncthreads();
         const int sh = d * 8;
         const unsigned long long himask = (d == 7) ? 0ull : (~0ull << (sh + 8));
-        for (int i = threadIdx.x; i < n; i += blockDim.x) {
-            const unsigned long long k = get(i);
-            if ((k & himask) == prefix) atomicAdd(&hist[(unsigned)(k >> sh) & 255u], 1u);
+        const int nround = (n + blockDim.x - 1) / blockDim.x * blockDim.x;
+        for (int i = threadIdx.x; i < nround; i += blockDim.x) {
+            const unsigned long long k = (i < n) ? get(i) : 0ull;
+            hist_add(hist, (unsigned)(k >> sh) & 255u, k != 0ull && (k & himask) == prefix);
         }
         __syncthreads();
-        if (threadIdx.x == 0) {
-            int above = 0, b = 255;
-            for (; b > 0; --b) {
-                const int c = (int)hist[b];
-                if (above + c >= need) break;
-                above += c;
+        // the bin holding the need-th largest key: parallel suffix sums over the 256 bins (4 waves)
+        if (threadIdx.x < 256) {
+            const int b = threadIdx.x, ln = b & 63;
+            const int c = (int)hist[b];
+            int suf = c;                                   // inclusive suffix sum inside the wave
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const int t = __shfl_down(suf, o);
+                if (ln + o < 64) suf += t;
             }
-            bcast[0] = (unsigned long long)b;
-            bcast[1] = (unsigned long long)(need - above);
+            if (ln == 0) wsum[b >> 6] = suf;               // total of this wave's 64 bins
+            scan_tmp[b] = suf;
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int b = threadIdx.x;
+            int hi = 0;
+            for (int wv = (b >> 6) + 1; wv < 4; ++wv) hi += wsum[wv];
+            const int incl = scan_tmp[b] + hi;             // keys in bins >= b
+            const int above = incl - (int)hist[b];         // keys in bins >  b
+            if (above < need && incl >= need) {
+                bcast[0] = (unsigned long long)b;
+                // every key of the chosen bin is wanted -> the prefix alone is the threshold
+                bcast[1] = (incl - above == need - above) ? ~0ull : (unsigned long long)(need - above);
+            }
         }
         __syncthreads();
         prefix |= bcast[0] << sh;
-        need = (int)bcast[1];
+        const unsigned long long nd = bcast[1];
         __syncthreads();
+        if (nd == ~0ull) break;
+        need = (int)nd;
     }
     return prefix;
 }
 
 struct Stage1Args {
     const float *hm;
-    unsigned long long *cand;   // [B*C*nseg][K]
-    int B, C, h, w, K, nseg;
+    unsigned long long *cand;   // [B*C*nseg][K], unused slots = 0
+    int B, C, h, w, K, nseg, seg;
 };
 
 __global__ __launch_bounds__(256) void decode_stage1_kernel(Stage1Args a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    // all LDS in the dynamic region so every carve offset is a multiple of 16 bytes
-    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);                    // [SEG]
-    unsigned long long *bcast = reinterpret_cast<unsigned long long *>(smem + S1_BCAST);        // [2]
-    unsigned *hist = reinterpret_cast<unsigned *>(smem + S1_HIST);                              // [256]
-    int &slot = *reinterpret_cast<int *>(smem + S1_SLOT);
-    float *rows = reinterpret_cast<float *>(smem + S1_ROWS);                                    // [nrows*w]
+    unsigned long long *keys = reinterpret_cast<unsigned long long *>(smem);                    // [SEG_MAX]
+    float *rows = reinterpret_cast<float *>(smem + SEG_MAX * sizeof(unsigned long long));      // [nrows*w]
+    __shared__ int npos;
 
     int bid = blockIdx.x;
     const int seg = bid % a.nseg; bid /= a.nseg;
     const int c = bid % a.C;
     const int b = bid / a.C;
     const int HW = a.h * a.w;
-    const int p_lo = seg * SEG;
-    const int p_hi = min(HW, p_lo + SEG);
+    const int p_lo = seg * a.seg;
+    const int p_hi = min(HW, p_lo + a.seg);
     const int nloc = p_hi - p_lo;
     const float *map = a.hm + ((size_t)b * a.C + c) * HW;
 
@@ -100,46 +135,60 @@ __global__ __launch_bounds__(256) void decode_stage1_kernel(Stage1Args a)
     const int r_lo = max(0, y_lo - 1), r_hi = min(a.h - 1, y_hi + 1);
     const int nstage = (r_hi - r_lo + 1) * a.w;
     for (int i = threadIdx.x; i < nstage; i += 256) rows[i] = map[r_lo * a.w + i];
-    if (threadIdx.x == 0) slot = 0;
+    if (threadIdx.x == 0) npos = 0;
     __syncthreads();
 
-    for (int i = threadIdx.x; i < nloc; i += 256) {
-        const int p = p_lo + i;
-        const int y = p / a.w, x = p - y * a.w;
-        const float v = rows[(y - r_lo) * a.w + x];
-        float m = v;
+    const int lane = threadIdx.x & 63;
+    const int nround = (nloc + 255) / 256 * 256;
+    for (int i = threadIdx.x; i < nround; i += 256) {
+        bool pos = false;
+        unsigned long long key = 0ull;
+        if (i < nloc) {
+            const int p = p_lo + i;
+            const int y = p / a.w, x = p - y * a.w;
+            const float v = rows[(y - r_lo) * a.w + x];
+            float m = v;
 #pragma unroll
-        for (int dy = -1; dy <= 1; ++dy) {
-            const int yy = y + dy;
-            if (yy < 0 || yy >= a.h) continue;
+            for (int dy = -1; dy <= 1; ++dy) {
+                const int yy = y + dy;
+                if (yy < 0 || yy >= a.h) continue;
 #pragma unroll
-            for (int dx = -1; dx <= 1; ++dx) {
-                const int xx = x + dx;
-                if (xx < 0 || xx >= a.w) continue;
-                m = fmaxf(m, rows[(yy - r_lo) * a.w + xx]);
+                for (int dx = -1; dx <= 1; ++dx) {
+                    const int xx = x + dx;
+                    if (xx < 0 || xx >= a.w) continue;
+                    m = fmaxf(m, rows[(yy - r_lo) * a.w + xx]);
+                }
             }
+            const float s = (m == v) ? v : v * 0.0f;      // heat * keep   (utils.py:57-58)
+            pos = s > 0.0f;
+            key = ((unsigned long long)f2ord(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
         }
-        const float s = (m == v) ? v : v * 0.0f;      // heat * keep   (utils.py:57-58)
-        keys[i] = ((unsigned long long)f2ord(s) << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)p);
+        const unsigned long long mask = __ballot(pos);
+        int base = 0;
+        if (lane == 0 && mask) base = atomicAdd(&npos, (int)__popcll(mask));
+        base = __shfl(base, 0);
+        if (pos) keys[base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = key;
     }
     __syncthreads();
 
-    const unsigned long long T = radix_select_kth([&](int i) { return keys[i]; }, nloc, a.K, hist, bcast);
+    const int n = npos;
     unsigned long long *out = a.cand + (size_t)blockIdx.x * a.K;
-    for (int i = threadIdx.x; i < nloc; i += 256) {
-        const unsigned long long k = keys[i];
-        if (k >= T) {
-            const int s = atomicAdd(&slot, 1);
-            if (s < a.K) out[s] = k;
+    if (n <= a.K) {
+        for (int i = threadIdx.x; i < a.K; i += 256) out[i] = (i < n) ? keys[i] : 0ull;
+    } else {
+        // rank counting: keys are distinct, the rank of a key = number of larger keys
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const unsigned long long k = keys[i];
+            int r = 0;
+            for (int j = 0; j < n; ++j) r += (keys[j] > k) ? 1 : 0;
+            if (r < a.K) out[r] = k;
         }
     }
-    __syncthreads();
-    for (int i = slot + threadIdx.x; i < a.K; i += 256) out[i] = 0ull;   // pad (only when nloc < K)
 }
 
 struct Stage2Args {
     const unsigned long long *cand;
-    const float *hm_unused;
+    const float *hm;
     const float *heads[CT_NUM_HEADS];
     int head_ch[CT_NUM_HEADS];
     float *out;
@@ -147,51 +196,172 @@ struct Stage2Args {
     int B, C, h, w, K, nseg, F;
 };
 
+// NMS'd score key of flat index f = cls*HW + p, straight from HBM (slow path only)
+__device__ __forceinline__ unsigned long long key_from_map(const float *hm_b, int C, int h, int w, unsigned f)
+{
+    const int HW = h * w;
+    const int cls = (int)(f / (unsigned)HW);
+    const int p = (int)(f - (unsigned)cls * (unsigned)HW);
+    const int y = p / w, x = p - y * w;
+    const float *map = hm_b + (size_t)cls * HW;
+    const float v = map[p];
+    float m = v;
+    for (int dy = -1; dy <= 1; ++dy) {
+        const int yy = y + dy;
+        if (yy < 0 || yy >= h) continue;
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int xx = x + dx;
+            if (xx < 0 || xx >= w) continue;
+            m = fmaxf(m, map[yy * w + xx]);
+        }
+    }
+    const float s = (m == v) ? v : v * 0.0f;
+    return ((unsigned long long)f2ord(s) << 32) | (unsigned long long)(0xFFFFFFFFu - f);
+}
+
+// Visit every candidate slot with the loads of 8 slots per thread in flight at once (a plain
+// one-load-per-iteration loop is latency-bound: one L2 round trip per slot and thread).  f(i, raw)
+// is called by all threads the same number of times (slots past the end come as raw = 0).
+template <typename F>
+__device__ __forceinline__ void scan_cands(const unsigned long long *cand, int M2, int tid, int NT, F f)
+{
+    constexpr int U = 8;
+    for (int i0 = tid; i0 - tid < M2; i0 += NT * U) {
+        unsigned long long raw[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int i = i0 + u * NT;
+            raw[u] = (i < M2) ? cand[i] : 0ull;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) f(i0 + u * NT, raw[u]);
+    }
+}
+
+constexpr int FCAP = 2048;        // capacity of the stage-2 filtered candidate list
+
 __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
 {
     __shared__ unsigned hist[256];
     __shared__ unsigned long long bcast[2];
     __shared__ unsigned long long win[MAXK];
-    __shared__ int slot;
+    __shared__ unsigned long long lmax[1024];
+    __shared__ unsigned long long filt[FCAP];
+    __shared__ unsigned long long Lsh;
+    __shared__ int slot, total, nf;
     const int b = blockIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int HW = a.h * a.w;
     const int M2 = a.C * a.nseg * a.K;
     const unsigned long long *cand = a.cand + (size_t)b * M2;
     const int per_class = a.nseg * a.K;
 
-    // key2 = score bits : ~(class*HW + pixel); pads (key 0) stay 0
-    auto get = [&](int i) -> unsigned long long {
-        const unsigned long long k = cand[i];
+    // key2 = score bits : ~(class*HW + pixel); empty slots (key 0) stay 0
+    auto key2 = [&](int i, unsigned long long k) -> unsigned long long {
         if (k == 0ull) return 0ull;
         const unsigned cls = (unsigned)(i / per_class);
         const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
         return (k & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (cls * (unsigned)HW + p));
     };
+    auto get = [&](int i) -> unsigned long long { return key2(i, cand[i]); };
     int KP = 1;
     while (KP < a.K) KP <<= 1;
-    for (int i = threadIdx.x; i < KP; i += blockDim.x) win[i] = 0ull;
-    if (threadIdx.x == 0) slot = 0;
+    for (int i = tid; i < KP; i += NT) win[i] = 0ull;
+    if (tid == 0) { slot = 0; total = 0; nf = 0; Lsh = 1ull; }
     __syncthreads();
-    const unsigned long long T = radix_select_kth(get, M2, a.K, hist, bcast);
-    for (int i = threadIdx.x; i < M2; i += blockDim.x) {
-        const unsigned long long k = get(i);
-        if (k >= T && k != 0ull) {
-            const int s = atomicAdd(&slot, 1);
-            if (s < a.K) win[s] = k;
+    // ---- pass 1: every thread's largest candidate + the number of candidates --------------------
+    {
+        unsigned long long mx = 0ull;
+        int cnt = 0;
+        scan_cands(cand, M2, tid, NT, [&](int i, unsigned long long raw) {
+            const unsigned long long k = key2(i, raw);
+            cnt += (k != 0ull) ? 1 : 0;
+            mx = (k > mx) ? k : mx;
+        });
+        lmax[tid] = mx;
+        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
+        if (lane == 0 && cnt) atomicAdd(&total, cnt);
+    }
+    __syncthreads();
+    bool need_sort = true;
+    if (total >= a.K) {
+        // L = K-th largest of the per-thread maxima (distinct keys): a lower bound of the K-th largest
+        // candidate, so {k >= L} contains the top K and, for randomly spread scores, little more
+        // (ranked among the first 256 threads' maxima only: ranking all 1024 costs more than the
+        //  ~4x longer filtered list it would save)
+        if (tid < 256) {
+            const int G = NT < 256 ? NT : 256;
+            const unsigned long long my = lmax[tid];
+            int r = 0;
+            for (int j = 0; j < G; ++j) r += (lmax[j] > my) ? 1 : 0;
+            if (my != 0ull && r == a.K - 1) Lsh = my;       // (fewer than K non-empty threads: L stays 1)
+        }
+        __syncthreads();
+        const unsigned long long L = Lsh;
+        scan_cands(cand, M2, tid, NT, [&](int i, unsigned long long raw) {
+            const unsigned long long k = key2(i, raw);
+            const bool hit = k >= L && k != 0ull;
+            const unsigned long long mask = __ballot(hit);
+            int base = 0;
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane == leader) base = atomicAdd(&nf, (int)__popcll(mask));
+                base = __shfl(base, leader);
+            }
+            if (hit) {
+                const int sl = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                if (sl < FCAP) filt[sl] = k;
+            }
+        });
+        __syncthreads();
+        const int n = nf;
+        if (n <= FCAP) {
+            // exact ranks among the filtered keys; the K best land in win[] already sorted
+            for (int i = tid; i < n; i += NT) {
+                const unsigned long long k = filt[i];
+                int r = 0;
+                for (int j = 0; j < n; ++j) r += (filt[j] > k) ? 1 : 0;
+                if (r < a.K) win[r] = k;
+            }
+            need_sort = false;
+        } else {
+            // adversarial layout (the top keys sit in few threads' stripes): plain radix select
+            const unsigned long long T = radix_select_kth(get, M2, a.K, hist, bcast);
+            for (int i = tid; i < M2; i += NT) {
+                const unsigned long long k = get(i);
+                if (k >= T && k != 0ull) {
+                    const int s = atomicAdd(&slot, 1);
+                    if (s < a.K) win[s] = k;
+                }
+            }
+        }
+    } else {
+        // fewer than K positive survivors: exact selection over every (class, pixel) of the image
+        const float *hm_b = a.hm + (size_t)b * a.C * HW;
+        const int NALL = a.C * HW;
+        auto getall = [&](int i) -> unsigned long long { return key_from_map(hm_b, a.C, a.h, a.w, (unsigned)i); };
+        const unsigned long long T = radix_select_kth(getall, NALL, a.K, hist, bcast);
+        for (int i = tid; i < NALL; i += NT) {
+            const unsigned long long k = getall(i);
+            if (k >= T) {
+                const int s = atomicAdd(&slot, 1);
+                if (s < a.K) win[s] = k;
+            }
         }
     }
     __syncthreads();
-    // bitonic sort, descending
-    for (int size = 2; size <= KP; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int i = threadIdx.x; i < KP / 2; i += blockDim.x) {
-                const int lo = 2 * i - (i & (stride - 1));
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long x = win[lo], y = win[hi];
-                if ((x < y) == desc) { win[lo] = y; win[hi] = x; }
+    if (need_sort) {          // (block-uniform) bitonic sort, descending
+        for (int size = 2; size <= KP; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int i = tid; i < KP / 2; i += NT) {
+                    const int lo = 2 * i - (i & (stride - 1));
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long x = win[lo], y = win[hi];
+                    if ((x < y) == desc) { win[lo] = y; win[hi] = x; }
+                }
+                __syncthreads();
             }
-            __syncthreads();
         }
     }
     for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
@@ -264,10 +434,20 @@ extern "C" int ct_decode_row_floats(const ct_decode_desc *d)
     return f;
 }
 
+// pixels per stage-1 workgroup: as large as possible (<= SEG_MAX) while the launch still has
+// >= 256 workgroups, never below 256
+static int pick_seg(const ct_decode_desc *d)
+{
+    const long HW = (long)d->h * d->w;
+    int seg = SEG_MAX;
+    while (seg > 256 && (long)d->B * d->C * ((HW + seg - 1) / seg) < 256) seg >>= 1;
+    return seg;
+}
+
 extern "C" size_t ct_decode_workspace_bytes(const ct_decode_desc *d)
 {
     if (check(d, "ct_decode_workspace_bytes") != CT_OK) return 0;
-    const int nseg = ct_cdiv(d->h * d->w, SEG);
+    const int nseg = ct_cdiv(d->h * d->w, pick_seg(d));
     return (size_t)d->B * d->C * nseg * d->K * sizeof(unsigned long long);
 }
 
@@ -276,19 +456,20 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     int rc = check(d, "ct_decode");
     if (rc != CT_OK) return rc;
     if (!d->out) CT_FAIL_ARG("ct_decode: null output");
-    const int nseg = ct_cdiv(d->h * d->w, SEG);
+    const int seg = pick_seg(d);
+    const int nseg = ct_cdiv(d->h * d->w, seg);
     const size_t need = (size_t)d->B * d->C * nseg * d->K * sizeof(unsigned long long);
     if (!d->workspace || d->workspace_bytes < need) {
         ct_set_error("ct_decode: needs %zu workspace bytes, got %zu", need, d->workspace_bytes);
         return CT_ERR_WORKSPACE;
     }
-    if (d->w > 2048) CT_FAIL_ARG("ct_decode: w=%d > 2048 unsupported", d->w);
+    if (d->w > 4096) CT_FAIL_ARG("ct_decode: w=%d > 4096 unsupported", d->w);
     hipStream_t s = (hipStream_t)stream;
     Stage1Args a1;
     a1.hm = d->hm; a1.cand = (unsigned long long *)d->workspace;
-    a1.B = d->B; a1.C = d->C; a1.h = d->h; a1.w = d->w; a1.K = d->K; a1.nseg = nseg;
-    const int max_rows = ct_cdiv(SEG, d->w) + 3;
-    const size_t lds1 = S1_ROWS + (size_t)max_rows * d->w * sizeof(float);
+    a1.B = d->B; a1.C = d->C; a1.h = d->h; a1.w = d->w; a1.K = d->K; a1.nseg = nseg; a1.seg = seg;
+    const int max_rows = ct_cdiv(seg, d->w) + 3;
+    const size_t lds1 = SEG_MAX * sizeof(unsigned long long) + (size_t)max_rows * d->w * sizeof(float);
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(decode_stage1_kernel),
@@ -299,12 +480,13 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     hipLaunchKernelGGL(decode_stage1_kernel, dim3((unsigned)(d->B * d->C * nseg)), dim3(256), lds1, s, a1);
     CT_CHECK_LAUNCH("ct_decode(stage 1)");
     Stage2Args a2;
-    a2.cand = a1.cand; a2.hm_unused = nullptr;
+    a2.cand = a1.cand; a2.hm = d->hm;
     for (int i = 0; i < CT_NUM_HEADS; ++i) { a2.heads[i] = d->heads[i]; a2.head_ch[i] = kHeadCh[i]; }
     a2.out = d->out; a2.inds = (long long *)d->inds;
     a2.B = d->B; a2.C = d->C; a2.h = d->h; a2.w = d->w; a2.K = d->K; a2.nseg = nseg;
     a2.F = ct_decode_row_floats(d);
-    hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(1024), 0, s, a2);
+    const long M2 = (long)d->C * nseg * d->K;
+    hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(M2 <= 2048 ? 256 : 1024), 0, s, a2);
     CT_CHECK_LAUNCH("ct_decode(stage 2)");
     return CT_OK;
 }

@@ -28,12 +28,13 @@ __global__ __launch_bounds__(256) void maxpool2x2_kernel(const float *x, int N, 
 }
 
 // out[oy,ox,c] = skip[oy,ox,c] + sum_{jy,jx in {0,1}} x[iy-jy, ix-jx, c] * w[c, ky+f*jy, kx+f*jx]
-// with (iy, ky) = divmod(oy + f/2, f): the depth-wise ConvTranspose2d(k=2f, s=f, p=f/2).
+// with (iy, ky) = divmod(oy + f/2, f): the depth-wise ConvTranspose2d(k=2f, s=f, p=f/2); w is the
+// kernel transposed to [2f*2f][C] so that a thread's 4 channels are one 16-byte load.
 __global__ __launch_bounds__(256) void upsample_add_kernel(const float *x, int N, int H, int W, int C, int ldx,
                                                            const float *w, int f, const float *skip, int lds,
                                                            float *y, int ldy)
 {
-    const int Ho = H * f, Wo = W * f, C4 = C >> 2, k2 = 4 * f * f, kw = 2 * f, p = f >> 1;
+    const int Ho = H * f, Wo = W * f, C4 = C >> 2, kw = 2 * f, p = f >> 1;
     const size_t total = (size_t)N * Ho * Wo * C4;
     for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
         const int c = (int)(idx % C4) * 4;
@@ -55,8 +56,9 @@ __global__ __launch_bounds__(256) void upsample_add_kernel(const float *x, int N
                 if (xx < 0 || xx >= W) continue;
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(x + (((size_t)n * H + yy) * W + xx) * ldx + c);
                 const int widx = (ky + f * jy) * kw + (kx + f * jx);
+                const f32x4 wv = *reinterpret_cast<const f32x4 *>(w + (size_t)widx * C + c);     // w is [2f*2f][C]
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i] += v[i] * w[(size_t)(c + i) * k2 + widx];
+                for (int i = 0; i < 4; ++i) acc[i] += v[i] * wv[i];
             }
         }
         *reinterpret_cast<f32x4 *>(y + opix * ldy + c) = acc;
@@ -102,29 +104,58 @@ __global__ __launch_bounds__(256) void nhwc_to_nchw_kernel(const float *x, int C
     }
 }
 
-// prior heat-map: max-splat of (2r+1)^2 Gaussians, sigma = (2r+1)/6, evaluated in float64
+// prior heat-map: max-splat of (2r+1)^2 Gaussians, sigma = (2r+1)/6, evaluated in float64.
+// One workgroup per 32x8 pixel tile: the stream's blob list is read once, culled against the tile
+// into LDS (wave ballots), and every pixel only visits the blobs that can touch its tile.
+constexpr int PHM_TW = 32, PHM_TH = 8, PHM_CAP = 256;
 __global__ __launch_bounds__(256) void render_pre_hm_kernel(const int *params, const int *counts, int cap, int B,
                                                             int H, int W, float *out, int also_flipped)
 {
-    const size_t total = (size_t)B * H * W;
-    for (size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (size_t)gridDim.x * 256) {
-        const int x = (int)(idx % W);
-        const int y = (int)((idx / W) % H);
-        const int b = (int)(idx / ((size_t)W * H));
-        const int n = min(counts[b], cap);
-        const int *p = params + (size_t)b * cap * 3;
-        float v = 0.0f;
-        for (int i = 0; i < n; ++i) {
-            const int cx = p[3 * i], cy = p[3 * i + 1], r = p[3 * i + 2];
-            const int dx = x - cx, dy = y - cy;
-            if (dx < -r || dx > r || dy < -r || dy > r) continue;
-            const double sigma = (double)(2 * r + 1) / 6.0;
-            const double g = exp(-(double)(dx * dx + dy * dy) / (2.0 * sigma * sigma));
-            v = fmaxf(v, (float)g);
+    __shared__ int blob[PHM_CAP * 3];
+    __shared__ int nblob;
+    const int tilesX = (W + PHM_TW - 1) / PHM_TW, tilesY = (H + PHM_TH - 1) / PHM_TH;
+    int bid = blockIdx.x;
+    const int tx = bid % tilesX; bid /= tilesX;
+    const int ty = bid % tilesY;
+    const int b = bid / tilesY;
+    const int x0 = tx * PHM_TW, y0 = ty * PHM_TH;
+    const int n = min(min(counts[b], cap), PHM_CAP);
+    const int *p = params + (size_t)b * cap * 3;
+    if (threadIdx.x == 0) nblob = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + threadIdx.x;
+        int cx = 0, cy = 0, r = -1;
+        if (i < n) { cx = p[3 * i]; cy = p[3 * i + 1]; r = p[3 * i + 2]; }
+        const bool hit = i < n && r >= 0 && cx + r >= x0 && cx - r < x0 + PHM_TW && cy + r >= y0 && cy - r < y0 + PHM_TH;
+        const unsigned long long mask = __ballot(hit);
+        int base = 0;
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(&nblob, (int)__popcll(mask));
+            base = __shfl(base, leader);
         }
-        out[idx] = v;
-        if (also_flipped) out[((size_t)(B + b) * H + y) * W + (W - 1 - x)] = v;
+        if (hit) {
+            const int s = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+            blob[3 * s] = cx; blob[3 * s + 1] = cy; blob[3 * s + 2] = r;
+        }
     }
+    __syncthreads();
+    const int x = x0 + (threadIdx.x & (PHM_TW - 1)), y = y0 + (threadIdx.x / PHM_TW);
+    if (x >= W || y >= H) return;
+    float v = 0.0f;
+    const int m = nblob;
+    for (int i = 0; i < m; ++i) {
+        const int cx = blob[3 * i], cy = blob[3 * i + 1], r = blob[3 * i + 2];
+        const int dx = x - cx, dy = y - cy;
+        if (dx < -r || dx > r || dy < -r || dy > r) continue;
+        const double sigma = (double)(2 * r + 1) / 6.0;
+        const double g = exp(-(double)(dx * dx + dy * dy) / (2.0 * sigma * sigma));
+        v = fmaxf(v, (float)g);
+    }
+    out[((size_t)b * H + y) * W + x] = v;
+    if (also_flipped) out[((size_t)(B + b) * H + y) * W + (W - 1 - x)] = v;
 }
 
 unsigned grid_for(size_t total)
@@ -188,8 +219,9 @@ extern "C" int ct_render_pre_hm(const int *params, const int *counts, int cap, i
                                 int also_flipped, void *stream)
 {
     if (!params || !counts || !out || cap <= 0 || B <= 0 || H <= 0 || W <= 0) CT_FAIL_ARG("ct_render_pre_hm: bad arguments");
-    const size_t total = (size_t)B * H * W;
-    hipLaunchKernelGGL(render_pre_hm_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, params, counts,
+    if (cap > PHM_CAP) CT_FAIL_ARG("ct_render_pre_hm: cap=%d > %d blobs per stream unsupported", cap, PHM_CAP);
+    const long blocks = (long)B * ((H + PHM_TH - 1) / PHM_TH) * ((W + PHM_TW - 1) / PHM_TW);
+    hipLaunchKernelGGL(render_pre_hm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, counts,
                        cap, B, H, W, out, also_flipped);
     CT_CHECK_LAUNCH("ct_render_pre_hm");
     return CT_OK;

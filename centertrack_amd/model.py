@@ -10,11 +10,12 @@ channel slices of shared buffers, and each frame is ~140 launches of
 libcentertrack_hip kernels on the current stream (capturable in one HIP graph).
 """
 import ctypes
+import os
 from collections import OrderedDict
 
 import torch
 
-from . import _lib, autotune, ops
+from . import _lib, autotune, ops, schedule
 from .ops import View
 from .weights import CHANNELS, LEVELS, dla34_param_shapes
 
@@ -29,11 +30,15 @@ def _fold_bn(sd, p):
 
 
 class _Launch(object):
-    """One pre-built C-ABI call."""
-    __slots__ = ('fn', 'args', 'name', 'keep')
+    """One pre-built C-ABI call + what it reads / writes (for the multi-stream schedule)."""
+    __slots__ = ('fn', 'args', 'name', 'keep', 'reads', 'writes', 'us', 'stream', 'waits', 'record', 'ws_need')
 
-    def __init__(self, name, fn, args, keep=()):
+    def __init__(self, name, fn, args, keep=(), reads=(), writes=(), us=5.0, ws_need=0):
         self.name, self.fn, self.args, self.keep = name, fn, args, keep
+        self.reads = [schedule.region(r) for r in reads if r is not None]
+        self.writes = [schedule.region(w) for w in writes if w is not None]
+        self.us, self.ws_need = us, ws_need
+        self.stream, self.waits, self.record = 0, [], False
 
 
 class DLASegHIP(torch.nn.Module):
@@ -143,7 +148,7 @@ class DLASegHIP(torch.nn.Module):
             for k in range(1, n + 1):
                 P['%s.proj_%d' % (p, k)] = deform('%s.proj_%d' % (p, k))
                 P['%s.node_%d' % (p, k)] = deform('%s.node_%d' % (p, k))
-                P['%s.up_%d' % (p, k)] = sd['%s.up_%d.weight' % (p, k)].contiguous()
+                P['%s.up_%d' % (p, k)] = ops.upsample_weight(sd['%s.up_%d.weight' % (p, k)])
         # heads: all first layers share their input -> one 64 -> 256*nh conv
         w0 = torch.cat([sd[h + '.0.weight'] for h in self.heads], 0)
         P['head0_w'] = ops.pack_weight(w0)
@@ -170,10 +175,10 @@ class DLASegHIP(torch.nn.Module):
         def add_conv(name, x, pk, cout, ks, stride=1, relu=True, res=None, out=None, **kw):
             wp, sc, sh = pk
             d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out, **kw)
-            if tune:
-                autotune.tune_conv(d, dev)
-            plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
-            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw'))))
+            us = autotune.tune_conv(d, dev)[2] if tune else 10.0
+            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw')), reads=(x, res),
+                             writes=(out, kw.get('out_nchw')), us=us,
+                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             return out
 
         # static inputs (copied into before each replay)
@@ -182,7 +187,7 @@ class DLASegHIP(torch.nn.Module):
         hm_in = torch.zeros((N, 1, H, W), device=dev) if with_hm else None
         plan['inputs'] = (x_in, img_in, hm_in)
         s0 = alloc(H, W, 16)
-        L.append(_Launch('stem', 'stem', (x_in, img_in, hm_in, s0), ()))
+        L.append(_Launch('stem', 'stem', (x_in, img_in, hm_in, s0), (), reads=(x_in, img_in, hm_in), writes=(s0,), us=46.0))
         l0 = add_conv('level0', s0, P['level0'], 16, 3, out=alloc(H, W, 16))
         l1 = add_conv('level1', l0, P['level1'], 32, 3, stride=2, out=alloc(H // 2, W // 2, 32))
 
@@ -191,7 +196,7 @@ class DLASegHIP(torch.nn.Module):
             h, w = x.H // stride, x.W // stride
             if stride > 1 and bottom is None:
                 bottom = R.slice(2 * cout, cin) if level_root else alloc(h, w, cin)
-                L.append(_Launch(name + '.pool', 'pool', (x, bottom)))
+                L.append(_Launch(name + '.pool', 'pool', (x, bottom), reads=(x,), writes=(bottom,)))
             elif stride == 1:
                 bottom = x
             if cin != cout:
@@ -223,7 +228,7 @@ class DLASegHIP(torch.nn.Module):
                 # Tree(levels=2): R2 = [y2 | y1 | bottom | x1]; the outer project is dead code (dla.py:218)
                 R2 = alloc(h, w, 3 * cout + cin)
                 bottom = R2.slice(2 * cout, cin)
-                L.append(_Launch(p + '.pool', 'pool', (x, bottom)))
+                L.append(_Launch(p + '.pool', 'pool', (x, bottom), reads=(x,), writes=(bottom,)))
                 x1 = R2.slice(2 * cout + cin, cout)
                 R1 = alloc(h, w, 2 * cout)
                 leaf(p + '.tree1', x, P[p + '.tree1'], cin, cout, 2, R1, x1, bottom=bottom)
@@ -231,25 +236,18 @@ class DLASegHIP(torch.nn.Module):
             feats.append(out)
             x = out
 
-        om_bufs = {}
-
         def deform(name, x, cout, out):
             """DeformConv.forward (dla.py:515-518): offset/mask conv -> DCNv2 -> BN -> ReLU"""
             pk = P[name]
-            key = (x.H, x.W)
-            if key not in om_bufs:
-                om_bufs[key] = ops.new_view(N, x.H, x.W, 32, dev)
-            om = om_bufs[key]
+            om = ops.new_view(N, x.H, x.W, 32, dev)       # one per DCN: independent branches may overlap
             d = ops.make_conv_desc(x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
-            if tune:
-                autotune.tune_conv(d, dev)
-            plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
-            L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk)))
+            us = autotune.tune_conv(d, dev)[2] if tune else 10.0
+            L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk), reads=(x,), writes=(om,), us=us,
+                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out)
-            if tune:
-                autotune.tune_dcn(dd, dev)
-            plan['ws_need'] = max(plan['ws_need'], lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd)))
-            L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk)))
+            us = autotune.tune_dcn(dd, dev)[2] if tune else 20.0
+            L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk), reads=(x, om), writes=(out,), us=us,
+                             ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd))))
             return out
 
         def ida(p, layers, startp, endp, o, up_f):
@@ -260,7 +258,8 @@ class DLASegHIP(torch.nn.Module):
                 xi = layers[i]
                 pr = deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o))
                 up = alloc(xi.H * f, xi.W * f, o)
-                L.append(_Launch('%s.up_%d' % (p, k), 'up', (pr, P['%s.up_%d' % (p, k)], f, layers[i - 1], up)))
+                L.append(_Launch('%s.up_%d' % (p, k), 'up', (pr, P['%s.up_%d' % (p, k)], f, layers[i - 1], up),
+                                 reads=(pr, layers[i - 1]), writes=(up,)))
                 layers[i] = deform('%s.node_%d' % (p, k), up, o, alloc(up.H, up.W, o))
 
         layers = list(feats)                                   # DLAUp.forward, dla.py:568-574
@@ -277,10 +276,9 @@ class DLASegHIP(torch.nn.Module):
         hc = self.head_conv
         mid = alloc(feat.H, feat.W, hc * nh)
         d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid)
-        if tune:
-            autotune.tune_conv(d, dev)
-        plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
-        L.append(_Launch('heads.0', 'conv', d, (feat, mid)))
+        us = autotune.tune_conv(d, dev)[2] if tune else 200.0
+        L.append(_Launch('heads.0', 'conv', d, (feat, mid), reads=(feat,), writes=(mid,), us=us,
+                         ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
         outputs = OrderedDict()
         for j, (hname, c) in enumerate(self.heads.items()):
             o = torch.empty((N, c, feat.H, feat.W), device=dev)
@@ -289,24 +287,43 @@ class DLASegHIP(torch.nn.Module):
             dep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
             d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=sig, dep=dep,
                                    depth_scale=self.depth_scale)
-            if tune:
-                autotune.tune_conv(d, dev)
-            plan['ws_need'] = max(plan['ws_need'], lib.ct_conv2d_workspace_bytes(ctypes.byref(d)))
-            L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o)))
+            us = autotune.tune_conv(d, dev)[2] if tune else 7.0
+            L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o), reads=(mid.slice(hc * j, hc),), writes=(o,),
+                             us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             outputs[hname] = o
         plan['outputs'] = outputs
-        ws = torch.empty(max(plan['ws_need'], 16) // 4, dtype=torch.float32, device=dev)
-        plan['ws'] = ws
-        for l in L:
-            if l.fn in ('conv', 'dcn'):
-                l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        # ---- streams: independent branches (IDAUp projections, residual projections, pools) overlap ----
+        S = int(os.environ.get('CENTERTRACK_STREAMS', '1'))   # > 1: experimental
+        if S > 1:
+            plan['makespan_us'] = schedule.schedule(L, S)
+        else:
+            schedule.serialize(L)
+        nstreams = 1 + max(l.stream for l in L)
+        plan['side_streams'] = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
+        plan['ws'] = []
+        for sidx in range(nstreams):                      # split-K partials: one workspace per stream
+            need = max([l.ws_need for l in L if l.stream == sidx] + [16])
+            ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
+            plan['ws'].append(ws)
+            for l in L:
+                if l.stream == sidx and l.fn in ('conv', 'dcn'):
+                    l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        plan['ws_need'] = sum(w.numel() * 4 for w in plan['ws'])
         return plan
 
     def _run_plan(self, plan):
         P = self._prepared
         lib = _lib.load()
-        st = _lib.stream_ptr()
-        for l in plan['launches']:
+        main = torch.cuda.current_stream()
+        streams = [main] + plan['side_streams']
+        for sd_ in plan['side_streams']:                   # fork (also what makes the side streams part of a capture)
+            sd_.wait_stream(main)
+        sptr = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams]
+        events = {}
+        for idx, l in enumerate(plan['launches']):
+            for i in l.waits:
+                streams[l.stream].wait_event(events[i])
+            st = sptr[l.stream]
             if l.fn == 'conv':
                 rc = lib.ct_conv2d(ctypes.byref(l.args), st)
             elif l.fn == 'dcn':
@@ -329,6 +346,12 @@ class DLASegHIP(torch.nn.Module):
                 raise AssertionError(l.fn)
             if rc != 0:
                 _lib.check(rc, l.name)
+            if l.record:
+                ev = torch.cuda.Event()
+                ev.record(streams[l.stream])
+                events[idx] = ev
+        for sd_ in plan['side_streams']:                   # join
+            main.wait_stream(sd_)
 
     def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False):
         key = (N, H, W, with_img, with_hm, fuse_sigmoid)

@@ -74,7 +74,7 @@ def _p(t):
 
 
 def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, relu=False, out=None,
-                   out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0):
+                   out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0, algo=0):
     d = ConvDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
     d.w_packed, d.Cout, d.ks, d.stride = wp.data_ptr(), Cout, ks, stride
@@ -95,6 +95,7 @@ def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, 
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     d.split_k = split_k
+    d.algo = algo
     return d
 
 
@@ -117,7 +118,7 @@ def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
     return out if out is not None else kw['out_nchw']
 
 
-def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0):
+def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0):
     d = DcnDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
     d.om, d.ldom = om.ptr, om.ld
@@ -128,14 +129,15 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     d.split_k = split_k
+    d.algo = algo
     return d
 
 
-def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0):
+def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0):
     lib = _lib.load()
     if out is None:
         out = new_view(x.N, x.H, x.W, Cout, x.buf.device)
-    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k)
+    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo)
     ws = None
     if split_k != 1:
         need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))
@@ -164,7 +166,15 @@ def maxpool2x2(x, out=None):
     return out
 
 
+def upsample_weight(w):
+    """ConvTranspose2d depth-wise weight [C,1,2f,2f] -> the kernel's [2f,2f,C] layout"""
+    return w.reshape(w.shape[0], -1).t().contiguous()
+
+
 def upsample_add(x, w, f, skip, out=None):
+    """w: the module weight [C,1,2f,2f] (transposed here) or an ``upsample_weight`` result [4f^2,C]"""
+    if w.dim() == 4:
+        w = upsample_weight(w)
     if out is None:
         out = new_view(x.N, x.H * f, x.W * f, x.C, x.buf.device)
     _lib.check(_lib.load().ct_upsample_add(x.ptr, x.N, x.H, x.W, x.C, x.ld, w.data_ptr(), f, skip.ptr, skip.ld,

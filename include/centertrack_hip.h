@@ -97,7 +97,8 @@ typedef struct ct_dcn_desc {
     int flags;                                  /* CT_RELU */
     float *workspace; size_t workspace_bytes;
     int split_k;
-    int algo;                                   /* 0 = heuristic; 64 / 128 = couts per workgroup */
+    int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
+                                                   workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts */
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
@@ -116,8 +117,8 @@ int ct_stem_forward(const float *x, const float *pre_img, const float *pre_hm, i
 /* nn.MaxPool2d(2,2) of Tree.downsample (dla.py:207-208,216), NHWC views */
 int ct_maxpool2x2(const float *x, int N, int H, int W, int C, int ldx, float *y, int ldy, void *stream);
 /* IDAUp step `up(proj) + skip` (dla.py:529-532,543-545): depth-wise ConvTranspose2d
- * (kernel 2f, stride f, padding f/2, groups=C, no bias; w = [C,1,2f,2f]) of x [N,H,W,C]
- * plus skip [N,fH,fW,C] -> y [N,fH,fW,C] */
+ * (kernel 2f, stride f, padding f/2, groups=C, no bias) of x [N,H,W,C] plus skip [N,fH,fW,C]
+ * -> y [N,fH,fW,C].  w = the module's weight [C,1,2f,2f] transposed once to [2f,2f,C]. */
 int ct_upsample_add(const float *x, int N, int H, int W, int C, int ldx, const float *w, int f,
                     const float *skip, int lds, float *y, int ldy, void *stream);
 /* layout converters for the NCHW drop-in ops */

@@ -162,8 +162,12 @@ def test_conv2d_nchw_output_sigmoid_dep(device):
 
 
 DCN_CASES = [
-    # N, H, W, Cin, Cout, off_scale, split_k
+    # N, H, W, Cin, Cout, off_scale, split_k[, algo]
     (1, 8, 16, 64, 64, 0.5, 1),
+    (1, 8, 16, 64, 64, 0.5, 1, 3264),     # 32-pixel tiles
+    (2, 7, 19, 64, 96, 3.0, 1, 3264),     # ragged, out-of-range taps, Cout not a multiple of the tile
+    (1, 6, 16, 128, 256, 1.0, 2, 32128),  # 32-pixel x 128-cout tiles + split-K
+    (1, 6, 16, 128, 256, 1.0, 1, 128),
     (2, 7, 19, 64, 64, 3.0, 1),       # ragged, big offsets (out-of-range taps)
     (1, 8, 8, 128, 64, 1.0, 0),
     (1, 4, 4, 512, 256, 1.0, 0),      # split-K
@@ -173,11 +177,12 @@ DCN_CASES = [
 ]
 
 
-@pytest.mark.parametrize('case', DCN_CASES, ids=lambda c: 'N%d_%dx%d_%d-%d_o%s_sk%d' % c)
+@pytest.mark.parametrize('case', DCN_CASES, ids=lambda c: 'N%d_%dx%d_%d-%d_o%s_sk%d' % c[:7] + ('_a%d' % c[7] if len(c) > 7 else ''))
 def test_dcn_v2_matches_oracle(device, case):
     from centertrack_amd import ops
     from oracle import dcn_v2 as odcn
-    N, H, W, Cin, Cout, osc, split_k = case
+    N, H, W, Cin, Cout, osc, split_k = case[:7]
+    algo = case[7] if len(case) > 7 else 0
     x = _rand(N, Cin, H, W, seed=11)
     w = _rand(Cout, Cin, 3, 3, seed=12, scale=(Cin * 9) ** -0.5)
     off = _rand(N, 18, H, W, seed=13, scale=osc)
@@ -190,7 +195,7 @@ def test_dcn_v2_matches_oracle(device, case):
     om[..., :18] = off.permute(0, 2, 3, 1)
     om[..., 18:27] = mask.permute(0, 2, 3, 1)
     out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), ops.View(om.to(device), 0, 27), ops.pack_weight(w.to(device)),
-                     Cout, scale.to(device), shift.to(device), relu=True, split_k=split_k)
+                     Cout, scale.to(device), shift.to(device), relu=True, split_k=split_k, algo=algo)
     _close(out.to_nchw(), y, msg='dcn')
 
 
@@ -309,6 +314,41 @@ def test_decode_nms_plateau_and_ties(device):
     assert out['clses'][0, :4].tolist() == [0, 1, 1, 0]
     assert out['xs'][0, :4].tolist() == [8, 3, 4, 5] and out['ys'][0, :4].tolist() == [8, 3, 3, 5]
     assert 0.4 not in [round(float(v), 3) for v in out['scores'][0]]
+
+
+def test_decode_sparse_maps_take_the_exact_slow_path(device):
+    """fewer than K strictly positive NMS survivors (near-empty heat map, exact zeros, even
+    negative values): the positive prefix matches the oracle, the rest follows the documented
+    order (score desc, then lower class, then lower pixel) over ALL pixels."""
+    from centertrack_amd import ops
+    from oracle import decode as odecode
+    B, C, h, w, K = 2, 3, 20, 24, 40
+    hm = torch.zeros((B, C, h, w))
+    g = torch.Generator().manual_seed(77)
+    for b in range(B):
+        for _ in range(9):
+            c, y, x = int(torch.randint(0, C, (1,), generator=g)), int(torch.randint(0, h, (1,), generator=g)), \
+                int(torch.randint(0, w, (1,), generator=g))
+            hm[b, c, y, x] = float(torch.rand(1, generator=g)) * 0.9 + 0.05
+    hm[1, 2, 5, 5] = -0.25                        # an unsuppressed negative: ranks after every zero
+    reg = torch.rand((B, 2, h, w), generator=g)
+    dec = ops.Decoder(hm.to(device), {'reg': reg.to(device)}, K)
+    out = dec.unpack(dec.run().cpu().numpy())
+    inds = dec.inds.cpu().numpy()
+    want = odecode.generic_decode({'hm': hm.clone(), 'reg': reg.clone()}, K=K, return_inds=True)
+    nms = odecode.nms(hm)
+    for b in range(B):
+        npos = int((nms[b] > 0).sum())
+        assert 0 < npos < K
+        np.testing.assert_array_equal(out['scores'][b, :npos], want['scores'][b, :npos].numpy())
+        np.testing.assert_array_equal(inds[b, :npos], want['inds'][b, :npos].numpy())
+        np.testing.assert_array_equal(out['clses'][b, :npos], want['clses'][b, :npos].numpy())
+        # the remainder: all (class, pixel) with NMS'd score +0.0 in flat order
+        flat = nms[b].reshape(-1).numpy()
+        zeros = np.nonzero((flat == 0) & ~np.signbit(flat))[0][:K - npos]
+        got_flat = out['clses'][b, npos:].astype(np.int64) * (h * w) + inds[b, npos:]
+        np.testing.assert_array_equal(got_flat, zeros)
+        assert (out['scores'][b, npos:] == 0).all()
 
 
 def test_decode_full_size_properties(device):

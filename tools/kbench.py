@@ -109,8 +109,10 @@ def main():
             ('dcn 256-128 @32', 2, S // 16, 256, 128), ('dcn 128-128 @64', 2, S // 8, 128, 128),
             ('dcn 128-64 @64', 4, S // 8, 128, 64), ('dcn 256-64 @32', 1, S // 16, 256, 64),
             ('dcn 64-64 @128', 5, S // 4, 64, 64)]
-    dvars = [('auto', {}), ('bn64', dict(dcn_bn=64)), ('bn128', dict(dcn_bn=128)), ('nosplit', dict(split=1)),
-             ('split2', dict(split=2)), ('split4', dict(split=4)), ('split8', dict(split=8))]
+    dvars = [('auto', {}), ('64/1', dict(algo=64, split=1)), ('64/2', dict(algo=64, split=2)), ('64/4', dict(algo=64, split=4)),
+             ('64/8', dict(algo=64, split=8)), ('32x64/1', dict(algo=3264, split=1)), ('32x64/2', dict(algo=3264, split=2)),
+             ('32x64/4', dict(algo=3264, split=4)), ('32x64/8', dict(algo=3264, split=8)),
+             ('32x128/1', dict(algo=32128, split=1)), ('32x128/4', dict(algo=32128, split=4))]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in dvars))
     dtot = {v[0]: 0.0 for v in dvars}
     for name, cnt, H, Cin, Cout in dcns:
@@ -124,8 +126,11 @@ def main():
         gf = 2.0 * 9 * Cin * Cout * N * H * H / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in dvars:
-            tune(dcn_bn=kw.get('dcn_bn', 0))
-            d = ops.make_dcn_desc(x, om, w, Cout, None, None, True, out, workspace=ws, split_k=kw.get('split', 0))
+            if kw.get('algo', 0) == 32128 and Cout < 128:
+                line += ' %12s' % '-'
+                continue
+            d = ops.make_dcn_desc(x, om, w, Cout, None, None, True, out, workspace=ws, split_k=kw.get('split', 0),
+                                  algo=kw.get('algo', 0))
             t = time_call(lambda: _lib.check(lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr())), args.reps)
             line += ' %7.1f/%4.0f' % (t, gf / t * 1e3)
             dtot[vname] += t * cnt
