@@ -150,11 +150,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     constexpr int S = NKK * KS * KS;                   // steps per chunk
     constexpr int RING = (S % 3 == 0) ? 3 : ((S % 2 == 0) ? 2 : 1);
     if (c_begin < c_end) {
+        // all first-use global loads go out together (one memory round trip before the first MFMA)
         stage_load(c_begin);
-        stage_store(0);
         f32x4 breg[RING][WN];
 #pragma unroll
         for (int p = 0; p < RING - 1; ++p) load_b(breg[p], c_begin, p / (KS * KS), p % (KS * KS));   // S >= RING
+        stage_store(0);
         __syncthreads();
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
@@ -337,11 +338,12 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     if (c_begin < c_end) {
+        // all first-use global loads go out together (one memory round trip before the first MFMA)
         stage_load(c_begin);
-        stage_store(0);
         f32x4 breg[R][WN];
 #pragma unroll
         for (int p = 0; p < D; ++p) load_b(breg[p % R], c_begin + p / S, p % S);
+        stage_store(0);
         __syncthreads();
         for (int c0 = c_begin; c0 < c_end; c0 += U) {
 #pragma unroll

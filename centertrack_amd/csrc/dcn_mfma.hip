@@ -69,30 +69,70 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
     const float *omn = a.om + (size_t)n * a.H * a.W * a.ldom;
 
-    // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
-    for (int it = tid; it < BM * 9; it += 256) {
-        const int m = it / 9, k = it - m * 9;
-        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);   // m < BM
-        int o[4] = {0, 0, 0, 0};
-        float wgt[4] = {0.f, 0.f, 0.f, 0.f};
-        if (oy < a.H && ox < a.W) {
-            const float *omp = omn + ((size_t)oy * a.W + ox) * a.ldom;
-            const float dy = omp[2 * k], dx = omp[2 * k + 1], mk = omp[18 + k];
-            const float ys = (float)(oy - 1 + k / 3) + dy;
-            const float xs = (float)(ox - 1 + k % 3) + dx;
-            if (ys > -1.0f && xs > -1.0f && ys < (float)a.H && xs < (float)a.W) {
-                const float yf = floorf(ys), xf = floorf(xs);
-                const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
-                const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
-                const bool vy0 = y0 >= 0, vy1 = y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
-                if (vy0 && vx0) { o[0] = (y0 * a.W + x0) * a.ldx; wgt[0] = hy * hx * mk; }
-                if (vy0 && vx1) { o[1] = (y0 * a.W + x1) * a.ldx; wgt[1] = hy * lx * mk; }
-                if (vy1 && vx0) { o[2] = (y1 * a.W + x0) * a.ldx; wgt[2] = ly * hx * mk; }
-                if (vy1 && vx1) { o[3] = (y1 * a.W + x1) * a.ldx; wgt[3] = ly * lx * mk; }
-            }
+    // ---- B fragment addressing (set up first so that the weights of step 0 are in flight while
+    //      the sampling table is built) --------------------------------------------------------
+    const int li = lane & 15, lg = lane >> 4;
+    const int nt0 = cb * (WGN * WN) + wn * WN;
+    const int NCH16 = a.Cin >> 4;
+    // branch-free B fragment loads (n-tiles past the padded Cout clamp to the last valid tile)
+    const float *bptr[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
+    const size_t slab_stride = (size_t)a.NT << 8;
+    auto load_b = [&](f32x4 (&b)[NKK][WN], int chunk, int tap) {
+#pragma unroll
+        for (int kk = 0; kk < NKK; ++kk) {
+            const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+                b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
         }
-        *reinterpret_cast<int4 *>(tab_off + it * 4) = make_int4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<f32x4 *>(tab_w + it * 4) = f32x4{wgt[0], wgt[1], wgt[2], wgt[3]};
+    };
+    f32x4 bq[2][NKK][WN];
+    load_b(bq[0], min(c_begin, a.nchunks - 1), 0);
+
+    // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
+    // (all offset/mask loads of a thread are issued before any of them is used: one round trip)
+    {
+        constexpr int TI = (BM * 9 + 255) / 256;
+        float tdy[TI], tdx[TI], tmk[TI];
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int it = tid + 256 * i;
+            const int m = it / 9, k = it - m * 9;
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+            const bool in = it < BM * 9 && oy < a.H && ox < a.W;
+            const float *omp = omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
+            tdy[i] = omp[in ? 2 * k : 0];
+            tdx[i] = omp[in ? 2 * k + 1 : 0];
+            tmk[i] = omp[in ? 18 + k : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < TI; ++i) {
+            const int it = tid + 256 * i;
+            if (it >= BM * 9) continue;
+            const int m = it / 9, k = it - m * 9;
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);   // m < BM
+            int o[4] = {0, 0, 0, 0};
+            float wgt[4] = {0.f, 0.f, 0.f, 0.f};
+            if (oy < a.H && ox < a.W) {
+                const float dy = tdy[i], dx = tdx[i], mk = tmk[i];
+                const float ys = (float)(oy - 1 + k / 3) + dy;
+                const float xs = (float)(ox - 1 + k % 3) + dx;
+                if (ys > -1.0f && xs > -1.0f && ys < (float)a.H && xs < (float)a.W) {
+                    const float yf = floorf(ys), xf = floorf(xs);
+                    const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
+                    const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
+                    const bool vy0 = y0 >= 0, vy1 = y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
+                    if (vy0 && vx0) { o[0] = (y0 * a.W + x0) * a.ldx; wgt[0] = hy * hx * mk; }
+                    if (vy0 && vx1) { o[1] = (y0 * a.W + x1) * a.ldx; wgt[1] = hy * lx * mk; }
+                    if (vy1 && vx0) { o[2] = (y1 * a.W + x0) * a.ldx; wgt[2] = ly * hx * mk; }
+                    if (vy1 && vx1) { o[3] = (y1 * a.W + x1) * a.ldx; wgt[3] = ly * lx * mk; }
+                }
+            }
+            *reinterpret_cast<int4 *>(tab_off + it * 4) = make_int4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<f32x4 *>(tab_w + it * 4) = f32x4{wgt[0], wgt[1], wgt[2], wgt[3]};
+        }
     }
     __syncthreads();
 
@@ -127,23 +167,6 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
         }
     };
 
-    const int li = lane & 15, lg = lane >> 4;
-    const int nt0 = cb * (WGN * WN) + wn * WN;
-    const int NCH16 = a.Cin >> 4;
-    // branch-free B fragment loads (n-tiles past the padded Cout clamp to the last valid tile)
-    const float *bptr[WN];
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;
-    auto load_b = [&](f32x4 (&b)[NKK][WN], int chunk, int tap) {
-#pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-                b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
-        }
-    };
     int aoff[WM];
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) {
@@ -166,11 +189,9 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
             chunk = c_begin + c;
             tap = s - c * 9;
         };
-        f32x4 bq[2][NKK][WN];
         int ch, tp;
         step_ct(0, ch, tp);
         gather_load(0, ch, tp);
-        load_b(bq[0], ch, tp);
         step_ct(1, ch, tp);
         gather_load(1, ch, tp);
         gather_store(0, 0);

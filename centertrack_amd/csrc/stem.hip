@@ -28,6 +28,9 @@ struct StemArgs {
     int N, H, W, ldy, tilesX, tilesY;
 };
 
+// per-thread staging register counts: plane values (3 planes: 3*14*38/256 -> 7) and weights (148*16/256 -> 10)
+constexpr int ST_NPV = 7, ST_NWV = 10;
+
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 {
     __shared__ __attribute__((aligned(16))) float planes[7 * ST_PS];
@@ -44,37 +47,68 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     const int oy0 = ty * ST_TH, ox0 = tx * ST_TW;
     const size_t HW = (size_t)a.H * a.W;
 
-    // ---- stage planes (zero padded), weights and the k -> offset table ----
-    for (int s = 0, plane = 0; s < 3; ++s) {
+    // k -> patch offset table of all three stems (pure index arithmetic)
+    for (int k = tid; k < ST_KTOT; k += 256) {
+        const int s = (k >= 296) ? 2 : ((k >= 148) ? 1 : 0);
+        const int kk = k - st_koff(s);
         const int cin = (s == 2) ? 1 : 3;
-        if (a.in[s]) {
-            const float *src = a.in[s] + (size_t)n * cin * HW;
-            for (int it = tid; it < cin * ST_PH * 38; it += 256) {
+        int off = 0;
+        if (kk < cin * 49) {
+            const int c = kk / 49, r = kk - c * 49;
+            off = (3 * s + c) * ST_PS + (r / 7) * ST_PW + (r % 7);
+        }
+        tab[k] = off;
+    }
+
+    // Staging of stem s (its input planes of the tile with a 3 px zero-padded halo, and its weights
+    // transposed to [k][16]) is split into "all global loads into registers" and "LDS stores", so that
+    // the loads of stem s+1 are in flight while the MFMAs of stem s run.
+    float pv[ST_NPV], wv[ST_NWV];
+    auto stage_load = [&](int s) {
+        const int cin = (s == 2) ? 1 : 3;
+        const int K = cin * 49;
+        const float *src = a.in[s] + (size_t)n * cin * HW;
+        const float *w = a.w[s];
+        const int np = cin * ST_PH * 38, nw = st_k4(s) * 16;
+#pragma unroll
+        for (int i = 0; i < ST_NPV; ++i) {
+            const int it = tid + 256 * i;
+            const int c = it / (ST_PH * 38);
+            const int r = it - c * (ST_PH * 38);
+            const int py = r / 38, px = r - py * 38;
+            const int iy = oy0 - 3 + py, ix = ox0 - 3 + px;
+            const bool ok = it < np && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W;
+            const float v = src[ok ? ((size_t)c * HW + (size_t)iy * a.W + ix) : 0];
+            pv[i] = ok ? v : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < ST_NWV; ++i) {
+            const int it = tid + 256 * i;
+            const int k = it >> 4, j = it & 15;
+            const bool ok = it < nw && k < K;
+            const float v = w[ok ? (j * K + k) : 0];
+            wv[i] = ok ? v : 0.0f;
+        }
+    };
+    auto stage_store = [&](int s) {
+        const int cin = (s == 2) ? 1 : 3;
+        const int np = cin * ST_PH * 38, nw = st_k4(s) * 16;
+#pragma unroll
+        for (int i = 0; i < ST_NPV; ++i) {
+            const int it = tid + 256 * i;
+            if (it < np) {
                 const int c = it / (ST_PH * 38);
                 const int r = it - c * (ST_PH * 38);
                 const int py = r / 38, px = r - py * 38;
-                const int iy = oy0 - 3 + py, ix = ox0 - 3 + px;
-                float v = 0.0f;
-                if (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) v = src[(size_t)c * HW + (size_t)iy * a.W + ix];
-                planes[(plane + c) * ST_PS + py * ST_PW + px] = v;
-            }
-            const int K = cin * 49;
-            for (int it = tid; it < st_k4(s) * 16; it += 256) {
-                const int k = it >> 4, j = it & 15;
-                wl[(st_koff(s) + k) * 16 + j] = (k < K) ? a.w[s][j * K + k] : 0.0f;
-            }
-            for (int k = tid; k < st_k4(s); k += 256) {
-                int off = 0;
-                if (k < K) {
-                    const int c = k / 49, r = k - c * 49;
-                    off = (plane + c) * ST_PS + (r / 7) * ST_PW + (r % 7);
-                }
-                tab[st_koff(s) + k] = off;
+                planes[(3 * s + c) * ST_PS + py * ST_PW + px] = pv[i];
             }
         }
-        plane += cin;
-    }
-    __syncthreads();
+#pragma unroll
+        for (int i = 0; i < ST_NWV; ++i) {
+            const int it = tid + 256 * i;
+            if (it < nw) wl[st_koff(s) * 16 + it] = wv[i];
+        }
+    };
 
     // wave -> rows 2w, 2w+1; m-tile mt -> (row 2w + mt/2, column block mt&1)
     int pbase[4];
@@ -85,27 +119,36 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
+    // (stem 0 = the current frame is always present)
+    stage_load(0);
+    stage_store(0);
+    __syncthreads();
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        if (!a.in[s]) continue;
-        f32x4 acc[4];
+        const bool have_next = (s < 2) && a.in[s + 1] != nullptr;
+        if (have_next) stage_load(s + 1);
+        if (a.in[s]) {
+            f32x4 acc[4];
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-        const int nsteps = st_k4(s) / 4;
+            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            const int nsteps = st_k4(s) / 4;
 #pragma unroll 4
-        for (int st = 0; st < nsteps; ++st) {
-            const int k = st_koff(s) + 4 * st + lg;
-            const int off = tab[k];
-            const float b = wl[k * 16 + li];
+            for (int st = 0; st < nsteps; ++st) {
+                const int k = st_koff(s) + 4 * st + lg;
+                const int off = tab[k];
+                const float b = wl[k * 16 + li];
+#pragma unroll
+                for (int mt = 0; mt < 4; ++mt)
+                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[off + pbase[mt]], b, acc[mt], 0, 0, 0);
+            }
+            const float sc = a.scale[s * 16 + li], sh = a.shift[s * 16 + li];
 #pragma unroll
             for (int mt = 0; mt < 4; ++mt)
-                acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[off + pbase[mt]], b, acc[mt], 0, 0, 0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) out[mt][e] += fmaxf(acc[mt][e] * sc + sh, 0.0f);
         }
-        const float sc = a.scale[s * 16 + li], sh = a.shift[s * 16 + li];
-#pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) out[mt][e] += fmaxf(acc[mt][e] * sc + sh, 0.0f);
+        if (have_next) stage_store(s + 1);
+        if (s < 2) __syncthreads();
     }
 
 #pragma unroll

@@ -132,16 +132,22 @@ class StreamDetector(object):
             ctx['cnt_dev'] = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
         if self.native:
             ctx['row_layout'] = fast_track.row_layout(ctx['decoder'].layout)
-        # tracking state owned by THIS detector (the plan's buffers are shared by every detector of the model)
-        ctx['pre_images'] = torch.zeros_like(img_in) if img_in is not None else None
-        ctx['graph'] = None
+        # Frame buffers owned by THIS detector (the plan's activation buffers are shared by every detector of
+        # the model).  Two of them ping-pong: the frame of step t is written into buffer t & 1 and read as
+        # `pre_img` from there at step t+1, so the reference's `self.pre_images = images` (detector.py:148)
+        # costs no copy; one captured graph per parity.
+        ctx['frames'] = [torch.zeros_like(x_in), torch.zeros_like(x_in) if img_in is not None else None]
+        ctx['parity'] = 0
+        ctx['graphs'] = [None, None]
 
-        def device_frame():
+        def device_frame(parity=0):
+            cur = ctx['frames'][parity if img_in is not None else 0]
+            prev = ctx['frames'][parity ^ 1] if img_in is not None else None
             if render:
                 _lib.check(_lib.load().ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
                                                         fast_track.MAX_BLOBS, self.B, H, W, hm_in.data_ptr(),
                                                         1 if self.flip else 0, _lib.stream_ptr()), 'ct_render_pre_hm')
-            self.model._run_plan(plan)
+            self.model._run_plan(plan, inputs=(cur, prev, hm_in))
             if self.flip:
                 self._flip_merge(outs, merged)
             if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:
@@ -155,17 +161,19 @@ class StreamDetector(object):
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
-                    device_frame()            # warm-up (lazy module loads must not happen in capture)
+                    device_frame(0)           # warm-up (lazy module loads must not happen in capture)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    device_frame()
-                ctx['graph'] = g
+                for par in ((0, 1) if img_in is not None else (0,)):
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        device_frame(par)
+                    ctx['graphs'][par] = g
             except Exception as e:             # capture is an optimisation; eager launches are the same kernels
                 print('centertrack_amd: HIP graph capture failed (%s); using eager launches' % e)
-                ctx['graph'] = None
+                ctx['graphs'] = [None, None]
                 torch.cuda.synchronize()
+        ctx['graph'] = ctx['graphs'][0]
         self._ctx = ctx
         return ctx
 
@@ -212,16 +220,16 @@ class StreamDetector(object):
                     if not self.native:
                         self.trackers[s].init_track(pre_dets)
             if img_in is not None:
-                pre = ctx['pre_images']
+                # first frame of a stream: pre_images = images (detector.py:99-103)
+                prev = ctx['frames'][ctx['parity'] ^ 1]
                 fresh = [s for s in range(B) if not self.started[s]]
                 if len(fresh) == B:
-                    pre.copy_(x_dev)
+                    prev.copy_(x_dev)
                 else:
                     for s in fresh:
-                        pre[s].copy_(x_dev[s])
+                        prev[s].copy_(x_dev[s])
                         if self.flip:
-                            pre[B + s].copy_(x_dev[B + s])
-                img_in.copy_(pre)
+                            prev[B + s].copy_(x_dev[B + s])
             if hm_in is not None and self.native:
                 ph, ch = ctx['prm_host'].numpy(), ctx['cnt_host'].numpy()
                 for s in range(B):
@@ -240,14 +248,15 @@ class StreamDetector(object):
                 hm_in.copy_(hh, non_blocking=True)
             for s in range(B):
                 self.started[s] = True
-        x_in.copy_(x_dev)
+        par = ctx['parity'] if img_in is not None else 0
+        ctx['frames'][par].copy_(x_dev)
         t1 = time.time()
-        if ctx['graph'] is not None:
-            ctx['graph'].replay()
+        if ctx['graphs'][par] is not None:
+            ctx['graphs'][par].replay()
         else:
-            ctx['device_frame']()
-        if tracking and img_in is not None:
-            ctx['pre_images'].copy_(x_dev)                     # self.pre_images = images (detector.py:148)
+            ctx['device_frame'](par)
+        if img_in is not None:
+            ctx['parity'] ^= 1                                 # this frame is the next step's pre_img
         if self.gather_fn is not None:
             self.gather_fn(ctx['decoder'].out)
         ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)

@@ -311,7 +311,10 @@ class DLASegHIP(torch.nn.Module):
         plan['ws_need'] = sum(w.numel() * 4 for w in plan['ws'])
         return plan
 
-    def _run_plan(self, plan):
+    def _run_plan(self, plan, inputs=None):
+        """Enqueue every launch of the plan.  ``inputs`` = (x, pre_img, pre_hm) tensors to read instead
+        of the plan's own static input buffers (a detector ping-pongs two frame buffers so that the
+        previous frame never has to be copied)."""
         P = self._prepared
         lib = _lib.load()
         main = torch.cuda.current_stream()
@@ -337,6 +340,8 @@ class DLASegHIP(torch.nn.Module):
                                          y.ptr, y.ld, st)
             elif l.fn == 'stem':
                 x, img, hm, y = l.args
+                if inputs is not None:
+                    x, img, hm = inputs
                 w = P['stem_w']
                 rc = lib.ct_stem_forward(x.data_ptr(), ops._p(img), ops._p(hm), x.shape[0], x.shape[2], x.shape[3],
                                          w[0].data_ptr(), ops._p(w[1]) if img is not None else None,
