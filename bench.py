@@ -17,7 +17,8 @@ Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the DCNv2 kernel (dcn_mfma_kernel): algorithmic flops (2*9*Cin*Cout*h*w per
                 layer) and algorithmic bytes (4*(Cin*h*w + 27*h*w + Cout*h*w + 9*Cin*Cout
                 + Cout)) of the 16 DCN layers / their summed launch time, measured with HIP
-                events on the launch stream in a dedicated pass of this process
+                events on the launch stream (graph replay of exactly these launches) in this process;
+                traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's CPU path) timed on the
                 host cores for a bounded sample of the same workload (reported baseline only)
 """
@@ -54,50 +55,76 @@ def parse():
     return ap.parse_args()
 
 
-def kernel_pass(model, plan, reps=20):
-    """Time every DCN / conv launch of the plan with HIP events on the launch stream."""
+def kernel_pass(model, plan, reps=10):
+    """Average duration of the DCN / conv launches of the plan: all launches of one kind are captured
+    back-to-back in a HIP graph and the replay is timed with HIP events on the launch stream (device time,
+    kernel boundaries included, host launch cost excluded -- the same thing rocprofv3's kernel trace sees)."""
     import ctypes
     from centertrack_amd import _lib
     lib = _lib.load()
-    st = _lib.stream_ptr()
     stats = {}
-    launches = [l for l in plan['launches'] if l.fn in ('dcn', 'conv')]
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in launches]
-    acc = [0.0] * len(launches)
     model._run_plan(plan)
     torch.cuda.synchronize()
-    for _ in range(reps):
-        for (e0, e1), l in zip(evs, launches):
-            e0.record()
-            if l.fn == 'dcn':
-                lib.ct_dcn_v2(ctypes.byref(l.args), st)
-            else:
-                lib.ct_conv2d(ctypes.byref(l.args), st)
-            e1.record()
-        torch.cuda.synchronize()
-        for i, (e0, e1) in enumerate(evs):
-            acc[i] += e0.elapsed_time(e1)
     for kind in ('dcn', 'conv'):
-        flops = bytes_ = ms = 0.0
-        n = 0
-        for a, l in zip(acc, launches):
-            if l.fn != kind:
-                continue
+        launches = [l for l in plan['launches'] if l.fn == kind]
+
+        def run():
+            st = _lib.stream_ptr()
+            for l in launches:
+                if kind == 'dcn':
+                    lib.ct_dcn_v2(ctypes.byref(l.args), st)
+                else:
+                    lib.ct_conv2d(ctypes.byref(l.args), st)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            run()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            run()
+        g.replay()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            g.replay()
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        flops = bytes_ = 0.0
+        for l in launches:
             d = l.args
             if kind == 'dcn':
                 hw = d.N * d.H * d.W
                 flops += 2.0 * 9 * d.Cin * d.Cout * hw
-                bytes_ += 4.0 * (d.Cin * hw + 27 * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout)
+                bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout)
+                if d.fuse_offset:          # offset/mask conv computed in the same launch: its flops and weights
+                    flops += 2.0 * 9 * d.Cin * 27 * hw
+                    bytes_ += 4.0 * (9 * d.Cin * 27 + 27)
+                else:                      # the 27-channel offset/mask map is read from HBM
+                    bytes_ += 4.0 * 27 * hw
             else:
                 pad = d.ks // 2
                 ho = (d.H + 2 * pad - d.ks) // d.stride + 1
                 wo = (d.W + 2 * pad - d.ks) // d.stride + 1
                 flops += 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)
-            ms += a / reps
-            n += 1
-        stats[kind] = dict(launches=n, flops=flops, bytes=bytes_, ms=ms)
+        stats[kind] = dict(launches=len(launches), flops=flops, bytes=bytes_, ms=ms)
     return stats
+
+
+def pmc_traffic():
+    """HBM bytes per DCN launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, made by
+    tools/collect_profiles.sh from FETCH_SIZE / WRITE_SIZE with the gfx950 corrections); None if absent."""
+    p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    try:
+        with open(p) as f:
+            j = json.load(f)
+        return j['dcn_mfma_kernel']['hbm_bytes_per_launch'], j.get('source', p)
+    except Exception:
+        return None, None
 
 
 def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes):
@@ -218,7 +245,7 @@ def main():
             gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
             out['roofline'] = {'kernel': 'dcn_mfma_kernel (16 DCNv2 layers of one frame batch, incl. split-K reduce)',
                                'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(tf / PEAK_FP32_TFLOPS, 4), 'traffic': None,
+                               'frac': round(tf / PEAK_FP32_TFLOPS, 4), 'traffic': None, 'traffic_source': None,
                                'avg_launch_us': round(1000.0 * d['ms'] / d['launches'], 2),
                                'hbm': {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': round(gbs / PEAK_HBM_GBS, 4),
@@ -229,6 +256,11 @@ def main():
                                     'achieved': round(ctf, 3), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(ctf / PEAK_FP32_TFLOPS, 4), 'total_ms': round(c['ms'], 4)}
             out['roofline']['total_ms'] = round(d['ms'], 4)
+            if B == 1 and args.config == 'mot17_512' and not args.height and not args.width:
+                tb, src = pmc_traffic()            # measured on this workload only
+                if tb is not None:
+                    out['roofline']['traffic'] = round(tb)
+                    out['roofline']['traffic_source'] = src
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg, heads, sd, [f[0:1] for f in frames_cpu], metas, opt_kw,

@@ -48,7 +48,8 @@ class DcnDesc(ctypes.Structure):
                 ('y', ctypes.c_void_p), ('ldy', ctypes.c_int),
                 ('flags', ctypes.c_int),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-                ('split_k', ctypes.c_int), ('algo', ctypes.c_int)]
+                ('split_k', ctypes.c_int), ('algo', ctypes.c_int), ('fuse_offset', ctypes.c_int),
+                ('w_off_packed', ctypes.c_void_p), ('b_off', ctypes.c_void_p)]
 
 
 class DecodeDesc(ctypes.Structure):

@@ -98,7 +98,7 @@ def _conv_key(d):
 
 
 def _dcn_key(d):
-    return 'dcn:%d,%d,%d,%d,%d' % (d.N, d.H, d.W, d.Cin, d.Cout)
+    return 'dcn%s:%d,%d,%d,%d,%d' % ('F' if d.fuse_offset else '', d.N, d.H, d.W, d.Cin, d.Cout)
 
 
 _REG_BN = [16, 32, 64, 128, 64, 32]          # couts per workgroup of the row-tiled shapes 0..5
@@ -123,9 +123,10 @@ def _conv_candidates(d):
 
 
 def _dcn_candidates(d):
-    cands = [(0, 0)]
+    cands = [] if d.fuse_offset else [(0, 0)]
     nchunks = d.Cin // 32
-    for bn in ([64, 128, 3264, 32128] if d.Cout >= 128 else [64, 3264]):
+    algos = [3264, 32128] if d.fuse_offset else [64, 128, 3264, 32128]
+    for bn in (algos if d.Cout >= 128 else [a for a in algos if a in (64, 3264)]):
         for sk in (1, 2, 4, 8, 16):
             if sk <= nchunks:
                 cands.append((bn, sk))

@@ -24,7 +24,8 @@ def build(force=False, verbose=False):
     hipcc = os.environ.get('HIPCC', '/opt/rocm/bin/hipcc')
     objdir = os.path.join(PKG, 'build')
     os.makedirs(objdir, exist_ok=True)
-    headers = [os.path.join(CSRC, 'ct_common.h'), os.path.join(ROOT, 'include', 'centertrack_hip.h')]
+    headers = [os.path.join(CSRC, 'ct_common.h'), os.path.join(CSRC, 'ksplit_core.h'),
+               os.path.join(ROOT, 'include', 'centertrack_hip.h')]
     objs = []
     procs = []
     for src in SOURCES:

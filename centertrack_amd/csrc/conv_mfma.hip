@@ -20,6 +20,7 @@
 //   * split-K over channel chunks (gridDim.y) writes raw partials to a workspace; a
 //     second kernel reduces them in a fixed order (deterministic) and applies the epilogue.
 #include "ct_common.h"
+#include "ksplit_core.h"
 
 namespace {
 
@@ -231,177 +232,28 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
 // ---------------------------------------------------------------------------------------------
 // K-split variant for layers with few output tiles (deep levels: 16x16 .. 64x64 maps with
-// 128..1280 input channels).  ALL waves of a workgroup own the SAME small output tile
-// (WM rows x 16 px  x  16*WN couts) and split the reduction: wave k contracts the k-th
-// 16-channel slab of every 16*WK-channel chunk (all taps); the WK partial tiles are summed
-// through LDS in wave order (deterministic) and the epilogue runs once.  This replaces the
-// global split-K (partials through HBM + a second reduce launch) for these layers and gives
-// every SIMD >= 1-2 waves even when M x N is only 256 x 512.
-template <int KS, int STRIDE, int WM, int WN, int WK>
-struct KsCfg {
-    static constexpr int NTHR = 64 * WK;
-    static constexpr int BN = 16 * WN;
-    static constexpr int PH = (WM - 1) * STRIDE + KS;
-    static constexpr int PW = 15 * STRIDE + KS;
-    static constexpr int PP = PH * PW;
-    static constexpr int SLAB = PP * 16;
-    static constexpr int BUF = WK * SLAB;
-    static constexpr int ITEMS = WK * PP * 4;
-    static constexpr int NR = (ITEMS + NTHR - 1) / NTHR;
-    static constexpr int RED = WK * WM * WN * 256;
-    static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)((2 * BUF > RED) ? 2 * BUF : RED);
-};
-
+// 128..1280 input channels): see ksplit_core.h.
 template <int KS, int STRIDE, int WM, int WN, int WK>
 __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
 {
-    using C = KsCfg<KS, STRIDE, WM, WN, WK>;
-    constexpr int PAD = KS / 2;
-    constexpr int S = KS * KS;                       // steps (taps) per chunk and wave
-    constexpr int D = 2;                             // B prefetch distance (steps)
-    constexpr int R = D + 1;                         // register ring
-    constexpr int U = (S % R == 0) ? 1 : R;          // chunk unroll so that ring slots stay static
     extern __shared__ __attribute__((aligned(16))) float lds[];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;                       // = K slab inside a chunk
-
+    const int lane = threadIdx.x & 63;
     int bid = blockIdx.x;
     const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
     const int oy0 = ty * WM, ox0 = tx * 16;
-    const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
     const int split = blockIdx.y;
     const int c_begin = split * a.chunksPerSplit;
     const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
-
-    int goff[C::NR], loff[C::NR];
-#pragma unroll
-    for (int r = 0; r < C::NR; ++r) {
-        const int it = tid + C::NTHR * r;
-        if (it < C::ITEMS) {
-            const int q = it & 3;
-            const int pp = it >> 2;
-            const int kk = pp / C::PP;
-            const int P = pp - kk * C::PP;
-            const int py = P / C::PW, px = P - py * C::PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            loff[r] = kk * C::SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
-            goff[r] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4) : -1;
-        } else {
-            loff[r] = -1;
-            goff[r] = -1;
-        }
-    }
-    f32x4 stage[C::NR];
-    auto stage_load = [&](int chunk) {
-        const int coff = chunk * (16 * WK);
-#pragma unroll
-        for (int r = 0; r < C::NR; ++r) {
-            const bool ok = goff[r] >= 0;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
-            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-    };
-    auto stage_store = [&](int buf) {
-        float *dst = lds + buf * C::BUF;
-#pragma unroll
-        for (int r = 0; r < C::NR; ++r)
-            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
-    };
-
-    const int li = lane & 15, lg = lane >> 4;
-    int pbase[WM];
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt) pbase[mt] = (mt * STRIDE) * C::PW + li * STRIDE;
     const int nt0 = cb * WN;
-    const int NCH16 = a.Cin >> 4;
-    const float *bptr[WN];
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;
-    // B fragment of (chunk, tap) for THIS wave's slab; chunks past the end clamp (loaded, never used)
-    auto load_b = [&](f32x4 (&b)[WN], int chunk, int tap) {
-        const size_t slab = (size_t)tap * NCH16 + (size_t)min(chunk, c_end - 1) * WK + wave;
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
-    };
-
-    f32x4 acc[WM][WN];
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (c_begin < c_end) {
-        // all first-use global loads go out together (one memory round trip before the first MFMA)
-        stage_load(c_begin);
-        f32x4 breg[R][WN];
-#pragma unroll
-        for (int p = 0; p < D; ++p) load_b(breg[p % R], c_begin + p / S, p % S);
-        stage_store(0);
-        __syncthreads();
-        for (int c0 = c_begin; c0 < c_end; c0 += U) {
-#pragma unroll
-            for (int u = 0; u < U; ++u) {
-                const int c = c0 + u;
-                if (c < c_end) {
-                    const int cur = (c - c_begin) & 1;
-                    stage_load(min(c + 1, c_end - 1));
-                    __builtin_amdgcn_sched_barrier(0x386);
-                    const float *buf = lds + cur * C::BUF + wave * C::SLAB;
-#pragma unroll
-                    for (int s = 0; s < S; ++s) {
-                        const int g = u * S + s;                    // static position in the unrolled body
-                        const int sp = s + D;
-                        load_b(breg[(g + D) % R], c + sp / S, sp % S);
-                        __builtin_amdgcn_sched_barrier(0x386);
-                        const int ky = s / KS, kx = s % KS;
-                        f32x4 af[WM];
-#pragma unroll
-                        for (int mt = 0; mt < WM; ++mt) {
-                            const int P = pbase[mt] + ky * C::PW + kx;
-                            af[mt] = *reinterpret_cast<const f32x4 *>(buf + P * 16 + ((lg ^ ((P >> 1) & 2)) << 2));
-                        }
-#pragma unroll
-                        for (int e = 0; e < 4; ++e)
-#pragma unroll
-                            for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                                for (int nt = 0; nt < WN; ++nt)
-                                    acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], breg[g % R][nt][e],
-                                                                                      acc[mt][nt], 0, 0, 0);
-                    }
-                    if (c + 1 < c_end) stage_store(cur ^ 1);
-                    __syncthreads();
-                }
-            }
-        }
-    }
-
-    // ---- cross-wave reduction through LDS (wave order 0..WK-1), then the epilogue ------------
-    constexpr int T = WM * WN;
-    float *red = lds;
-#pragma unroll
-    for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt)
-            *reinterpret_cast<f32x4 *>(red + ((wave * T + mt * WN + nt) * 64 + lane) * 4) = acc[mt][nt];
-    __syncthreads();
-#pragma unroll
-    for (int t0 = 0; t0 < T; t0 += WK) {
-        const int t = t0 + wave;
-        if (t < T) {
-            f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (t * 64 + lane) * 4);
-#pragma unroll
-            for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
-            const int mt = t / WN, nt = t - mt * WN;
+    ksplit_conv_tile<KS, STRIDE, WM, WN, WK>(
+        xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds, [&](int mt, int nt, f32x4 sum) {
             const int oy = oy0 + mt;
             if (a.ws) {
+                const int li = lane & 15, lg = lane >> 4;
                 const size_t Mtot = (size_t)a.N * a.epi.Ho * a.epi.Wo;
                 float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
                 const int co = (nt0 + nt) * 16 + li;
@@ -415,8 +267,7 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
             } else {
                 ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane);
             }
-        }
-    }
+        });
 }
 
 // Deterministic split-K reduction + epilogue: one thread per (pixel, 4 couts).

@@ -20,6 +20,7 @@
 #include <type_traits>
 
 #include "ct_common.h"
+#include "ksplit_core.h"
 
 namespace {
 
@@ -33,12 +34,20 @@ struct DcnArgs {
     int nchunks, chunksPerSplit;     // chunks of 32 channels
     float *ws;
     int wsCout;
+    const float *w_off;              // fused offset/mask conv (FUSE kernels): packed 3x3 Cin -> 27 weights, bias
+    const float *b_off;
     EpiArgs epi;
 };
 
+// fused offset/mask conv stage: the K-split conv tile of ksplit_core.h on the workgroup's own 2 x 16 pixels
+using OffCfg = KsCfg<3, 1, 2, 2, 4>;
+
 // BM = pixels per workgroup (64 = 4 rows x 16, 32 = 2 rows x 16); wave grid is (BM/32) pixel-row
 // pairs x (128/BM) cout groups; wave tile = 2 m-tiles x WN n-tiles => BN = 16 * WN * 128 / BM couts.
-template <int BM, int WN>
+// FUSE: the offset/mask conv of upstream's DCN.forward (conv_offset_mask + sigmoid of the mask channels) is
+// computed by the workgroup itself for its own pixels (ksplit_conv_tile, result kept in LDS) instead of being
+// read from a map another launch wrote: one launch and one HBM round trip of the 27-channel map less per layer.
+template <int BM, int WN, bool FUSE>
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 {
     constexpr int NKK = 2, WM = 2;
@@ -46,10 +55,14 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     constexpr int ROWS = BM / 16;
     constexpr int SLAB = BM * 16;            // floats
     constexpr int BUF = NKK * SLAB;
-    // LDS: A tile double buffer | table offsets int4[BM*9] | table weights float4[BM*9]
-    __shared__ __attribute__((aligned(16))) float lds_a[2 * BUF];
-    __shared__ __attribute__((aligned(16))) int tab_off[BM * 9 * 4];
-    __shared__ __attribute__((aligned(16))) float tab_w[BM * 9 * 4];
+    static_assert(!FUSE || BM == 32, "the fused offset conv works on 32-pixel tiles");
+    // dynamic LDS: [ om tile float[BM*32] (FUSE) ] | A tile double buffer | table offsets int4[BM*9] | table
+    // weights float4[BM*9]; the offset-conv stage's scratch aliases everything after the om tile
+    extern __shared__ __attribute__((aligned(16))) float dlds[];
+    float *om_lds = dlds;
+    float *lds_a = dlds + (FUSE ? BM * 32 : 0);
+    int *tab_off = reinterpret_cast<int *>(lds_a + 2 * BUF);
+    float *tab_w = lds_a + 2 * BUF + BM * 9 * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -67,7 +80,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
 
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
-    const float *omn = a.om + (size_t)n * a.H * a.W * a.ldom;
+    const float *omn = FUSE ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
 
     // ---- B fragment addressing (set up first so that the weights of step 0 are in flight while
     //      the sampling table is built) --------------------------------------------------------
@@ -88,6 +101,21 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
                 b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
         }
     };
+    if (FUSE) {
+        // ---- offset / mask conv of this tile (all input channels, whatever K range this split owns) ----
+        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a,
+                                        [&](int mt, int nt, f32x4 sum) {
+                                            const int co = nt * 16 + li;
+                                            const float b = (co < 27) ? a.b_off[co] : 0.0f;
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) {
+                                                float v = sum[e] + b;
+                                                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
+                                                om_lds[(mt * 16 + lg * 4 + e) * 32 + co] = v;
+                                            }
+                                        });
+        __syncthreads();
+    }
     f32x4 bq[2][NKK][WN];
     load_b(bq[0], min(c_begin, a.nchunks - 1), 0);
 
@@ -102,10 +130,17 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
             const int m = it / 9, k = it - m * 9;
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             const bool in = it < BM * 9 && oy < a.H && ox < a.W;
-            const float *omp = omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
-            tdy[i] = omp[in ? 2 * k : 0];
-            tdx[i] = omp[in ? 2 * k + 1 : 0];
-            tmk[i] = omp[in ? 18 + k : 0];
+            if (FUSE) {
+                const float *omp = om_lds + (in ? m * 32 : 0);
+                tdy[i] = omp[in ? 2 * k : 0];
+                tdx[i] = omp[in ? 2 * k + 1 : 0];
+                tmk[i] = omp[in ? 18 + k : 0];
+            } else {
+                const float *omp = omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
+                tdy[i] = omp[in ? 2 * k : 0];
+                tdx[i] = omp[in ? 2 * k + 1 : 0];
+                tmk[i] = omp[in ? 18 + k : 0];
+            }
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
@@ -261,15 +296,20 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 }
 
 struct DcnPlan {
+    int fuse;
     int BM, BN, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
 };
 
 int make_plan(const ct_dcn_desc *d, DcnPlan *p)
 {
-    if (!d || !d->x || !d->om || !d->w_packed || !d->y) CT_FAIL_ARG("ct_dcn_v2: null pointer");
+    if (!d || !d->x || !d->w_packed || !d->y) CT_FAIL_ARG("ct_dcn_v2: null pointer");
+    p->fuse = d->fuse_offset ? 1 : 0;
+    if (p->fuse && (!d->w_off_packed || !d->b_off)) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
+    if (p->fuse && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs Cin %% 64 == 0 (got %d)", d->Cin);
+    if (!p->fuse && !d->om) CT_FAIL_ARG("ct_dcn_v2: null offset/mask map");
     if (d->Cin % 32 || d->Cin <= 0) CT_FAIL_ARG("ct_dcn_v2: Cin=%d must be a positive multiple of 32", d->Cin);
     if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_dcn_v2: input view must be 16-byte aligned");
-    if (d->ldom < 27) CT_FAIL_ARG("ct_dcn_v2: offset/mask map needs >= 27 channels");
+    if (!p->fuse && d->ldom < 27) CT_FAIL_ARG("ct_dcn_v2: offset/mask map needs >= 27 channels");
     if (d->Cout <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) CT_FAIL_ARG("ct_dcn_v2: bad shape");
     if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_dcn_v2: NCHW output unsupported");
     p->NT = ct_cdiv(d->Cout, 16);
@@ -286,6 +326,10 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 128 && d->Cout >= 128) p->BN = 128;
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 64) p->BN = 64;
     else if (d->Cout >= 128 && (long)d->N * p->tilesX * ct_cdiv(d->H, 4) * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
+    if (p->fuse) {
+        if (d->algo == 64 || d->algo == 128) CT_FAIL_ARG("ct_dcn_v2: fuse_offset runs on the 32-pixel tiles (algo 3264 / 32128)");
+        if (p->BM != 32) { p->BM = 32; p->BN = 64; }
+    }
     p->tilesY = ct_cdiv(d->H, p->BM / 16);
     p->coutBlocks = ct_cdiv(d->Cout, p->BN);
     p->nchunks = d->Cin / 32;
@@ -371,12 +415,23 @@ extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
     dim3 grid((unsigned)blocks, (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
-    if (p.BM == 32) {
-        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1>), grid, dim3(256), 0, s, a);
+    a.w_off = d->w_off_packed; a.b_off = d->b_off;
+    // dynamic LDS: A double buffer + the two tables (+ om tile and the offset-conv scratch when fused)
+    auto lds_bytes = [&](int BM) {
+        size_t regionA = sizeof(float) * (size_t)(2 * 2 * BM * 16 + 2 * BM * 9 * 4);
+        if (!p.fuse) return regionA;
+        const size_t scratch = (d->Cin == 64) ? sizeof(float) * (size_t)OffCfg::LDS1_FLOATS : OffCfg::LDS_BYTES;
+        return sizeof(float) * (size_t)(BM * 32) + (scratch > regionA ? scratch : regionA);
+    };
+    if (p.fuse) {
+        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true>), grid, dim3(256), lds_bytes(32), s, a);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), grid, dim3(256), lds_bytes(32), s, a);
+    } else if (p.BM == 32) {
+        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false>), grid, dim3(256), lds_bytes(32), s, a);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false>), grid, dim3(256), lds_bytes(32), s, a);
     } else {
-        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4>), grid, dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2>), grid, dim3(256), 0, s, a);
+        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4, false>), grid, dim3(256), lds_bytes(64), s, a);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2, false>), grid, dim3(256), lds_bytes(64), s, a);
     }
     CT_CHECK_LAUNCH("ct_dcn_v2");
     if (p.splits > 1) {

@@ -20,6 +20,7 @@ from .ops import View
 from .weights import CHANNELS, LEVELS, dla34_param_shapes
 
 BN_EPS = 1e-5
+FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 
 
 def _fold_bn(sd, p):
@@ -241,11 +242,20 @@ class DLASegHIP(torch.nn.Module):
             pk = P[name]
             om = ops.new_view(N, x.H, x.W, 32, dev)       # one per DCN: independent branches may overlap
             d = ops.make_conv_desc(x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
-            us = autotune.tune_conv(d, dev)[2] if tune else 10.0
-            L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk), reads=(x,), writes=(om,), us=us,
-                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            us_off = autotune.tune_conv(d, dev)[2] if tune else 10.0
             dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out)
             us = autotune.tune_dcn(dd, dev)[2] if tune else 20.0
+            if tune and x.C % 64 == 0 and FUSE_OFFSET:
+                # one launch computing the offset/mask conv itself vs offset conv + DCN (+ a kernel boundary)
+                df = ops.make_dcn_desc(x, None, pk['w'], cout, pk['scale'], pk['shift'], True, out,
+                                       w_off=pk['w_off'], b_off=pk['b_off'])
+                us_f = autotune.tune_dcn(df, dev)[2]
+                if 0.0 < us_f < us_off + us + 1.0:
+                    L.append(_Launch(name + '.dcn', 'dcn', df, (x, None, out, pk), reads=(x,), writes=(out,),
+                                     us=us_f, ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(df))))
+                    return out
+            L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk), reads=(x,), writes=(om,), us=us_off,
+                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk), reads=(x, om), writes=(out,), us=us,
                              ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd))))
             return out

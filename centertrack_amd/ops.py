@@ -118,10 +118,16 @@ def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
     return out if out is not None else kw['out_nchw']
 
 
-def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0):
+def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0, w_off=None,
+                  b_off=None):
+    """``w_off`` (packed conv_offset_mask weight) + ``b_off`` given: the offset/mask conv runs inside the DCN
+    launch (``om`` may be None); otherwise ``om`` is the precomputed NHWC offset/mask map."""
     d = DcnDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
-    d.om, d.ldom = om.ptr, om.ld
+    if om is not None:
+        d.om, d.ldom = om.ptr, om.ld
+    if w_off is not None:
+        d.fuse_offset, d.w_off_packed, d.b_off = 1, w_off.data_ptr(), b_off.data_ptr()
     d.w_packed, d.Cout = wp.data_ptr(), Cout
     d.scale, d.shift = _p(scale), _p(shift)
     d.y, d.ldy = out.ptr, out.ld
@@ -133,11 +139,11 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
     return d
 
 
-def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0):
+def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0, w_off=None, b_off=None):
     lib = _lib.load()
     if out is None:
         out = new_view(x.N, x.H, x.W, Cout, x.buf.device)
-    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo)
+    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo, w_off=w_off, b_off=b_off)
     ws = None
     if split_k != 1:
         need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))

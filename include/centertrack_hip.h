@@ -99,6 +99,10 @@ typedef struct ct_dcn_desc {
     int split_k;
     int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
                                                    workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts */
+    int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
+                                                   from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
+                                                   unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile */
+    const float *w_off_packed; const float *b_off;
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);

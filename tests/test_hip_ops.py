@@ -228,6 +228,21 @@ def test_offset_conv_plus_dcn_is_DCN_module(device):
     _close(out.to_nchw(), y, msg='DCN module')
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k', [(1, 12, 20, 64, 64, 3264, 1), (2, 9, 21, 128, 64, 0, 2),
+                                                       (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8)])
+def test_dcn_with_fused_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, algo, split_k):
+    """one launch: conv_offset_mask + sigmoid(mask) + deformable conv == upstream DCN.forward (oracle)"""
+    from centertrack_amd import ops
+    from oracle import dcn_v2 as odcn
+    x = F.relu(_rand(N, Cin, H, W, seed=40))
+    w, b = _rand(Cout, Cin, 3, 3, seed=41, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=42)
+    wo, bo = _rand(27, Cin, 3, 3, seed=43, scale=0.6 * (Cin * 9) ** -0.5), _rand(27, seed=44, scale=0.3)
+    y = odcn.dcn_forward(x, w, b, wo, bo)
+    out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), None, ops.pack_weight(w.to(device)), Cout, shift=b.to(device),
+                     algo=algo, split_k=split_k, w_off=ops.pack_weight(wo.to(device)), b_off=bo.to(device))
+    _close(out.to_nchw(), y, msg='fused DCN')
+
+
 @pytest.mark.parametrize('with_img,with_hm,shape', [(True, True, (2, 24, 40)), (True, False, (1, 16, 32)),
                                                    (False, False, (1, 9, 33)), (True, True, (1, 64, 96))])
 def test_stem_matches_torch(device, with_img, with_hm, shape):

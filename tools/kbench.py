@@ -112,7 +112,9 @@ def main():
     dvars = [('auto', {}), ('64/1', dict(algo=64, split=1)), ('64/2', dict(algo=64, split=2)), ('64/4', dict(algo=64, split=4)),
              ('64/8', dict(algo=64, split=8)), ('32x64/1', dict(algo=3264, split=1)), ('32x64/2', dict(algo=3264, split=2)),
              ('32x64/4', dict(algo=3264, split=4)), ('32x64/8', dict(algo=3264, split=8)),
-             ('32x128/1', dict(algo=32128, split=1)), ('32x128/4', dict(algo=32128, split=4))]
+             ('32x128/1', dict(algo=32128, split=1)), ('32x128/4', dict(algo=32128, split=4)),
+             ('F32x64/1', dict(algo=3264, split=1, fuse=1)), ('F32x64/2', dict(algo=3264, split=2, fuse=1)),
+             ('F32x64/4', dict(algo=3264, split=4, fuse=1)), ('F32x64/8', dict(algo=3264, split=8, fuse=1))]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in dvars))
     dtot = {v[0]: 0.0 for v in dvars}
     for name, cnt, H, Cin, Cout in dcns:
@@ -123,14 +125,17 @@ def main():
         om.buf[..., 18:].sigmoid_()
         w = ops.pack_weight(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05)
         out = ops.new_view(N, H, H, Cout, dev)
+        w_off = ops.pack_weight(torch.randn(27, Cin, 3, 3, device=dev) * 0.01)
+        b_off = torch.zeros(27, device=dev)
         gf = 2.0 * 9 * Cin * Cout * N * H * H / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in dvars:
             if kw.get('algo', 0) == 32128 and Cout < 128:
                 line += ' %12s' % '-'
                 continue
+            fz = dict(w_off=w_off, b_off=b_off) if kw.get('fuse') else {}
             d = ops.make_dcn_desc(x, om, w, Cout, None, None, True, out, workspace=ws, split_k=kw.get('split', 0),
-                                  algo=kw.get('algo', 0))
+                                  algo=kw.get('algo', 0), **fz)
             t = time_call(lambda: _lib.check(lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr())), args.reps)
             line += ' %7.1f/%4.0f' % (t, gf / t * 1e3)
             dtot[vname] += t * cnt
