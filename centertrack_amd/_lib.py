@@ -49,7 +49,9 @@ class DcnDesc(ctypes.Structure):
                 ('flags', ctypes.c_int),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
                 ('split_k', ctypes.c_int), ('algo', ctypes.c_int), ('fuse_offset', ctypes.c_int),
-                ('w_off_packed', ctypes.c_void_p), ('b_off', ctypes.c_void_p)]
+                ('w_off_packed', ctypes.c_void_p), ('b_off', ctypes.c_void_p),
+                ('up_w', ctypes.c_void_p), ('up_f', ctypes.c_int), ('up_skip', ctypes.c_void_p), ('up_lds', ctypes.c_int),
+                ('up_y', ctypes.c_void_p), ('up_ldy', ctypes.c_int)]
 
 
 class DecodeDesc(ctypes.Structure):

@@ -98,7 +98,8 @@ def _conv_key(d):
 
 
 def _dcn_key(d):
-    return 'dcn%s:%d,%d,%d,%d,%d' % ('F' if d.fuse_offset else '', d.N, d.H, d.W, d.Cin, d.Cout)
+    return 'dcn%s%s:%d,%d,%d,%d,%d' % ('F' if d.fuse_offset else '', 'U%d' % d.up_f if d.up_w else '', d.N, d.H, d.W,
+                                       d.Cin, d.Cout)
 
 
 _REG_BN = [16, 32, 64, 128, 64, 32]          # couts per workgroup of the row-tiled shapes 0..5

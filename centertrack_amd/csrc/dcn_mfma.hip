@@ -307,6 +307,12 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     if (p->fuse && (!d->w_off_packed || !d->b_off)) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
     if (p->fuse && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs Cin %% 64 == 0 (got %d)", d->Cin);
     if (!p->fuse && !d->om) CT_FAIL_ARG("ct_dcn_v2: null offset/mask map");
+    if (d->up_w) {
+        if (!d->up_skip || !d->up_y) CT_FAIL_ARG("ct_dcn_v2: up_w given without up_skip / up_y");
+        if (d->up_f != 2 && d->up_f != 4 && d->up_f != 8) CT_FAIL_ARG("ct_dcn_v2: up_f=%d unsupported", d->up_f);
+        if (d->Cout % 4 || d->up_lds % 4 || d->up_ldy % 4 || ((uintptr_t)d->up_skip & 15) || ((uintptr_t)d->up_y & 15))
+            CT_FAIL_ARG("ct_dcn_v2: up-sample views must be 16-byte aligned with Cout %% 4 == 0");
+    }
     if (d->Cin % 32 || d->Cin <= 0) CT_FAIL_ARG("ct_dcn_v2: Cin=%d must be a positive multiple of 32", d->Cin);
     if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_dcn_v2: input view must be 16-byte aligned");
     if (!p->fuse && d->ldom < 27) CT_FAIL_ARG("ct_dcn_v2: offset/mask map needs >= 27 channels");
@@ -377,6 +383,56 @@ __global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(const float *ws,
     }
 }
 
+// Split-K reduction fused with the IDAUp step that consumes a `proj` DCN (dla.py:543-545): one thread per
+// output pixel and 4 channels reduces the partials of the (at most four) input pixels it needs, applies
+// BN + ReLU and accumulates the depth-wise transposed conv on top of the skip tensor -- the same operation
+// order as dcn_splitk_reduce_kernel followed by upsample_add_kernel (bit-identical result), in one launch
+// and without materialising the DCN output.
+struct UpArgs {
+    const float *w;      // [2f*2f][C]
+    const float *skip;
+    float *y;
+    int f, lds, ldy;
+};
+__global__ __launch_bounds__(256) void dcn_reduce_upsample_kernel(const float *ws, int splits, size_t Mtot, int wsCout,
+                                                                  EpiArgs e, int N, int H, int W, UpArgs u)
+{
+    const int C = e.Cout, C4 = C >> 2, f = u.f, kw = 2 * f, p = f >> 1;
+    const int Ho = H * f, Wo = W * f;
+    const size_t total = (size_t)N * Ho * Wo * C4;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int c = (int)(idx % C4) * 4;
+    size_t q = idx / C4;
+    const int ox = (int)(q % Wo); q /= Wo;
+    const int oy = (int)(q % Ho);
+    const int n = (int)(q / Ho);
+    const int iy = (oy + p) / f, ky = (oy + p) - iy * f;
+    const int ix = (ox + p) / f, kx = (ox + p) - ix * f;
+    const size_t opix = ((size_t)n * Ho + oy) * Wo + ox;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(u.skip + opix * u.lds + c);
+    const f32x4 sc = e.scale ? *reinterpret_cast<const f32x4 *>(e.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
+    const f32x4 sh = e.shift ? *reinterpret_cast<const f32x4 *>(e.shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jy = 0; jy < 2; ++jy) {
+        const int yy = iy - jy;
+        if (yy < 0 || yy >= H) continue;
+#pragma unroll
+        for (int jx = 0; jx < 2; ++jx) {
+            const int xx = ix - jx;
+            if (xx < 0 || xx >= W) continue;
+            const size_t m = ((size_t)n * H + yy) * W + xx;
+            f32x4 s = *reinterpret_cast<const f32x4 *>(ws + m * wsCout + c);
+            for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(ws + ((size_t)k * Mtot + m) * wsCout + c);
+            const int widx = (ky + f * jy) * kw + (kx + f * jx);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(u.w + (size_t)widx * C + c);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] += ct_epilogue_value(e, s[i], c + i, sc[i], sh[i], 0.0f) * wv[i];
+        }
+    }
+    *reinterpret_cast<f32x4 *>(u.y + opix * u.ldy + c) = acc;
+}
+
 }  // namespace
 
 extern "C" size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d)
@@ -434,12 +490,23 @@ extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
         else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2, false>), grid, dim3(256), lds_bytes(64), s, a);
     }
     CT_CHECK_LAUNCH("ct_dcn_v2");
-    if (p.splits > 1) {
+    if (p.splits > 1 && d->up_w) {
+        const size_t Mtot = (size_t)d->N * d->H * d->W;
+        UpArgs u;
+        u.w = d->up_w; u.skip = d->up_skip; u.y = d->up_y; u.f = d->up_f; u.lds = d->up_lds; u.ldy = d->up_ldy;
+        const size_t nq = Mtot * (size_t)(d->up_f * d->up_f) * (size_t)(d->Cout / 4);
+        hipLaunchKernelGGL(dcn_reduce_upsample_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
+                           d->workspace, p.splits, Mtot, a.wsCout, a.epi, d->N, d->H, d->W, u);
+        CT_CHECK_LAUNCH("ct_dcn_v2(split-K reduce + upsample)");
+    } else if (p.splits > 1) {
         const size_t Mtot = (size_t)d->N * d->H * d->W;
         const size_t nq = Mtot * (size_t)(a.wsCout / 4);
         hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
                            d->workspace, p.splits, Mtot, a.wsCout, a.epi);
         CT_CHECK_LAUNCH("ct_dcn_v2(split-K reduce)");
     }
+    if (d->up_w && p.splits <= 1)      // no partials to fuse with: the plain IDAUp step on the DCN output
+        return ct_upsample_add(d->y, d->N, d->H, d->W, d->Cout, d->ldy, d->up_w, d->up_f, d->up_skip, d->up_lds, d->up_y,
+                               d->up_ldy, stream);
     return CT_OK;
 }

@@ -373,7 +373,19 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         const float ys0 = (float)(p / a.w), xs0 = (float)(p % a.w);
         float *row = a.out + ((size_t)b * a.K + r) * a.F;
         if (a.inds) a.inds[(size_t)b * a.K + r] = p;
-        auto hv = [&](int hd, int ch) { return a.heads[hd][((size_t)b * a.head_ch[hd] + ch) * HW + p]; };
+        // every head value of this row is fetched up front, branch-free (absent heads read hm[0] and are
+        // ignored): ~39 independent loads in flight instead of a chain of dependent round trips
+        constexpr int HCH[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
+        float hval[CT_NUM_HEADS][8];
+#pragma unroll
+        for (int hd = 0; hd < CT_NUM_HEADS; ++hd) {
+            const float *hp = a.heads[hd];
+            const bool on = hp != nullptr;
+            const float *base = on ? hp + (size_t)b * HCH[hd] * HW + p : a.hm;
+#pragma unroll
+            for (int ch = 0; ch < HCH[hd]; ++ch) hval[hd][ch] = base[on ? (size_t)ch * HW : 0];
+        }
+        auto hv = [&](int hd, int ch) { return hval[hd][ch]; };
         int f = 0;
         row[f++] = score; row[f++] = (float)cls; row[f++] = xs0; row[f++] = ys0;
         float xs = xs0 + 0.5f, ys = ys0 + 0.5f;                       // decode.py:102-110
@@ -400,10 +412,12 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         if (a.heads[CT_HEAD_LTRB_AMODAL]) for (int i = 0; i < 4; ++i) row[f++] = am[i];
         const int rest[7] = {CT_HEAD_TRACKING, CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET,
                              CT_HEAD_NUSCENES_ATT, CT_HEAD_VELOCITY};
+#pragma unroll
         for (int q = 0; q < 7; ++q) {
             const int hd = rest[q];
             if (!a.heads[hd]) continue;
-            for (int ch = 0; ch < a.head_ch[hd]; ++ch) row[f++] = hv(hd, ch);
+#pragma unroll
+            for (int ch = 0; ch < HCH[hd]; ++ch) row[f++] = hval[hd][ch];
         }
     }
 }

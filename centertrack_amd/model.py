@@ -21,6 +21,7 @@ from .weights import CHANNELS, LEVELS, dla34_param_shapes
 
 BN_EPS = 1e-5
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
+FUSE_UP = os.environ.get('CENTERTRACK_FUSE_UP', '1') != '0'
 
 
 def _fold_bn(sd, p):
@@ -237,26 +238,30 @@ class DLASegHIP(torch.nn.Module):
             feats.append(out)
             x = out
 
-        def deform(name, x, cout, out):
-            """DeformConv.forward (dla.py:515-518): offset/mask conv -> DCNv2 -> BN -> ReLU"""
+        def deform(name, x, cout, out, up=None):
+            """DeformConv.forward (dla.py:515-518): offset/mask conv -> DCNv2 -> BN -> ReLU; with ``up`` =
+            (weight, f, skip view, output view) the IDAUp step `up(.) + skip` (dla.py:543-545) that consumes a
+            `proj` node runs in the same C-ABI call (fused into the split-K reduction when there is one)."""
+            wr = (out,) if up is None else (out, up[3])
+            rd_up = () if up is None else (up[2],)
             pk = P[name]
             om = ops.new_view(N, x.H, x.W, 32, dev)       # one per DCN: independent branches may overlap
             d = ops.make_conv_desc(x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
             us_off = autotune.tune_conv(d, dev)[2] if tune else 10.0
-            dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out)
+            dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out, up=up)
             us = autotune.tune_dcn(dd, dev)[2] if tune else 20.0
             if tune and x.C % 64 == 0 and FUSE_OFFSET:
                 # one launch computing the offset/mask conv itself vs offset conv + DCN (+ a kernel boundary)
                 df = ops.make_dcn_desc(x, None, pk['w'], cout, pk['scale'], pk['shift'], True, out,
-                                       w_off=pk['w_off'], b_off=pk['b_off'])
+                                       w_off=pk['w_off'], b_off=pk['b_off'], up=up)
                 us_f = autotune.tune_dcn(df, dev)[2]
                 if 0.0 < us_f < us_off + us + 1.0:
-                    L.append(_Launch(name + '.dcn', 'dcn', df, (x, None, out, pk), reads=(x,), writes=(out,),
+                    L.append(_Launch(name + '.dcn', 'dcn', df, (x, None, out, pk, up), reads=(x,) + rd_up, writes=wr,
                                      us=us_f, ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(df))))
                     return out
             L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk), reads=(x,), writes=(om,), us=us_off,
                              ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-            L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk), reads=(x, om), writes=(out,), us=us,
+            L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk, up), reads=(x, om) + rd_up, writes=wr, us=us,
                              ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd))))
             return out
 
@@ -266,10 +271,14 @@ class DLASegHIP(torch.nn.Module):
                 k = i - startp
                 f = up_f[k]
                 xi = layers[i]
-                pr = deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o))
                 up = alloc(xi.H * f, xi.W * f, o)
-                L.append(_Launch('%s.up_%d' % (p, k), 'up', (pr, P['%s.up_%d' % (p, k)], f, layers[i - 1], up),
-                                 reads=(pr, layers[i - 1]), writes=(up,)))
+                if FUSE_UP:
+                    deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o),
+                           up=(P['%s.up_%d' % (p, k)], f, layers[i - 1], up))
+                else:
+                    pr = deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o))
+                    L.append(_Launch('%s.up_%d' % (p, k), 'up', (pr, P['%s.up_%d' % (p, k)], f, layers[i - 1], up),
+                                     reads=(pr, layers[i - 1]), writes=(up,)))
                 layers[i] = deform('%s.node_%d' % (p, k), up, o, alloc(up.H, up.W, o))
 
         layers = list(feats)                                   # DLAUp.forward, dla.py:568-574

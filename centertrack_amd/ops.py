@@ -119,7 +119,7 @@ def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
 
 
 def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0, w_off=None,
-                  b_off=None):
+                  b_off=None, up=None):
     """``w_off`` (packed conv_offset_mask weight) + ``b_off`` given: the offset/mask conv runs inside the DCN
     launch (``om`` may be None); otherwise ``om`` is the precomputed NHWC offset/mask map."""
     d = DcnDesc()
@@ -128,6 +128,10 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
         d.om, d.ldom = om.ptr, om.ld
     if w_off is not None:
         d.fuse_offset, d.w_off_packed, d.b_off = 1, w_off.data_ptr(), b_off.data_ptr()
+    if up is not None:                 # (upsample_weight [4f^2,C], f, skip view, output view): fused IDAUp step
+        w_up, f, skip, up_out = up
+        d.up_w, d.up_f, d.up_skip, d.up_lds = w_up.data_ptr(), f, skip.ptr, skip.ld
+        d.up_y, d.up_ldy = up_out.ptr, up_out.ld
     d.w_packed, d.Cout = wp.data_ptr(), Cout
     d.scale, d.shift = _p(scale), _p(shift)
     d.y, d.ldy = out.ptr, out.ld
@@ -139,11 +143,13 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
     return d
 
 
-def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0, w_off=None, b_off=None):
+def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0, w_off=None, b_off=None,
+           up=None):
     lib = _lib.load()
     if out is None:
         out = new_view(x.N, x.H, x.W, Cout, x.buf.device)
-    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo, w_off=w_off, b_off=b_off)
+    d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo, w_off=w_off, b_off=b_off,
+                      up=up)
     ws = None
     if split_k != 1:
         need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))

@@ -103,6 +103,10 @@ typedef struct ct_dcn_desc {
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
                                                    unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile */
     const float *w_off_packed; const float *b_off;
+    /* optional fused IDAUp step (dla.py:543-545) for a `proj` DCN: when up_w != NULL the layer's result goes
+     * through ct_upsample_add(result, up_w, up_f, up_skip) into up_y; with split-K the reduction kernel does
+     * it directly from the partials (`y` is then never written), otherwise `y` holds the DCN output. */
+    const float *up_w; int up_f; const float *up_skip; int up_lds; float *up_y; int up_ldy;
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);

@@ -243,6 +243,34 @@ def test_dcn_with_fused_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, al
     _close(out.to_nchw(), y, msg='fused DCN')
 
 
+@pytest.mark.parametrize('f,split_k', [(2, 4), (2, 1), (4, 2)])
+def test_dcn_with_fused_idaup_step(device, f, split_k):
+    """proj DCN + BN + ReLU + `up(.) + skip` in one C-ABI call (fused into the split-K reduction when there is
+    one) == the two separate ops, bit for bit, and == the oracle."""
+    from centertrack_amd import ops
+    from oracle import dcn_v2 as odcn
+    N, H, W, Cin, Cout = 2, 6, 10, 128, 64
+    x = F.relu(_rand(N, Cin, H, W, seed=50))
+    w, b = _rand(Cout, Cin, 3, 3, seed=51, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=52)
+    wo, bo = _rand(27, Cin, 3, 3, seed=53, scale=0.5 * (Cin * 9) ** -0.5), _rand(27, seed=54, scale=0.3)
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(55)) + 0.5
+    wup = _rand(Cout, 1, 2 * f, 2 * f, seed=56)
+    skip = _rand(N, Cout, H * f, W * f, seed=57)
+    y = F.relu(odcn.dcn_forward(x, w, None, wo, bo) * scale.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+    y = F.conv_transpose2d(y, wup, None, stride=f, padding=f // 2, groups=Cout) + skip
+    xv, sv = ops.view_from_nchw(x.to(device)), ops.view_from_nchw(skip.to(device))
+    wp, wop = ops.pack_weight(w.to(device)), ops.pack_weight(wo.to(device))
+    wt = ops.upsample_weight(wup.to(device))
+    up_out = ops.new_view(N, H * f, W * f, Cout, device)
+    ops.dcn_v2(xv, None, wp, Cout, scale=scale.to(device), shift=b.to(device), relu=True, split_k=split_k, algo=3264,
+               w_off=wop, b_off=bo.to(device), up=(wt, f, sv, up_out))
+    _close(up_out.to_nchw(), y, msg='fused IDAUp step')
+    pr = ops.dcn_v2(xv, None, wp, Cout, scale=scale.to(device), shift=b.to(device), relu=True, split_k=split_k, algo=3264,
+                    w_off=wop, b_off=bo.to(device))
+    two = ops.upsample_add(pr, wt, f, sv)
+    assert torch.equal(two.to_nchw(), up_out.to_nchw())
+
+
 @pytest.mark.parametrize('with_img,with_hm,shape', [(True, True, (2, 24, 40)), (True, False, (1, 16, 32)),
                                                    (False, False, (1, 9, 33)), (True, True, (1, 64, 96))])
 def test_stem_matches_torch(device, with_img, with_hm, shape):
