@@ -59,7 +59,8 @@ class DecodeDesc(ctypes.Structure):
                 ('w', ctypes.c_int), ('K', ctypes.c_int),
                 ('heads', ctypes.c_void_p * NUM_HEADS),
                 ('out', ctypes.c_void_p), ('inds', ctypes.c_void_p),
-                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
+                ('hm_batch_stride', ctypes.c_size_t), ('head_batch_stride', ctypes.c_size_t * NUM_HEADS)]
 
 
 class RowLayout(ctypes.Structure):

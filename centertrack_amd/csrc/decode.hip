@@ -112,6 +112,7 @@ struct Stage1Args {
     const float *hm;
     unsigned long long *cand;   // [B*C*nseg][K], unused slots = 0
     int B, C, h, w, K, nseg, seg;
+    size_t hm_bs;               // floats between consecutive images of hm
 };
 
 __global__ __launch_bounds__(256) void decode_stage1_kernel(Stage1Args a)
@@ -129,7 +130,7 @@ __global__ __launch_bounds__(256) void decode_stage1_kernel(Stage1Args a)
     const int p_lo = seg * a.seg;
     const int p_hi = min(HW, p_lo + a.seg);
     const int nloc = p_hi - p_lo;
-    const float *map = a.hm + ((size_t)b * a.C + c) * HW;
+    const float *map = a.hm + (size_t)b * a.hm_bs + (size_t)c * HW;
 
     const int y_lo = p_lo / a.w, y_hi = (p_hi - 1) / a.w;
     const int r_lo = max(0, y_lo - 1), r_hi = min(a.h - 1, y_hi + 1);
@@ -191,6 +192,8 @@ struct Stage2Args {
     const float *hm;
     const float *heads[CT_NUM_HEADS];
     int head_ch[CT_NUM_HEADS];
+    size_t head_bs[CT_NUM_HEADS];   // floats between consecutive images of each head map
+    size_t hm_bs;
     float *out;
     long long *inds;
     int B, C, h, w, K, nseg, F;
@@ -337,7 +340,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         }
     } else {
         // fewer than K positive survivors: exact selection over every (class, pixel) of the image
-        const float *hm_b = a.hm + (size_t)b * a.C * HW;
+        const float *hm_b = a.hm + (size_t)b * a.hm_bs;
         const int NALL = a.C * HW;
         auto getall = [&](int i) -> unsigned long long { return key_from_map(hm_b, a.C, a.h, a.w, (unsigned)i); };
         const unsigned long long T = radix_select_kth(getall, NALL, a.K, hist, bcast);
@@ -381,7 +384,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         for (int hd = 0; hd < CT_NUM_HEADS; ++hd) {
             const float *hp = a.heads[hd];
             const bool on = hp != nullptr;
-            const float *base = on ? hp + (size_t)b * HCH[hd] * HW + p : a.hm;
+            const float *base = on ? hp + (size_t)b * a.head_bs[hd] + p : a.hm;
 #pragma unroll
             for (int ch = 0; ch < HCH[hd]; ++ch) hval[hd][ch] = base[on ? (size_t)ch * HW : 0];
         }
@@ -482,6 +485,8 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     Stage1Args a1;
     a1.hm = d->hm; a1.cand = (unsigned long long *)d->workspace;
     a1.B = d->B; a1.C = d->C; a1.h = d->h; a1.w = d->w; a1.K = d->K; a1.nseg = nseg; a1.seg = seg;
+    const size_t HWs = (size_t)d->h * d->w;
+    a1.hm_bs = d->hm_batch_stride ? (size_t)d->hm_batch_stride : (size_t)d->C * HWs;
     const int max_rows = ct_cdiv(seg, d->w) + 3;
     const size_t lds1 = SEG_MAX * sizeof(unsigned long long) + (size_t)max_rows * d->w * sizeof(float);
     static bool attr_set = false;
@@ -495,7 +500,11 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     CT_CHECK_LAUNCH("ct_decode(stage 1)");
     Stage2Args a2;
     a2.cand = a1.cand; a2.hm = d->hm;
-    for (int i = 0; i < CT_NUM_HEADS; ++i) { a2.heads[i] = d->heads[i]; a2.head_ch[i] = kHeadCh[i]; }
+    for (int i = 0; i < CT_NUM_HEADS; ++i) {
+        a2.heads[i] = d->heads[i]; a2.head_ch[i] = kHeadCh[i];
+        a2.head_bs[i] = d->head_batch_stride[i] ? (size_t)d->head_batch_stride[i] : (size_t)kHeadCh[i] * HWs;
+    }
+    a2.hm_bs = a1.hm_bs;
     a2.out = d->out; a2.inds = (long long *)d->inds;
     a2.B = d->B; a2.C = d->C; a2.h = d->h; a2.w = d->w; a2.K = d->K; a2.nseg = nseg;
     a2.F = ct_decode_row_floats(d);

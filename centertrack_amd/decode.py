@@ -29,8 +29,11 @@ def generic_decode(output, K=100, opt=None):
     hm = output['hm']
     if not hm.is_cuda or hm.dtype != torch.float32:
         raise _lib.CTError('generic_decode runs on an MI355X (cuda fp32 tensors); no CPU fallback')
-    heads = {k: v.contiguous() for k, v in output.items() if k in _lib.HEAD_INDEX}
-    dec = ops.Decoder(hm.contiguous(), heads, K)
+    def planes(t):     # ct_decode wants every image's [c,h,w] block contiguous (images may be strided)
+        ok = t.stride(3) == 1 and t.stride(2) == t.shape[3] and (t.shape[1] == 1 or t.stride(1) == t.shape[2] * t.shape[3])
+        return t if ok else t.contiguous()
+    heads = {k: planes(v) for k, v in output.items() if k in _lib.HEAD_INDEX}
+    dec = ops.Decoder(planes(hm), heads, K)
     packed = dec.run()
     ret = dec.unpack(packed)
     # (decode.py:159: with an ltrb_amodal head the kernel already writes the amodal box into 'bboxes')

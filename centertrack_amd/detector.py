@@ -126,10 +126,14 @@ class StreamDetector(object):
         ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if (with_hm and not self.native) else None
         render = self.native and with_hm
         if render:
-            ctx['prm_host'] = torch.zeros((self.B, fast_track.MAX_BLOBS, 3), dtype=torch.int32).pin_memory()
-            ctx['cnt_host'] = torch.zeros((self.B,), dtype=torch.int32).pin_memory()
-            ctx['prm_dev'] = torch.zeros((self.B, fast_track.MAX_BLOBS, 3), dtype=torch.int32, device=self.device)
-            ctx['cnt_dev'] = torch.zeros((self.B,), dtype=torch.int32, device=self.device)
+            # blob triples of every stream followed by the per-stream counts: ONE pinned buffer, one H2D per frame
+            nprm = self.B * fast_track.MAX_BLOBS * 3
+            ctx['pc_host'] = torch.zeros((nprm + self.B,), dtype=torch.int32).pin_memory()
+            ctx['pc_dev'] = torch.zeros((nprm + self.B,), dtype=torch.int32, device=self.device)
+            ctx['prm_host'] = ctx['pc_host'][:nprm].view(self.B, fast_track.MAX_BLOBS, 3)
+            ctx['cnt_host'] = ctx['pc_host'][nprm:]
+            ctx['prm_dev'] = ctx['pc_dev'][:nprm]
+            ctx['cnt_dev'] = ctx['pc_dev'][nprm:]
         if self.native:
             ctx['row_layout'] = fast_track.row_layout(ctx['decoder'].layout)
         # Frame buffers owned by THIS detector (the plan's activation buffers are shared by every detector of
@@ -236,8 +240,7 @@ class StreamDetector(object):
                     m = metas[s]
                     ch[s], _ = self.fast[s].prehm_params(opt.pre_thresh, m['trans_input'], m['inp_width'],
                                                          m['inp_height'], out=ph[s])
-                ctx['prm_dev'].copy_(ctx['prm_host'], non_blocking=True)
-                ctx['cnt_dev'].copy_(ctx['cnt_host'], non_blocking=True)
+                ctx['pc_dev'].copy_(ctx['pc_host'], non_blocking=True)
             elif hm_in is not None:
                 hh = ctx['host_hm']
                 for s in range(B):

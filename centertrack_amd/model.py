@@ -155,7 +155,18 @@ class DLASegHIP(torch.nn.Module):
         w0 = torch.cat([sd[h + '.0.weight'] for h in self.heads], 0)
         P['head0_w'] = ops.pack_weight(w0)
         P['head0_b'] = torch.cat([sd[h + '.0.bias'] for h in self.heads], 0).contiguous()
-        for h in self.heads:
+        # ... and all second (1x1) layers as ONE block-diagonal 256*nh -> sum(c) conv: a single launch reads
+        # the intermediate once and writes every head into channel slices of one NCHW tensor
+        hc = self.head_conv
+        ctot = sum(self.heads.values())
+        w2 = torch.zeros((ctot, hc * len(self.heads), 1, 1), device=dev)
+        c0 = 0
+        for j, (h, c) in enumerate(self.heads.items()):
+            w2[c0:c0 + c, hc * j:hc * (j + 1)] = sd[h + '.2.weight']
+            c0 += c
+        P['head2_w'] = ops.pack_weight(w2)
+        P['head2_b'] = torch.cat([sd[h + '.2.bias'] for h in self.heads], 0).contiguous()
+        for h in self.heads:      # per-head form, used when the block-diagonal one would waste too many flops
             P[h + '.2'] = (ops.pack_weight(sd[h + '.2.weight']), sd[h + '.2.bias'].contiguous())
         self._prepared = P
         return P
@@ -298,18 +309,39 @@ class DLASegHIP(torch.nn.Module):
         us = autotune.tune_conv(d, dev)[2] if tune else 200.0
         L.append(_Launch('heads.0', 'conv', d, (feat, mid), reads=(feat,), writes=(mid,), us=us,
                          ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+        ctot = sum(self.heads.values())
+        comb = torch.empty((N, ctot, feat.H, feat.W), device=dev)
+        sig, dep = (0, 0), (0, 0)
+        c0 = 0
         outputs = OrderedDict()
-        for j, (hname, c) in enumerate(self.heads.items()):
-            o = torch.empty((N, c, feat.H, feat.W), device=dev)
-            wp, b = P[hname + '.2']
-            sig = (0, c) if (fuse_sigmoid and hname in ('hm', 'hm_hp')) else (0, 0)
-            dep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
-            d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=sig, dep=dep,
+        for hname, c in self.heads.items():
+            if fuse_sigmoid and hname == 'hm':
+                sig = (c0, c0 + c)
+            if fuse_sigmoid and hname == 'dep':
+                dep = (c0, c0 + c)
+            outputs[hname] = comb[:, c0:c0 + c]            # channel-slice views of the combined tensor
+            c0 += c
+        if ctot <= 32:
+            # few output channels (MOT 11, KITTI 9, nuScenes 30): one block-diagonal conv over the whole intermediate
+            d = ops.make_conv_desc(mid, P['head2_w'], ctot, 1, 1, shift=P['head2_b'], out_nchw=comb, sig=sig, dep=dep,
                                    depth_scale=self.depth_scale)
-            us = autotune.tune_conv(d, dev)[2] if tune else 7.0
-            L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o), reads=(mid.slice(hc * j, hc),), writes=(o,),
-                             us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-            outputs[hname] = o
+            us = autotune.tune_conv(d, dev)[2] if tune else 20.0
+            L.append(_Launch('heads.2', 'conv', d, (mid, comb), reads=(mid,), writes=(comb,), us=us,
+                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+        else:
+            # a wide head (COCO: 80 classes): the block-diagonal form would multiply its flops by the number of heads
+            outputs = OrderedDict()
+            for j, (hname, c) in enumerate(self.heads.items()):
+                o = torch.empty((N, c, feat.H, feat.W), device=dev)
+                wp, b = P[hname + '.2']
+                hsig = (0, c) if (fuse_sigmoid and hname == 'hm') else (0, 0)
+                hdep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
+                d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=hsig, dep=hdep,
+                                       depth_scale=self.depth_scale)
+                us = autotune.tune_conv(d, dev)[2] if tune else 7.0
+                L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o), reads=(mid.slice(hc * j, hc),), writes=(o,),
+                                 us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+                outputs[hname] = o
         plan['outputs'] = outputs
         # ---- streams: independent branches (IDAUp projections, residual projections, pools) overlap ----
         S = int(os.environ.get('CENTERTRACK_STREAMS', '1'))   # > 1: experimental

@@ -221,12 +221,18 @@ class Decoder(object):
         self.K = K
         B, C, h, w = hm.shape
         self.hm, self.heads = hm, dict(heads)
+
+        def planes_ok(t):      # every image's [c,h,w] block contiguous; images may be strided (channel slices)
+            return t.stride(3) == 1 and t.stride(2) == w and (t.shape[1] == 1 or t.stride(1) == h * w)
         d = DecodeDesc()
+        assert planes_ok(hm)
         d.hm, d.B, d.C, d.h, d.w, d.K = hm.data_ptr(), B, C, h, w, K
+        d.hm_batch_stride = hm.stride(0)
         for name, t in heads.items():
             if name in _lib.HEAD_INDEX:
-                assert t.is_contiguous() and t.shape[1] == _lib.HEAD_CH[name], name
+                assert planes_ok(t) and t.shape[1] == _lib.HEAD_CH[name], name
                 d.heads[_lib.HEAD_INDEX[name]] = t.data_ptr()
+                d.head_batch_stride[_lib.HEAD_INDEX[name]] = t.stride(0)
         self.layout, self.F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX])
         assert lib.ct_decode_row_floats(ctypes.byref(d)) == self.F
         self.out = torch.empty((B, K, self.F), dtype=torch.float32, device=hm.device)

@@ -150,6 +150,9 @@ typedef struct ct_decode_desc {
     float *out;                /* [B,K,F] floats, F = ct_decode_row_floats(heads present) */
     int64_t *inds;             /* [B,K] flat pixel indices (may be NULL) */
     void *workspace; size_t workspace_bytes;
+    /* floats between consecutive images of hm / of each head map; 0 = densely packed ([B,c,h,w] contiguous).
+     * Lets the head maps be channel slices of one wider NCHW tensor (all heads written by one conv launch). */
+    size_t hm_batch_stride; size_t head_batch_stride[CT_NUM_HEADS];
 } ct_decode_desc;
 /* row layout: score, cls, xs0, ys0, then for each present field in this order:
  * bbox[4] (if wh|ltrb|ltrb_amodal), bbox_amodal[4] (if ltrb_amodal), tracking[2], dep[1],
