@@ -36,7 +36,7 @@ class ConvDesc(ctypes.Structure):
                 ('sig_lo', ctypes.c_int), ('sig_hi', ctypes.c_int),
                 ('dep_lo', ctypes.c_int), ('dep_hi', ctypes.c_int), ('depth_scale', ctypes.c_float),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-                ('split_k', ctypes.c_int), ('algo', ctypes.c_int)]
+                ('split_k', ctypes.c_int), ('algo', ctypes.c_int), ('w_winograd', ctypes.c_void_p)]
 
 
 class DcnDesc(ctypes.Structure):
@@ -74,7 +74,8 @@ class Track(ctypes.Structure):
                 ('row', ctypes.c_int)]
 
 
-EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight', 'ct_conv2d',
+EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
+           'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
            'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_render_pre_hm',
@@ -105,6 +106,9 @@ def load():
     lib.ct_packed_weight_elems.restype = sz
     lib.ct_packed_weight_elems.argtypes = [i, i, i]
     lib.ct_pack_conv_weight.argtypes = [p, p, i, i, i, p]
+    lib.ct_packed_winograd_elems.restype = sz
+    lib.ct_packed_winograd_elems.argtypes = [i, i]
+    lib.ct_pack_winograd_weight.argtypes = [p, p, i, i, p]
     lib.ct_conv2d.argtypes = [ctypes.POINTER(ConvDesc), p]
     lib.ct_conv2d_workspace_bytes.restype = sz
     lib.ct_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]

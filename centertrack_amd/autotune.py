@@ -93,8 +93,8 @@ def _time_graph(fn, reps=REPS):
 
 
 def _conv_key(d):
-    return 'conv:%d,%d,%d,%d,%d,%d,%d,%d,%d' % (d.N, d.H, d.W, d.Cin, d.Cout, d.ks, d.stride,
-                                                 1 if d.res else 0, 1 if (d.flags & _lib.CT_OUT_NCHW) else 0)
+    return 'conv%s:%d,%d,%d,%d,%d,%d,%d,%d,%d' % ('W' if d.w_winograd else '', d.N, d.H, d.W, d.Cin, d.Cout, d.ks,
+                                                   d.stride, 1 if d.res else 0, 1 if (d.flags & _lib.CT_OUT_NCHW) else 0)
 
 
 def _dcn_key(d):
@@ -120,6 +120,9 @@ def _conv_candidates(d):
         if 16 * wn > max(32, cout_pad):
             continue
         cands.append((101 + i, 1))
+    if d.w_winograd and d.ks == 3 and d.stride == 1 and d.Cin % 64 == 0 and not (d.flags & _lib.CT_OUT_NCHW):
+        cands.append((201, 1))                    # Winograd F(2x2,3x3), 64 / 32 couts per workgroup
+        cands.append((202, 1))
     return cands
 
 

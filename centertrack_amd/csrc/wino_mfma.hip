@@ -1,0 +1,302 @@
+// 3x3 stride-1 convolution by Winograd F(2x2, 3x3) on the fp32 matrix cores.
+//
+//   Y = A^T [ (G g G^T) .* (B^T d B) ] A          (Lavin & Gray): 16 multiplies per 2x2 outputs instead of 36
+//
+// fp32 MFMA on gfx950 runs at the fp32 vector rate, so the dense 3x3 layers are MFMA-bound and the 2.25x
+// cut in multiplies is the one algorithmic lever left (cuDNN, the reference's backend, makes the same
+// choice for these layers).  The element-wise product over channels is 16 independent GEMMs, one per
+// position (r,c) of the 4x4 transformed tile:  M[pos][tile, co] = sum_ci V[pos][tile, ci] * U[pos][ci, co].
+//
+// One workgroup (4 waves) = 16 Winograd tiles (2 tile rows x 8 tile columns = 4 x 16 output pixels, the
+// MFMA M dimension) x 16*WN couts.  Wave r owns the four positions (r, 0..3):
+//   * the raw input patch (6 x 18 pixels, zero padded) of a 64-channel chunk is staged once in LDS (same
+//     swizzled [slab][pixel][16 ch] layout as conv_mfma.hip); the input transform B^T d B is done ON THE FLY
+//     while building an A fragment: 8 ds_read_b128 + 8 vector adds give the 4 fragments V[(r,0..3)] of a slab;
+//   * U = G g G^T is precomputed by ct_pack_winograd_weight into MFMA fragment order [pos][Cin/16][NT][256]
+//     (1 KiB per fragment, loaded L2 -> VGPR two steps ahead);
+//   * output transform: columns (c) in registers, rows (r) across the four waves through LDS, then
+//     scale/shift/residual/ReLU and the NHWC store.
+#include "ct_common.h"
+
+namespace {
+
+struct WinoArgs {
+    const float *x;
+    const float *up;          // packed U
+    int N, H, W, Cin, ldx;
+    int tilesX, tilesY, coutBlocks;
+    int NT;                   // CoutPad / 16
+    int nchunks;              // Cin / 64
+    EpiArgs epi;
+};
+
+constexpr int W_PH = 6, W_PW = 18, W_PP = W_PH * W_PW;       // raw patch of a 4 x 16 output block
+constexpr int W_SLAB = W_PP * 16;                           // floats per 16-channel slab
+constexpr int W_BUF = 4 * W_SLAB;                           // floats per 64-channel chunk
+constexpr int W_ITEMS = 4 * W_PP * 4;                       // float4 items per chunk
+constexpr int W_NR = (W_ITEMS + 255) / 256;
+
+// B^T rows as (i1, i2, s2): V = d[i1] + s2 * d[i2]   (r=0: d0-d2, r=1: d1+d2, r=2: d2-d1, r=3: d1-d3)
+__device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
+{
+    i1 = (r == 0) ? 0 : ((r == 2) ? 2 : 1);
+    i2 = (r == 0) ? 2 : ((r == 1) ? 2 : ((r == 2) ? 1 : 3));
+    s2 = (r == 1) ? 1.0f : -1.0f;
+}
+
+template <int WN>
+__global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+
+    int bid = blockIdx.x;
+    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int tx = bid % a.tilesX; bid /= a.tilesX;
+    const int ty = bid % a.tilesY; bid /= a.tilesY;
+    const int n = bid;
+    const int oy0 = ty * 4, ox0 = tx * 16;
+    const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
+
+    // ---- staging of the raw patch (rows oy0-1 .. oy0+4, cols ox0-1 .. ox0+16) -------------------------
+    int goff[W_NR], loff[W_NR];
+#pragma unroll
+    for (int r = 0; r < W_NR; ++r) {
+        const int it = tid + 256 * r;
+        if (it < W_ITEMS) {
+            const int q = it & 3;
+            const int pp = it >> 2;
+            const int kk = pp / W_PP;
+            const int P = pp - kk * W_PP;
+            const int py = P / W_PW, px = P - py * W_PW;
+            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+            loff[r] = kk * W_SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
+            goff[r] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4) : -1;
+        } else {
+            loff[r] = -1;
+            goff[r] = -1;
+        }
+    }
+    f32x4 stage[W_NR];
+    auto stage_load = [&](int chunk) {
+        const int coff = chunk * 64;
+#pragma unroll
+        for (int r = 0; r < W_NR; ++r) {
+            const bool ok = goff[r] >= 0;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
+            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto stage_store = [&](int buf) {
+        float *dst = lds + buf * W_BUF;
+#pragma unroll
+        for (int r = 0; r < W_NR; ++r)
+            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
+    };
+
+    // ---- A side: lane li = Winograd tile (row li>>3, column li&7), lg = channel quad; wave = row r of the
+    //      transformed tile.  Patch pixel of d[i][j] of this lane's tile: (2*trow + i, 2*tcol + j).
+    int ri1, ri2;
+    float rs2;
+    bt_row(wave, ri1, ri2, rs2);
+    const int trow = li >> 3, tcol = li & 7;
+    int pa[2][4];                                   // LDS float offsets (inside a slab) of d[i1][0..3], d[i2][0..3]
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int P1 = (2 * trow + ri1) * W_PW + 2 * tcol + j;
+        const int P2 = (2 * trow + ri2) * W_PW + 2 * tcol + j;
+        pa[0][j] = P1 * 16 + ((lg ^ ((P1 >> 1) & 2)) << 2);
+        pa[1][j] = P2 * 16 + ((lg ^ ((P2 >> 1) & 2)) << 2);
+    }
+
+    // ---- B side ----------------------------------------------------------------------------------------
+    const int nt0 = cb * WN;
+    const int NCH16 = a.Cin >> 4;
+    const float *bptr[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.up + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
+    const size_t slab_stride = (size_t)a.NT << 8;
+    // step s of a chunk = (slab s>>2, column c = s&3); position = wave*4 + c
+    auto load_b = [&](f32x4 (&b)[WN], int chunk, int s) {
+        const int c = s & 3, kk = s >> 2;
+        const size_t slab = (size_t)(wave * 4 + c) * NCH16 + (size_t)min(chunk, a.nchunks - 1) * 4 + kk;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
+    };
+
+    f32x4 acc[4][WN];                              // [column c of the transformed tile][n-tile]
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    constexpr int S = 16, D = 2, R = 4;            // 16 steps per chunk, B prefetched 2 steps ahead, ring of 4
+    {
+        stage_load(0);
+        f32x4 breg[R][WN];
+        load_b(breg[0], 0, 0);
+        load_b(breg[1], 0, 1);
+        stage_store(0);
+        __syncthreads();
+        for (int ch = 0; ch < a.nchunks; ++ch) {
+            const int cur = ch & 1;
+            stage_load(min(ch + 1, a.nchunks - 1));
+            __builtin_amdgcn_sched_barrier(0x386);
+            const float *buf = lds + cur * W_BUF;
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+                // input transform of this slab: rows combined first, then the four column combinations
+                f32x4 e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 d1 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + pa[0][j]);
+                    const f32x4 d2 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + pa[1][j]);
+                    e[j] = d1 + rs2 * d2;
+                }
+                f32x4 v[4];
+                v[0] = e[0] - e[2];
+                v[1] = e[1] + e[2];
+                v[2] = e[2] - e[1];
+                v[3] = e[1] - e[3];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const int s = kk * 4 + c;
+                    const int sp = s + D;
+                    load_b(breg[(s + D) % R], ch + sp / S, sp % S);
+                    __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+                    for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][ee], breg[s % R][nt][ee], acc[c][nt], 0, 0, 0);
+                }
+            }
+            if (ch + 1 < a.nchunks) stage_store(cur ^ 1);
+            __syncthreads();
+        }
+    }
+
+    // ---- output transform: columns in registers ... ---------------------------------------------------
+    // T[q][nt]: q=0: M0+M1+M2, q=1: M1-M2-M3   (this wave's row r)
+    float *exch = lds;                              // [r 4][q 2][nt WN][lane 64] float4
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        const f32x4 t0 = acc[0][nt] + acc[1][nt] + acc[2][nt];
+        const f32x4 t1 = acc[1][nt] - acc[2][nt] - acc[3][nt];
+        *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 0) * WN + nt) * 64 + lane) * 4) = t0;
+        *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 1) * WN + nt) * 64 + lane) * 4) = t1;
+    }
+    __syncthreads();
+    // ... rows across the waves: Y[0][q] = T0+T1+T2, Y[1][q] = T1-T2-T3; 2*WN (q, nt) pairs over 4 waves
+#pragma unroll
+    for (int w0 = 0; w0 < 2 * WN; w0 += 4) {
+        const int job = w0 + wave;
+        if (job < 2 * WN) {
+            const int q = job & 1, nt = job >> 1;
+            f32x4 t[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) t[r] = *reinterpret_cast<const f32x4 *>(exch + (((r * 2 + q) * WN + nt) * 64 + lane) * 4);
+            const f32x4 y0 = t[0] + t[1] + t[2];
+            const f32x4 y1 = t[1] - t[2] - t[3];
+            const int co = (nt0 + nt) * 16 + li;
+            if (co < a.epi.Cout) {
+                const float sc = a.epi.scale ? a.epi.scale[co] : 1.0f;
+                const float sh = a.epi.shift ? a.epi.shift[co] : 0.0f;
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const int tile = lg * 4 + ee;
+                    const int ox = ox0 + 2 * (tile & 7) + q;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const int oy = oy0 + 2 * (tile >> 3) + p;
+                        if (oy < a.epi.Ho && ox < a.epi.Wo) {
+                            const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
+                            const float r = a.epi.res ? a.epi.res[pix * a.epi.ldr + co] : 0.0f;
+                            a.epi.y[pix * a.epi.ldy + co] = ct_epilogue_value(a.epi, p ? y1[ee] : y0[ee], co, sc, sh, r);
+                        }
+                    }
+                }
+            }
+        }
+    }
+}
+
+// U[pos][co][ci] = (G g G^T)[r][c], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
+__global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, float *p, int Cout, int Cin, int NT)
+{
+    const size_t total = (size_t)16 * (Cin >> 4) * NT * 256;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const int e = idx & 3, j = (idx >> 2) & 15, g = (idx >> 6) & 3;
+    size_t t = idx >> 8;
+    const int nt = t % NT; t /= NT;
+    const int c16 = t % (Cin >> 4);
+    const int pos = (int)(t / (Cin >> 4));
+    const int co = nt * 16 + j, ci = c16 * 16 + 4 * g + e;
+    float u = 0.0f;
+    if (co < Cout) {
+        const float G[4][3] = {{1.f, 0.f, 0.f}, {.5f, .5f, .5f}, {.5f, -.5f, .5f}, {0.f, 0.f, 1.f}};
+        const int r = pos >> 2, c = pos & 3;
+        const float *g3 = w + ((size_t)co * Cin + ci) * 9;
+        for (int aa = 0; aa < 3; ++aa)
+            for (int bb = 0; bb < 3; ++bb) u += G[r][aa] * g3[aa * 3 + bb] * G[c][bb];
+    }
+    p[idx] = u;
+}
+
+template <int WN>
+int launch_wino(const WinoArgs &a, dim3 grid, size_t lds, hipStream_t s)
+{
+    auto k = wino_conv_kernel<WN>;
+    static bool attr_set = false;
+    if (!attr_set) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    return CT_OK;
+}
+
+}  // namespace
+
+extern "C" size_t ct_packed_winograd_elems(int Cout, int Cin) { return (size_t)16 * (Cin / 16) * ct_cdiv(Cout, 16) * 256; }
+
+extern "C" int ct_pack_winograd_weight(const float *w_oihw, float *packed, int Cout, int Cin, void *stream)
+{
+    if (!w_oihw || !packed) CT_FAIL_ARG("ct_pack_winograd_weight: null pointer");
+    if (Cin % 16 || Cin <= 0 || Cout <= 0) CT_FAIL_ARG("ct_pack_winograd_weight: Cin=%d must be a multiple of 16", Cin);
+    const size_t total = ct_packed_winograd_elems(Cout, Cin);
+    hipLaunchKernelGGL(pack_winograd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       w_oihw, packed, Cout, Cin, ct_cdiv(Cout, 16));
+    CT_CHECK_LAUNCH("ct_pack_winograd_weight");
+    return CT_OK;
+}
+
+// called by ct_conv2d for algo 201 (64 couts / workgroup) and 202 (32 couts / workgroup)
+int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
+{
+    if (d->ks != 3 || d->stride != 1) CT_FAIL_ARG("ct_conv2d: the Winograd algo is for 3x3 stride-1 convolutions");
+    if (!d->w_winograd) CT_FAIL_ARG("ct_conv2d: algo %d needs w_winograd (ct_pack_winograd_weight)", d->algo);
+    if (d->Cin % 64) CT_FAIL_ARG("ct_conv2d: the Winograd algo needs Cin %% 64 == 0 (got %d)", d->Cin);
+    if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_conv2d: the Winograd algo writes NHWC only");
+    if (d->sig_hi > d->sig_lo || d->dep_hi > d->dep_lo) CT_FAIL_ARG("ct_conv2d: the Winograd algo has no sigmoid epilogue");
+    const int WN = (d->algo == 201) ? 4 : 2;
+    WinoArgs a;
+    a.x = d->x; a.up = d->w_winograd;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN);
+    a.NT = ct_cdiv(d->Cout, 16); a.nchunks = d->Cin / 64;
+    a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = d->res; a.epi.y = d->y;
+    a.epi.ldr = d->ldr; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;
+    a.epi.flags = d->flags; a.epi.sig_lo = a.epi.sig_hi = 0; a.epi.dep_lo = a.epi.dep_hi = 0; a.epi.depth_scale = 1.0f;
+    const long blocks = (long)d->N * a.tilesX * a.tilesY * a.coutBlocks;
+    if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_conv2d: grid too large");
+    const size_t patch = sizeof(float) * (size_t)W_BUF * (a.nchunks > 1 ? 2 : 1);
+    const size_t exch = sizeof(float) * (size_t)(4 * 2 * WN * 256);
+    const size_t lds = patch > exch ? patch : exch;
+    int rc = (WN == 4) ? launch_wino<4>(a, dim3((unsigned)blocks), lds, (hipStream_t)stream)
+                       : launch_wino<2>(a, dim3((unsigned)blocks), lds, (hipStream_t)stream);
+    CT_CHECK_LAUNCH("ct_conv2d(winograd)");
+    return rc;
+}

@@ -22,6 +22,7 @@ from .weights import CHANNELS, LEVELS, dla34_param_shapes
 BN_EPS = 1e-5
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 FUSE_UP = os.environ.get('CENTERTRACK_FUSE_UP', '1') != '0'
+WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 
 
 def _fold_bn(sd, p):
@@ -104,9 +105,14 @@ class DLASegHIP(torch.nn.Module):
         sd = {k: v.to(dev) for k, v in self.state_dict().items()}
         P = {}
 
+        def wino(w):
+            """Winograd F(2x2,3x3) form of a 3x3 weight the stride-1 layers may be run with (autotuner's choice)"""
+            ok = WINOGRAD and w.shape[2] == 3 and w.shape[1] % 64 == 0
+            return ops.pack_winograd(w) if ok else None
+
         def conv_bn(wkey, bnkey):
             sc, sh = _fold_bn(sd, bnkey)
-            return ops.pack_weight(sd[wkey]), sc, sh
+            return ops.pack_weight(sd[wkey]), sc, sh, wino(sd[wkey])
 
         P['stem_w'] = [sd['base.base_layer.0.weight'].contiguous(),
                        sd['base.pre_img_layer.0.weight'].contiguous() if self.pre_img else None,
@@ -154,6 +160,7 @@ class DLASegHIP(torch.nn.Module):
         # heads: all first layers share their input -> one 64 -> 256*nh conv
         w0 = torch.cat([sd[h + '.0.weight'] for h in self.heads], 0)
         P['head0_w'] = ops.pack_weight(w0)
+        P['head0_ww'] = wino(w0)
         P['head0_b'] = torch.cat([sd[h + '.0.bias'] for h in self.heads], 0).contiguous()
         # ... and all second (1x1) layers as ONE block-diagonal 256*nh -> sum(c) conv: a single launch reads
         # the intermediate once and writes every head into channel slices of one NCHW tensor
@@ -186,8 +193,9 @@ class DLASegHIP(torch.nn.Module):
             return ops.new_view(N, h, w, c, dev)
 
         def add_conv(name, x, pk, cout, ks, stride=1, relu=True, res=None, out=None, **kw):
-            wp, sc, sh = pk
-            d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out, **kw)
+            wp, sc, sh, ww = pk
+            d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out,
+                                   w_wino=(ww if stride == 1 else None), **kw)
             us = autotune.tune_conv(d, dev)[2] if tune else 10.0
             L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw')), reads=(x, res),
                              writes=(out, kw.get('out_nchw')), us=us,
@@ -305,7 +313,8 @@ class DLASegHIP(torch.nn.Module):
         nh = len(self.heads)
         hc = self.head_conv
         mid = alloc(feat.H, feat.W, hc * nh)
-        d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid)
+        d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid,
+                               w_wino=P['head0_ww'])
         us = autotune.tune_conv(d, dev)[2] if tune else 200.0
         L.append(_Launch('heads.0', 'conv', d, (feat, mid), reads=(feat,), writes=(mid,), us=us,
                          ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))

@@ -69,12 +69,25 @@ def pack_weight(w):
     return out
 
 
+def pack_winograd(w):
+    """OIHW 3x3 conv weight -> Winograd F(2x2,3x3) fragments (ct_conv2d algo 201 / 202)"""
+    lib = _lib.load()
+    w = w.contiguous().float()
+    Cout, Cin, ks, ks2 = w.shape
+    assert ks == 3 and ks2 == 3 and Cin % 16 == 0
+    out = torch.empty(lib.ct_packed_winograd_elems(Cout, Cin), dtype=torch.float32, device=w.device)
+    _lib.check(lib.ct_pack_winograd_weight(w.data_ptr(), out.data_ptr(), Cout, Cin, _lib.stream_ptr()),
+               'ct_pack_winograd_weight')
+    return out
+
+
 def _p(t):
     return None if t is None else t.data_ptr()
 
 
 def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, relu=False, out=None,
-                   out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0, algo=0):
+                   out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0, algo=0,
+                   w_wino=None):
     d = ConvDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
     d.w_packed, d.Cout, d.ks, d.stride = wp.data_ptr(), Cout, ks, stride
@@ -96,6 +109,8 @@ def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, 
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     d.split_k = split_k
     d.algo = algo
+    if w_wino is not None:
+        d.w_winograd = w_wino.data_ptr()
     return d
 
 

@@ -52,6 +52,10 @@ int ct_set_tuning(const char *key, int value);
  * dla.py:38-66,154-172,506-518; base_model.py:24-40).  Cin must be a multiple of 16. */
 size_t ct_packed_weight_elems(int Cout, int Cin, int ks);
 int ct_pack_conv_weight(const float *w_oihw, float *packed, int Cout, int Cin, int ks, void *stream);
+/* Winograd F(2x2,3x3) form of a 3x3 weight: U = G g G^T per (cout, cin), 16 positions in the same fragment
+ * order [pos][Cin/16][CoutPad/16][4][16][4] (used by ct_conv2d algo 201 / 202). */
+size_t ct_packed_winograd_elems(int Cout, int Cin);
+int ct_pack_winograd_weight(const float *w_oihw, float *packed, int Cout, int Cin, void *stream);
 
 /* ---- dense convolution (implicit GEMM on fp32 MFMA) -------------------------------
  * Replaces nn.Conv2d + eval-mode nn.BatchNorm2d (+ residual add) (+ ReLU) of BasicBlock /
@@ -74,8 +78,11 @@ typedef struct ct_conv_desc {
     int split_k;                                /* 0 = choose automatically */
     int algo;                                   /* 0 = heuristic; 1..6 = tile shape 0..5 of the row-tiled
                                                    kernel; 101..105 = K-split-in-workgroup shape 0..4
-                                                   (CT_ERR_ARG if the shape cannot run this layer); picked
-                                                   per layer by the host-side autotuner */
+                                                   (CT_ERR_ARG if the shape cannot run this layer); 201 / 202 =
+                                                   Winograd F(2x2,3x3) with 64 / 32 couts per workgroup (3x3
+                                                   stride 1, Cin % 64 == 0, NHWC output, needs w_winograd);
+                                                   picked per layer by the host-side autotuner */
+    const float *w_winograd;                    /* ct_pack_winograd_weight() of the same OIHW weight, or NULL */
 } ct_conv_desc;
 int ct_conv2d(const ct_conv_desc *d, void *stream);
 size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);

@@ -142,6 +142,27 @@ def test_conv2d_ksplit_kernel_matches_torch(device, case):
     _close(out.to_nchw(), y, msg='ksplit conv')
 
 
+@pytest.mark.parametrize('algo,N,H,W,Cin,Cout', [(201, 1, 16, 32, 64, 64), (202, 2, 9, 21, 64, 48), (201, 1, 8, 16, 128, 256),
+                                                 (202, 1, 5, 7, 256, 96), (201, 1, 12, 20, 64, 1280)])
+def test_conv2d_winograd_matches_torch(device, algo, N, H, W, Cin, Cout):
+    """Winograd F(2x2,3x3) conv (ct_conv2d algo 201 / 202) == torch fp32 conv + BN + residual + ReLU; ragged
+    edges, several chunks, Cout not a multiple of the tile.  Tolerance 5e-4 abs on O(1) outputs (the transforms
+    add a few ulps of rounding on top of the summation order; north_star allows 1e-3)."""
+    from centertrack_amd import ops
+    x = F.relu(_rand(N, Cin, H, W, seed=60))
+    w = _rand(Cout, Cin, 3, 3, seed=61, scale=(Cin * 9) ** -0.5)
+    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(62)) + 0.5
+    shift = _rand(Cout, seed=63)
+    res = _rand(N, Cout, H, W, seed=64)
+    y = F.relu(F.conv2d(x, w, None, padding=1) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
+    wd = w.to(device)
+    out = ops.conv2d(ops.view_from_nchw(x.to(device)), ops.pack_weight(wd), Cout, 3, 1, scale=scale.to(device),
+                     shift=shift.to(device), res=ops.view_from_nchw(res.to(device)), relu=True, split_k=1, algo=algo,
+                     w_wino=ops.pack_winograd(wd))
+    torch.cuda.synchronize()
+    _close(out.to_nchw(), y, atol=5e-4, msg='winograd conv')
+
+
 def test_conv2d_nchw_output_sigmoid_dep(device):
     from centertrack_amd import ops
     N, H, W, Cin = 2, 8, 12, 256

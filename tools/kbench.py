@@ -76,24 +76,27 @@ def main():
     variants = [('auto', {}), ('old', dict(conv_ks=-2)), ('ks0', dict(conv_ks=0)), ('ks1', dict(conv_ks=1)),
                 ('ks2', dict(conv_ks=2)), ('ks3', dict(conv_ks=3)), ('ks4', dict(conv_ks=4)),
                 ('old/cfg2', dict(conv_ks=-2, conv_cfg=2)), ('old/cfg4', dict(conv_ks=-2, conv_cfg=4)),
-                ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('old/nosplit', dict(conv_ks=-2, splitk_target=1))]
+                ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('wino64', dict(algo=201)), ('wino32', dict(algo=202))]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
     tot = {v[0]: 0.0 for v in variants}
     for name, cnt, H, Cin, Cout, ks, stride in convs:
         x = ops.new_view(N, H, H, Cin, dev)
         x.buf.normal_()
-        w = ops.pack_weight(torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05)
+        wraw = torch.randn(Cout, Cin, ks, ks, device=dev) * 0.05
+        w = ops.pack_weight(wraw)
         Ho = H // stride
         out = ops.new_view(N, Ho, Ho, Cout, dev, ld=(Cout + 3) // 4 * 4)
         gf = 2.0 * ks * ks * Cin * Cout * N * Ho * Ho / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in variants:
             tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1)
-            tune(**kw)
-            if kw.get('conv_cfg', -1) in (0, 1, 5) and Cout > 32 * 8:
+            algo = kw.get('algo', 0)
+            tune(**{k: v for k, v in kw.items() if k != 'algo'})
+            if (kw.get('conv_cfg', -1) in (0, 1, 5) and Cout > 32 * 8) or (algo and (ks != 3 or stride != 1 or Cin % 64)):
                 line += ' %12s' % '-'
                 continue
-            d = ops.make_conv_desc(x, w, Cout, ks, stride, out=out, relu=True, workspace=ws)
+            ww = ops.pack_winograd(wraw) if algo else None        # (kept alive: the descriptor only holds its address)
+            d = ops.make_conv_desc(x, w, Cout, ks, stride, out=out, relu=True, workspace=ws, algo=algo, w_wino=ww)
             try:
                 t = time_call(lambda: _lib.check(lib.ct_conv2d(ctypes.byref(d), _lib.stream_ptr())), args.reps)
                 line += ' %7.1f/%4.0f' % (t, gf / t * 1e3)      # us / TFLOP/s
