@@ -30,11 +30,15 @@ struct WinoArgs {
     EpiArgs epi;
 };
 
-constexpr int W_PH = 6, W_PW = 18, W_PP = W_PH * W_PW;       // raw patch of a 4 x 16 output block
-constexpr int W_SLAB = W_PP * 16;                           // floats per 16-channel slab
-constexpr int W_BUF = 4 * W_SLAB;                           // floats per 64-channel chunk
-constexpr int W_ITEMS = 4 * W_PP * 4;                       // float4 items per chunk
-constexpr int W_NR = (W_ITEMS + 255) / 256;
+// WM = m-tiles (blocks of 4 x 16 output pixels = 16 Winograd tiles) stacked vertically per workgroup
+template <int WM>
+struct WCfg {
+    static constexpr int PH = 4 * WM + 2, PW = 18, PP = PH * PW;   // raw patch of a (4*WM) x 16 output block
+    static constexpr int SLAB = PP * 16;                           // floats per 16-channel slab
+    static constexpr int BUF = 4 * SLAB;                           // floats per 64-channel chunk
+    static constexpr int ITEMS = 4 * PP * 4;                       // float4 items per chunk
+    static constexpr int NR = (ITEMS + 255) / 256;
+};
 
 // B^T rows as (i1, i2, s2): V = d[i1] + s2 * d[i2]   (r=0: d0-d2, r=1: d1+d2, r=2: d2-d1, r=3: d1-d3)
 __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
@@ -44,9 +48,13 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
     s2 = (r == 1) ? 1.0f : -1.0f;
 }
 
-template <int WN>
+// MULTI = more than one 64-channel chunk (the next chunk's patch is prefetched into registers during the
+// MFMAs); the single-chunk instance (Cin = 64: level 2, heads) needs ~40 VGPRs less -> one more wave per SIMD.
+template <int WM, int WN, bool MULTI>
 __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
 {
+    using C = WCfg<WM>;
+    constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS, W_NR = C::NR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lg = lane >> 4;
@@ -56,10 +64,10 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
-    const int oy0 = ty * 4, ox0 = tx * 16;
+    const int oy0 = ty * 4 * WM, ox0 = tx * 16;
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
 
-    // ---- staging of the raw patch (rows oy0-1 .. oy0+4, cols ox0-1 .. ox0+16) -------------------------
+    // ---- staging of the raw patch (rows oy0-1 .. oy0+4*WM, cols ox0-1 .. ox0+16) -------------------------
     int goff[W_NR], loff[W_NR];
 #pragma unroll
     for (int r = 0; r < W_NR; ++r) {
@@ -101,7 +109,9 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
     float rs2;
     bt_row(wave, ri1, ri2, rs2);
     const int trow = li >> 3, tcol = li & 7;
-    int pa[2][4];                                   // LDS float offsets (inside a slab) of d[i1][0..3], d[i2][0..3]
+    // LDS float offsets (inside a slab) of d[i1][0..3], d[i2][0..3] of m-tile 0; m-tile mt adds 4*mt patch
+    // rows = 72*mt pixels, an even multiple of 4 pixels, so the swizzle term ((P >> 1) & 2) is unchanged
+    int pa[2][4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int P1 = (2 * trow + ri1) * W_PW + 2 * tcol + j;
@@ -109,6 +119,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
         pa[0][j] = P1 * 16 + ((lg ^ ((P1 >> 1) & 2)) << 2);
         pa[1][j] = P2 * 16 + ((lg ^ ((P2 >> 1) & 2)) << 2);
     }
+    constexpr int MT_OFF = 4 * W_PW * 16;            // floats between the patches of consecutive m-tiles
 
     // ---- B side ----------------------------------------------------------------------------------------
     const int nt0 = cb * WN;
@@ -125,40 +136,49 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
         for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
     };
 
-    f32x4 acc[4][WN];                              // [column c of the transformed tile][n-tile]
+    f32x4 acc[WM][4][WN];                          // [m-tile][column c of the transformed tile][n-tile]
 #pragma unroll
-    for (int c = 0; c < 4; ++c)
+    for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) acc[c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        for (int c = 0; c < 4; ++c)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) acc[mt][c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int S = 16, D = 2, R = 4;            // 16 steps per chunk, B prefetched 2 steps ahead, ring of 4
+    constexpr int S = 16, D = 3, R = 4;            // 16 steps per chunk, B prefetched 3 steps ahead, ring of 4
     {
         stage_load(0);
         f32x4 breg[R][WN];
         load_b(breg[0], 0, 0);
         load_b(breg[1], 0, 1);
+        load_b(breg[2], 0, 2);
         stage_store(0);
         __syncthreads();
-        for (int ch = 0; ch < a.nchunks; ++ch) {
+        const int nchunks = MULTI ? a.nchunks : 1;
+        for (int ch = 0; ch < nchunks; ++ch) {
             const int cur = ch & 1;
-            stage_load(min(ch + 1, a.nchunks - 1));
-            __builtin_amdgcn_sched_barrier(0x386);
+            if (MULTI) {
+                stage_load(min(ch + 1, a.nchunks - 1));
+                __builtin_amdgcn_sched_barrier(0x386);
+            }
             const float *buf = lds + cur * W_BUF;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 // input transform of this slab: rows combined first, then the four column combinations
-                f32x4 e[4];
+                f32x4 v[WM][4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 d1 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + pa[0][j]);
-                    const f32x4 d2 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + pa[1][j]);
-                    e[j] = d1 + rs2 * d2;
+                for (int mt = 0; mt < WM; ++mt) {
+                    f32x4 e[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 d1 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + mt * MT_OFF + pa[0][j]);
+                        const f32x4 d2 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + mt * MT_OFF + pa[1][j]);
+                        e[j] = d1 + rs2 * d2;
+                    }
+                    v[mt][0] = e[0] - e[2];
+                    v[mt][1] = e[1] + e[2];
+                    v[mt][2] = e[2] - e[1];
+                    v[mt][3] = e[1] - e[3];
                 }
-                f32x4 v[4];
-                v[0] = e[0] - e[2];
-                v[1] = e[1] + e[2];
-                v[2] = e[2] - e[1];
-                v[3] = e[1] - e[3];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int s = kk * 4 + c;
@@ -168,35 +188,42 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
 #pragma unroll
                     for (int ee = 0; ee < 4; ++ee)
 #pragma unroll
-                        for (int nt = 0; nt < WN; ++nt)
-                            acc[c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[c][ee], breg[s % R][nt][ee], acc[c][nt], 0, 0, 0);
+                        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                            for (int nt = 0; nt < WN; ++nt)
+                                acc[mt][c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[mt][c][ee], breg[s % R][nt][ee],
+                                                                                     acc[mt][c][nt], 0, 0, 0);
                 }
             }
-            if (ch + 1 < a.nchunks) stage_store(cur ^ 1);
+            if (MULTI && ch + 1 < a.nchunks) stage_store(cur ^ 1);
             __syncthreads();
         }
     }
 
     // ---- output transform: columns in registers ... ---------------------------------------------------
     // T[q][nt]: q=0: M0+M1+M2, q=1: M1-M2-M3   (this wave's row r)
-    float *exch = lds;                              // [r 4][q 2][nt WN][lane 64] float4
+    float *exch = lds;                              // [r 4][q 2][mt WM][nt WN][lane 64] float4
+    constexpr int TN = WM * WN;
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) {
-        const f32x4 t0 = acc[0][nt] + acc[1][nt] + acc[2][nt];
-        const f32x4 t1 = acc[1][nt] - acc[2][nt] - acc[3][nt];
-        *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 0) * WN + nt) * 64 + lane) * 4) = t0;
-        *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 1) * WN + nt) * 64 + lane) * 4) = t1;
-    }
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const f32x4 t0 = acc[mt][0][nt] + acc[mt][1][nt] + acc[mt][2][nt];
+            const f32x4 t1 = acc[mt][1][nt] - acc[mt][2][nt] - acc[mt][3][nt];
+            *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 0) * TN + mt * WN + nt) * 64 + lane) * 4) = t0;
+            *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 1) * TN + mt * WN + nt) * 64 + lane) * 4) = t1;
+        }
     __syncthreads();
-    // ... rows across the waves: Y[0][q] = T0+T1+T2, Y[1][q] = T1-T2-T3; 2*WN (q, nt) pairs over 4 waves
+    // ... rows across the waves: Y[0][q] = T0+T1+T2, Y[1][q] = T1-T2-T3; 2*WM*WN (q, mt, nt) jobs over 4 waves
 #pragma unroll
-    for (int w0 = 0; w0 < 2 * WN; w0 += 4) {
+    for (int w0 = 0; w0 < 2 * TN; w0 += 4) {
         const int job = w0 + wave;
-        if (job < 2 * WN) {
-            const int q = job & 1, nt = job >> 1;
+        if (job < 2 * TN) {
+            const int q = job & 1, tn = job >> 1;
+            const int mt = tn / WN, nt = tn - mt * WN;
             f32x4 t[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = *reinterpret_cast<const f32x4 *>(exch + (((r * 2 + q) * WN + nt) * 64 + lane) * 4);
+            for (int r = 0; r < 4; ++r) t[r] = *reinterpret_cast<const f32x4 *>(exch + (((r * 2 + q) * TN + tn) * 64 + lane) * 4);
             const f32x4 y0 = t[0] + t[1] + t[2];
             const f32x4 y1 = t[1] - t[2] - t[3];
             const int co = (nt0 + nt) * 16 + li;
@@ -209,7 +236,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
                     const int ox = ox0 + 2 * (tile & 7) + q;
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
-                        const int oy = oy0 + 2 * (tile >> 3) + p;
+                        const int oy = oy0 + 4 * mt + 2 * (tile >> 3) + p;
                         if (oy < a.epi.Ho && ox < a.epi.Wo) {
                             const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
                             const float r = a.epi.res ? a.epi.res[pix * a.epi.ldr + co] : 0.0f;
@@ -245,17 +272,26 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, floa
     p[idx] = u;
 }
 
-template <int WN>
-int launch_wino(const WinoArgs &a, dim3 grid, size_t lds, hipStream_t s)
+template <int WM, int WN, bool MULTI>
+int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
-    auto k = wino_conv_kernel<WN>;
+    using C = WCfg<WM>;
+    auto k = wino_conv_kernel<WM, WN, MULTI>;
+    const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
+    const size_t exch = sizeof(float) * (size_t)(4 * 2 * WM * WN * 256);
+    const size_t lds = patch > exch ? patch : exch;
     static bool attr_set = false;
     if (!attr_set) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
     return CT_OK;
+}
+template <int WM, int WN>
+int launch_wino(const WinoArgs &a, dim3 grid, hipStream_t s)
+{
+    return a.nchunks > 1 ? launch_wino2<WM, WN, true>(a, grid, s) : launch_wino2<WM, WN, false>(a, grid, s);
 }
 
 }  // namespace
@@ -273,7 +309,7 @@ extern "C" int ct_pack_winograd_weight(const float *w_oihw, float *packed, int C
     return CT_OK;
 }
 
-// called by ct_conv2d for algo 201 (64 couts / workgroup) and 202 (32 couts / workgroup)
+// called by ct_conv2d for algo 201..204
 int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
 {
     if (d->ks != 3 || d->stride != 1) CT_FAIL_ARG("ct_conv2d: the Winograd algo is for 3x3 stride-1 convolutions");
@@ -281,22 +317,28 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     if (d->Cin % 64) CT_FAIL_ARG("ct_conv2d: the Winograd algo needs Cin %% 64 == 0 (got %d)", d->Cin);
     if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_conv2d: the Winograd algo writes NHWC only");
     if (d->sig_hi > d->sig_lo || d->dep_hi > d->dep_lo) CT_FAIL_ARG("ct_conv2d: the Winograd algo has no sigmoid epilogue");
-    const int WN = (d->algo == 201) ? 4 : 2;
+    // algo 201: 64 px x 64 couts, 202: 64 px x 32 couts, 203: 128 px x 32 couts, 204: 128 px x 16 couts per workgroup
+    const int WM = (d->algo >= 203) ? 2 : 1;
+    const int WN = (d->algo == 201) ? 4 : ((d->algo == 204) ? 1 : 2);
     WinoArgs a;
     a.x = d->x; a.up = d->w_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN);
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN);
     a.NT = ct_cdiv(d->Cout, 16); a.nchunks = d->Cin / 64;
     a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = d->res; a.epi.y = d->y;
     a.epi.ldr = d->ldr; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;
     a.epi.flags = d->flags; a.epi.sig_lo = a.epi.sig_hi = 0; a.epi.dep_lo = a.epi.dep_hi = 0; a.epi.depth_scale = 1.0f;
     const long blocks = (long)d->N * a.tilesX * a.tilesY * a.coutBlocks;
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_conv2d: grid too large");
-    const size_t patch = sizeof(float) * (size_t)W_BUF * (a.nchunks > 1 ? 2 : 1);
-    const size_t exch = sizeof(float) * (size_t)(4 * 2 * WN * 256);
-    const size_t lds = patch > exch ? patch : exch;
-    int rc = (WN == 4) ? launch_wino<4>(a, dim3((unsigned)blocks), lds, (hipStream_t)stream)
-                       : launch_wino<2>(a, dim3((unsigned)blocks), lds, (hipStream_t)stream);
+    const dim3 grid((unsigned)blocks);
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    switch (d->algo) {
+    case 201: rc = launch_wino<1, 4>(a, grid, st); break;
+    case 202: rc = launch_wino<1, 2>(a, grid, st); break;
+    case 203: rc = launch_wino<2, 2>(a, grid, st); break;
+    default: rc = launch_wino<2, 1>(a, grid, st); break;
+    }
     CT_CHECK_LAUNCH("ct_conv2d(winograd)");
     return rc;
 }
