@@ -121,7 +121,7 @@ def _conv_candidates(d):
             continue
         cands.append((101 + i, 1))
     if d.w_winograd and d.ks == 3 and d.stride == 1 and d.Cin % 64 == 0 and not (d.flags & _lib.CT_OUT_NCHW):
-        for algo in (201, 202, 203, 204):         # Winograd F(2x2,3x3): 64x64, 64x32, 128x32, 128x16 (px x couts)
+        for algo in (201, 202, 203, 204, 205, 206, 207):   # Winograd F(2x2,3x3) tile / K-split shapes (centertrack_hip.h)
             cands.append((algo, 1))
     return cands
 

@@ -526,7 +526,7 @@ extern "C" int ct_pack_conv_weight(const float *w_oihw, float *packed, int Cout,
 
 extern "C" size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d)
 {
-    if (d && d->algo >= 201 && d->algo <= 204) return 0;
+    if (d && d->algo >= 201 && d->algo <= 207) return 0;
     Plan p;
     ct_conv_desc t = *d;
     float dummy;
@@ -540,7 +540,7 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream);       // wino_mfma.
 
 extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
 {
-    if (d && d->algo >= 201 && d->algo <= 204) {
+    if (d && d->algo >= 201 && d->algo <= 207) {
         if (!d->x || !d->y) CT_FAIL_ARG("ct_conv2d: null pointer");
         if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_conv2d: input view must be 16-byte aligned (ld %% 4 == 0)");
         return ct_conv2d_winograd(d, stream);

@@ -50,13 +50,18 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 
 // MULTI = more than one 64-channel chunk (the next chunk's patch is prefetched into registers during the
 // MFMAs); the single-chunk instance (Cin = 64: level 2, heads) needs ~40 VGPRs less -> one more wave per SIMD.
-template <int WM, int WN, bool MULTI>
-__global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
+// KS = K-split inside the workgroup for the deep levels (32x32 / 16x16 maps have too few pixel tiles to fill
+// the chip): 4*KS waves, wave (r, kp) contracts slabs kp*4/KS .. of every chunk for row r; the KS partial
+// results are summed (in kp order) by the output transform.
+template <int WM, int WN, int KS, bool MULTI>
+__global__ __launch_bounds__(256 * KS) void wino_conv_kernel(WinoArgs a)
 {
     using C = WCfg<WM>;
-    constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS, W_NR = C::NR;
+    constexpr int NTHR = 256 * KS;
+    constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS;
+    constexpr int W_NR = (W_ITEMS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kp = tid >> 8;
     const int li = lane & 15, lg = lane >> 4;
 
     int bid = blockIdx.x;
@@ -71,7 +76,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
     int goff[W_NR], loff[W_NR];
 #pragma unroll
     for (int r = 0; r < W_NR; ++r) {
-        const int it = tid + 256 * r;
+        const int it = tid + NTHR * r;
         if (it < W_ITEMS) {
             const int q = it & 3;
             const int pp = it >> 2;
@@ -128,9 +133,10 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.up + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
     const size_t slab_stride = (size_t)a.NT << 8;
-    // step s of a chunk = (slab s>>2, column c = s&3); position = wave*4 + c
+    // step s of a chunk (for this wave) = (slab kp*SPK + (s>>2), column c = s&3); position = wave*4 + c
+    constexpr int SPK = 4 / KS;                     // slabs of a chunk per K part
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int s) {
-        const int c = s & 3, kk = s >> 2;
+        const int c = s & 3, kk = kp * SPK + (s >> 2);
         const size_t slab = (size_t)(wave * 4 + c) * NCH16 + (size_t)min(chunk, a.nchunks - 1) * 4 + kk;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
@@ -144,13 +150,12 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) acc[mt][c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int S = 16, D = 3, R = 4;            // 16 steps per chunk, B prefetched 3 steps ahead, ring of 4
+    constexpr int S = 16 / KS, D = 3, R = 4;       // steps per chunk and wave, B prefetched 3 steps ahead, ring of 4
     {
         stage_load(0);
         f32x4 breg[R][WN];
-        load_b(breg[0], 0, 0);
-        load_b(breg[1], 0, 1);
-        load_b(breg[2], 0, 2);
+#pragma unroll
+        for (int p = 0; p < D; ++p) load_b(breg[p], p / S, p % S);
         stage_store(0);
         __syncthreads();
         const int nchunks = MULTI ? a.nchunks : 1;
@@ -162,7 +167,8 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
             }
             const float *buf = lds + cur * W_BUF;
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int ks = 0; ks < SPK; ++ks) {
+                const int kk = kp * SPK + ks;
                 // input transform of this slab: rows combined first, then the four column combinations
                 f32x4 v[WM][4];
 #pragma unroll
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
                 }
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const int s = kk * 4 + c;
+                    const int s = ks * 4 + c;
                     const int sp = s + D;
                     load_b(breg[(s + D) % R], ch + sp / S, sp % S);
                     __builtin_amdgcn_sched_barrier(0x386);
@@ -202,28 +208,34 @@ __global__ __launch_bounds__(256) void wino_conv_kernel(WinoArgs a)
 
     // ---- output transform: columns in registers ... ---------------------------------------------------
     // T[q][nt]: q=0: M0+M1+M2, q=1: M1-M2-M3   (this wave's row r)
-    float *exch = lds;                              // [r 4][q 2][mt WM][nt WN][lane 64] float4
+    float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
     constexpr int TN = WM * WN;
+    const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) {
             const f32x4 t0 = acc[mt][0][nt] + acc[mt][1][nt] + acc[mt][2][nt];
             const f32x4 t1 = acc[mt][1][nt] - acc[mt][2][nt] - acc[mt][3][nt];
-            *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 0) * TN + mt * WN + nt) * 64 + lane) * 4) = t0;
-            *reinterpret_cast<f32x4 *>(exch + (((wave * 2 + 1) * TN + mt * WN + nt) * 64 + lane) * 4) = t1;
+            *reinterpret_cast<f32x4 *>(exch + (((wr * 2 + 0) * TN + mt * WN + nt) * 64 + lane) * 4) = t0;
+            *reinterpret_cast<f32x4 *>(exch + (((wr * 2 + 1) * TN + mt * WN + nt) * 64 + lane) * 4) = t1;
         }
     __syncthreads();
     // ... rows across the waves: Y[0][q] = T0+T1+T2, Y[1][q] = T1-T2-T3; 2*WM*WN (q, mt, nt) jobs over 4 waves
 #pragma unroll
-    for (int w0 = 0; w0 < 2 * TN; w0 += 4) {
-        const int job = w0 + wave;
+    for (int w0 = 0; w0 < 2 * TN; w0 += 4 * KS) {
+        const int job = w0 + (tid >> 6);
         if (job < 2 * TN) {
             const int q = job & 1, tn = job >> 1;
             const int mt = tn / WN, nt = tn - mt * WN;
             f32x4 t[4];
 #pragma unroll
-            for (int r = 0; r < 4; ++r) t[r] = *reinterpret_cast<const f32x4 *>(exch + (((r * 2 + q) * TN + tn) * 64 + lane) * 4);
+            for (int r = 0; r < 4; ++r) {
+                t[r] = *reinterpret_cast<const f32x4 *>(exch + (((r * 2 + q) * TN + tn) * 64 + lane) * 4);
+#pragma unroll
+                for (int k = 1; k < KS; ++k)        // K parts, in order
+                    t[r] += *reinterpret_cast<const f32x4 *>(exch + ((((k * 4 + r) * 2 + q) * TN + tn) * 64 + lane) * 4);
+            }
             const f32x4 y0 = t[0] + t[1] + t[2];
             const f32x4 y1 = t[1] - t[2] - t[3];
             const int co = (nt0 + nt) * 16 + li;
@@ -272,26 +284,27 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, floa
     p[idx] = u;
 }
 
-template <int WM, int WN, bool MULTI>
+template <int WM, int WN, int KS, bool MULTI>
 int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
     using C = WCfg<WM>;
-    auto k = wino_conv_kernel<WM, WN, MULTI>;
+    auto k = wino_conv_kernel<WM, WN, KS, MULTI>;
     const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
-    const size_t exch = sizeof(float) * (size_t)(4 * 2 * WM * WN * 256);
+    const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256);
     const size_t lds = patch > exch ? patch : exch;
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
+    hipLaunchKernelGGL(k, grid, dim3(256 * KS), lds, s, a);
     return CT_OK;
 }
-template <int WM, int WN>
+template <int WM, int WN, int KS>
 int launch_wino(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
-    return a.nchunks > 1 ? launch_wino2<WM, WN, true>(a, grid, s) : launch_wino2<WM, WN, false>(a, grid, s);
+    if (KS > 1) return launch_wino2<WM, WN, KS, true>(a, grid, s);      // (K-split instances are for the deep levels)
+    return a.nchunks > 1 ? launch_wino2<WM, WN, KS, true>(a, grid, s) : launch_wino2<WM, WN, KS, false>(a, grid, s);
 }
 
 }  // namespace
@@ -309,7 +322,7 @@ extern "C" int ct_pack_winograd_weight(const float *w_oihw, float *packed, int C
     return CT_OK;
 }
 
-// called by ct_conv2d for algo 201..204
+// called by ct_conv2d for algo 201..207
 int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
 {
     if (d->ks != 3 || d->stride != 1) CT_FAIL_ARG("ct_conv2d: the Winograd algo is for 3x3 stride-1 convolutions");
@@ -317,9 +330,10 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     if (d->Cin % 64) CT_FAIL_ARG("ct_conv2d: the Winograd algo needs Cin %% 64 == 0 (got %d)", d->Cin);
     if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_conv2d: the Winograd algo writes NHWC only");
     if (d->sig_hi > d->sig_lo || d->dep_hi > d->dep_lo) CT_FAIL_ARG("ct_conv2d: the Winograd algo has no sigmoid epilogue");
-    // algo 201: 64 px x 64 couts, 202: 64 px x 32 couts, 203: 128 px x 32 couts, 204: 128 px x 16 couts per workgroup
-    const int WM = (d->algo >= 203) ? 2 : 1;
-    const int WN = (d->algo == 201) ? 4 : ((d->algo == 204) ? 1 : 2);
+    // algo 201: 64 px x 64 couts, 202: 64 x 32, 203: 128 x 32, 204: 128 x 16 per workgroup of 4 waves;
+    // 205 / 206: 64 x 32 with K split over 2 / 4 wave groups (8 / 16 waves), 207: 64 x 16 with K split 4
+    const int WM = (d->algo == 203 || d->algo == 204) ? 2 : 1;
+    const int WN = (d->algo == 201) ? 4 : ((d->algo == 204 || d->algo == 207) ? 1 : 2);
     WinoArgs a;
     a.x = d->x; a.up = d->w_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
@@ -334,10 +348,13 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     hipStream_t st = (hipStream_t)stream;
     int rc;
     switch (d->algo) {
-    case 201: rc = launch_wino<1, 4>(a, grid, st); break;
-    case 202: rc = launch_wino<1, 2>(a, grid, st); break;
-    case 203: rc = launch_wino<2, 2>(a, grid, st); break;
-    default: rc = launch_wino<2, 1>(a, grid, st); break;
+    case 201: rc = launch_wino<1, 4, 1>(a, grid, st); break;
+    case 202: rc = launch_wino<1, 2, 1>(a, grid, st); break;
+    case 203: rc = launch_wino<2, 2, 1>(a, grid, st); break;
+    case 204: rc = launch_wino<2, 1, 1>(a, grid, st); break;
+    case 205: rc = launch_wino<1, 2, 2>(a, grid, st); break;
+    case 206: rc = launch_wino<1, 2, 4>(a, grid, st); break;
+    default: rc = launch_wino<1, 1, 4>(a, grid, st); break;
     }
     CT_CHECK_LAUNCH("ct_conv2d(winograd)");
     return rc;

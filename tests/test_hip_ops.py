@@ -144,7 +144,9 @@ def test_conv2d_ksplit_kernel_matches_torch(device, case):
 
 @pytest.mark.parametrize('algo,N,H,W,Cin,Cout', [(201, 1, 16, 32, 64, 64), (202, 2, 9, 21, 64, 48), (201, 1, 8, 16, 128, 256),
                                                  (202, 1, 5, 7, 256, 96), (201, 1, 12, 20, 64, 1280), (203, 2, 13, 21, 64, 80),
-                                                 (203, 1, 8, 16, 128, 64), (204, 1, 10, 18, 192, 40), (204, 1, 16, 16, 64, 27)])
+                                                 (203, 1, 8, 16, 128, 64), (204, 1, 10, 18, 192, 40), (204, 1, 16, 16, 64, 27),
+                                                 (205, 1, 9, 17, 128, 96), (206, 1, 8, 8, 256, 64), (207, 2, 4, 4, 512, 48),
+                                                 (206, 1, 8, 16, 64, 32)])
 def test_conv2d_winograd_matches_torch(device, algo, N, H, W, Cin, Cout):
     """Winograd F(2x2,3x3) conv (ct_conv2d algo 201 / 202) == torch fp32 conv + BN + residual + ReLU; ragged
     edges, several chunks, Cout not a multiple of the tile.  Tolerance 5e-4 abs on O(1) outputs (the transforms

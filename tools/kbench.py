@@ -76,8 +76,8 @@ def main():
     variants = [('auto', {}), ('old', dict(conv_ks=-2)), ('ks0', dict(conv_ks=0)), ('ks1', dict(conv_ks=1)),
                 ('ks2', dict(conv_ks=2)), ('ks3', dict(conv_ks=3)), ('ks4', dict(conv_ks=4)),
                 ('old/cfg2', dict(conv_ks=-2, conv_cfg=2)), ('old/cfg4', dict(conv_ks=-2, conv_cfg=4)),
-                ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('w64x64', dict(algo=201)), ('w64x32', dict(algo=202)), ('w128x32', dict(algo=203)),
-                ('w128x16', dict(algo=204))]
+                ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('w64x32', dict(algo=202)), ('w32/k2', dict(algo=205)), ('w32/k4', dict(algo=206)),
+                ('w16/k4', dict(algo=207))]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
     tot = {v[0]: 0.0 for v in variants}
     for name, cnt, H, Cin, Cout, ks, stride in convs:
