@@ -80,7 +80,8 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_render_pre_hm',
            'ct_tracker_create', 'ct_tracker_destroy', 'ct_tracker_reset', 'ct_tracker_num_tracks',
-           'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params']
+           'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params',
+           'ct_preprocess_image']
 
 _lib = None
 
@@ -136,6 +137,7 @@ def load():
     lib.ct_tracker_get_tracks.argtypes = [p, p, i]
     lib.ct_tracker_step.argtypes = [p, p, i, i, ctypes.POINTER(RowLayout), ctypes.c_float, p, p, i]
     lib.ct_tracker_prehm_params.argtypes = [p, ctypes.c_float, p, i, i, p, i]
+    lib.ct_preprocess_image.argtypes = [p, i, i, i, i, p, i, i, p, p, p, i]
     _lib = lib
     return lib
 

@@ -338,11 +338,38 @@ class Detector(object):
         return self.impl.fast[0] if self.impl.native else self.impl.trackers[0]
 
     def pre_process(self, image, scale, input_meta={}):
-        """detector.py:207-239.  The cv2 resize/warpAffine of a raw BGR frame is the step
-        *before* the hot path and is not re-implemented yet: hand over
-        the normalised tensor (as test.py's PrefetchDataset does) or a pre-processed dict."""
-        raise NotImplementedError('raw-image pre-processing (cv2 warpAffine) is outside the hot path; '
-                                  'pass a pre-processed dict or (tensor, meta)')
+        """detector.py:207-239: crop / scale the original u8 HWC frame to the network input
+        (``cv2.warpAffine(image, trans_input, (inp_w, inp_h), INTER_LINEAR)``), normalise, HWC -> CHW,
+        optional flipped copy, and the ``meta`` dict.  Host code like the reference's (test.py runs it in
+        DataLoader worker processes): ``ct_preprocess_image`` restates OpenCV's fixed-point warp (cv2 is not
+        needed).  As in the reference, ``scale`` is accepted and ignored (``_transform_scale(image)`` is
+        called with its default, detector.py:212-213)."""
+        import ctypes
+        opt = self.opt
+        image = np.ascontiguousarray(image)
+        if image.dtype != np.uint8 or image.ndim != 3:
+            raise _lib.CTError('pre_process expects a uint8 HxWxC image (got %s %s)' % (image.dtype, image.shape))
+        height, width, ch = image.shape
+        meta = make_meta(getattr(opt, 'input_h', -1), getattr(opt, 'input_w', -1), height, width,
+                         down_ratio=getattr(opt, 'down_ratio', 4), calib=input_meta.get('calib'),
+                         focal_length=self.rest_focal_length, fix_res=bool(getattr(opt, 'fix_res', True)),
+                         fix_short=getattr(opt, 'fix_short', 0), pad=getattr(opt, 'pad', 31))
+        inp_h, inp_w = meta['inp_height'], meta['inp_width']
+        flip = bool(getattr(opt, 'flip_test', False))
+        out = np.empty((2 if flip else 1, ch, inp_h, inp_w), np.float32)
+        trans = np.ascontiguousarray(meta['trans_input'], np.float64)
+        mean = np.ascontiguousarray(self.mean.reshape(-1)[:ch], np.float32)
+        std = np.ascontiguousarray(self.std.reshape(-1)[:ch], np.float32)
+        _lib.check(_lib.load().ct_preprocess_image(
+            image.ctypes.data_as(ctypes.c_void_p), height, width, image.strides[0], ch,
+            trans.ctypes.data_as(ctypes.c_void_p), inp_w, inp_h, mean.ctypes.data_as(ctypes.c_void_p),
+            std.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), 1 if flip else 0),
+            'ct_preprocess_image')
+        if 'pre_dets' in input_meta:
+            meta['pre_dets'] = input_meta['pre_dets']
+        if 'cur_dets' in input_meta:
+            meta['cur_dets'] = input_meta['cur_dets']
+        return torch.from_numpy(out), meta
 
     def run(self, image_or_path_or_tensor, meta={}):
         start = time.time()
@@ -357,8 +384,11 @@ class Detector(object):
             meta = m
         elif torch.is_tensor(x):
             images = x
+        elif isinstance(x, np.ndarray):                        # raw BGR frame (demo.py / README embedding)
+            images, meta = self.pre_process(x, 1.0, meta)
         else:
-            return self.pre_process(x, 1.0, meta)
+            raise _lib.CTError('run() takes a uint8 image array, a normalised tensor + meta, or a pre-processed '
+                               'dict; reading image files (cv2.imread) is left to the caller')
         if images.shape[0] == 2 and self.impl.flip:
             images = images[0:1]                               # the flipped copy is rebuilt on device
         loaded = time.time()
@@ -383,7 +413,8 @@ def default_opt(heads, **kw):
         tracking=True, pre_img=True, pre_hm=True, zero_pre_hm=False, flip_test=False, K=100,
         track_thresh=0.3, out_thresh=-1.0, pre_thresh=-1.0, new_thresh=0.3, max_age=-1, hungarian=False,
         public_det=False, zero_tracking=False, depth_scale=1.0, down_ratio=4, num_classes=heads['hm'],
-        test_scales=[1.0], model_output_list=False, no_pause=True, dataset='', test_focal_length=-1)
+        test_scales=[1.0], model_output_list=False, no_pause=True, dataset='', test_focal_length=-1,
+        input_h=512, input_w=512, fix_res=True, fix_short=0, pad=31)
     for k, v in kw.items():
         setattr(o, k, v)
     if o.tracking:

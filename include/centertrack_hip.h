@@ -208,6 +208,13 @@ int ct_tracker_step(void *tracker, const float *rows, int K, int F, const ct_row
 int ct_tracker_prehm_params(void *tracker, float pre_thresh, const double *trans_input, int inp_w, int inp_h,
                             int *params, int cap);
 
+/* ---- image pre-processing (CPU, like the reference's: it runs in DataLoader worker processes) -----
+ * Replaces the cv2.warpAffine + normalise + HWC->CHW (+ flipped copy) of Detector.pre_process
+ * (src/lib/detector.py:207-239).  img: HOST u8 [h, w, channels] (row pitch `stride` bytes); trans: float64
+ * [2,3] trans_input; out: HOST fp32 [channels (*2 if flip_copy), dst_h, dst_w]. */
+int ct_preprocess_image(const uint8_t *img, int h, int w, int stride, int channels, const double *trans,
+                        int dst_w, int dst_h, const float *mean, const float *stdv, float *out, int flip_copy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -111,3 +111,59 @@ def draw_umich_gaussian(heatmap, center, radius, k=1):
     if min(masked_gaussian.shape) > 0 and min(masked_heatmap.shape) > 0:
         np.maximum(masked_heatmap, masked_gaussian * k, out=masked_heatmap)
     return heatmap
+
+
+def warp_affine_u8(img, trans, dst_w, dst_h):
+    """cv2.warpAffine(img, trans, (dst_w, dst_h), flags=INTER_LINEAR) for uint8 HxWxC images with the
+    default constant border 0, restated from OpenCV's published fixed-point algorithm
+    (modules/imgproc/src/imgwarp.cpp: WarpAffineInvoker + remapBilinear): inverse map in 10-bit fixed point,
+    1/32-pixel coordinates, 15-bit integer tap weights, round-to-nearest.  cv2 itself is not installed here:
+    PARITY UNPINNED (this vectorised numpy form is the independent checker of csrc/host_preprocess.cpp).
+    Reference call site: src/lib/detector.py:218-220."""
+    img = np.asarray(img)
+    h, w = img.shape[:2]
+    M = np.array(trans, np.float64).reshape(2, 3).copy()
+    D = M[0, 0] * M[1, 1] - M[0, 1] * M[1, 0]
+    D = 1.0 / D if D != 0 else 0.0
+    A11, A22 = M[1, 1] * D, M[0, 0] * D
+    M[0, 0] = A11; M[0, 1] *= -D
+    M[1, 0] *= -D; M[1, 1] = A22
+    b1 = -M[0, 0] * M[0, 2] - M[0, 1] * M[1, 2]
+    b2 = -M[1, 0] * M[0, 2] - M[1, 1] * M[1, 2]
+    M[0, 2], M[1, 2] = b1, b2
+    AB = 1024
+    xs = np.arange(dst_w, dtype=np.float64)
+    ys = np.arange(dst_h, dtype=np.float64)
+    adelta = np.rint(M[0, 0] * xs * AB).astype(np.int64)
+    bdelta = np.rint(M[1, 0] * xs * AB).astype(np.int64)
+    X0 = np.rint((M[0, 1] * ys + M[0, 2]) * AB).astype(np.int64) + 16
+    Y0 = np.rint((M[1, 1] * ys + M[1, 2]) * AB).astype(np.int64) + 16
+    X = (X0[:, None] + adelta[None, :]) >> 5
+    Y = (Y0[:, None] + bdelta[None, :]) >> 5
+    sx, sy = np.clip(X >> 5, -32768, 32767), np.clip(Y >> 5, -32768, 32767)
+    fx, fy = X & 31, Y & 31
+    pad = np.zeros((h + 2, w + 2) + img.shape[2:], np.int64)          # zero border of one pixel
+    pad[1:-1, 1:-1] = img
+
+    def tap(yy, xx):
+        ok = (yy >= -1) & (yy <= h) & (xx >= -1) & (xx <= w)
+        v = pad[np.clip(yy + 1, 0, h + 1), np.clip(xx + 1, 0, w + 1)]
+        return v * ok[..., None] if img.ndim == 3 else v * ok
+    w00 = ((32 - fx) * (32 - fy) * 32)
+    w01 = (fx * (32 - fy) * 32)
+    w10 = ((32 - fx) * fy * 32)
+    w11 = (fx * fy * 32)
+    if img.ndim == 3:
+        w00, w01, w10, w11 = w00[..., None], w01[..., None], w10[..., None], w11[..., None]
+    acc = tap(sy, sx) * w00 + tap(sy, sx + 1) * w01 + tap(sy + 1, sx) * w10 + tap(sy + 1, sx + 1) * w11
+    return np.clip((acc + (1 << 14)) >> 15, 0, 255).astype(np.uint8)
+
+
+def pre_process_image(image, trans_input, inp_w, inp_h, mean, std, flip_test=False):
+    """detector.py:218-226: warp, ((x/255 - mean)/std).astype(float32), HWC -> CHW, optional flipped copy."""
+    inp = warp_affine_u8(image, trans_input, inp_w, inp_h)
+    inp = ((inp / 255. - mean) / std).astype(np.float32)
+    images = inp.transpose(2, 0, 1).reshape(1, 3, inp_h, inp_w)
+    if flip_test:
+        images = np.concatenate((images, images[:, :, :, ::-1]), axis=0)
+    return images

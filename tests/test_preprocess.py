@@ -1,0 +1,86 @@
+"""Host pre-processing (Detector.pre_process, src/lib/detector.py:207-239): the C++ restatement of
+cv2.warpAffine + normalisation behind ct_preprocess_image against the independent numpy restatement in
+oracle/image.py, plus known-answer cases.  cv2 is not installed: parity with cv2 itself is unpinned."""
+import ctypes
+import types
+
+import numpy as np
+import pytest
+
+from centertrack_amd import _lib
+from centertrack_amd.detector import MEAN, STD
+from centertrack_amd.image import get_affine_transform, make_meta
+from oracle import image as oimage
+
+
+def _run(img, trans, dw, dh, flip=False):
+    lib = _lib.load()
+    img = np.ascontiguousarray(img)
+    ch = img.shape[2]
+    out = np.empty((2 if flip else 1, ch, dh, dw), np.float32)
+    trans = np.ascontiguousarray(trans, np.float64)
+    mean, std = np.ascontiguousarray(MEAN.reshape(-1)), np.ascontiguousarray(STD.reshape(-1))
+    rc = lib.ct_preprocess_image(img.ctypes.data_as(ctypes.c_void_p), img.shape[0], img.shape[1], img.strides[0], ch,
+                                 trans.ctypes.data_as(ctypes.c_void_p), dw, dh, mean.ctypes.data_as(ctypes.c_void_p),
+                                 std.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), int(flip))
+    assert rc == 0, lib.ct_last_error()
+    return out
+
+
+def _norm(u8):
+    return ((u8 / 255. - MEAN) / STD).astype(np.float32).transpose(2, 0, 1)[None]
+
+
+def test_identity_and_integer_shift_are_exact():
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    ident = np.array([[1, 0, 0], [0, 1, 0]], np.float64)
+    np.testing.assert_array_equal(_run(img, ident, 53, 37), _norm(img))
+    shift = np.array([[1, 0, 5], [0, 1, -3]], np.float64)          # dst(x, y) = src(x - 5, y + 3), zero outside
+    want = np.zeros_like(img)
+    want[:37 - 3, 5:] = img[3:, :53 - 5]
+    np.testing.assert_array_equal(_run(img, shift, 53, 37), _norm(want))
+
+
+def test_half_pixel_blend_rounds_to_nearest():
+    img = np.zeros((4, 6, 3), np.uint8)
+    img[:, ::2] = 10
+    img[:, 1::2] = 13
+    half = np.array([[1, 0, 0.5], [0, 1, 0]], np.float64)          # samples at x - 0.5: (a + b) / 2 -> 11.5 -> 12
+    got = _run(img, half, 6, 4)
+    want = np.full((4, 6, 3), 12, np.uint8)
+    want[:, 0] = 5                                                   # half of pixel 0 + half of the zero border
+    np.testing.assert_array_equal(got, _norm(want))
+
+
+@pytest.mark.parametrize('h,w,inp_h,inp_w,flip', [(360, 480, 128, 160, False), (375, 1242, 96, 320, True),
+                                                   (120, 90, 64, 64, False), (33, 47, 64, 96, True)])
+def test_reference_crop_matches_numpy_restatement(h, w, inp_h, inp_w, flip):
+    rs = np.random.RandomState(h + w)
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    meta = make_meta(inp_h, inp_w, h, w)
+    got = _run(img, meta['trans_input'], inp_w, inp_h, flip)
+    want = oimage.pre_process_image(img, meta['trans_input'], inp_w, inp_h, MEAN, STD, flip)
+    np.testing.assert_array_equal(got, want)
+    # rotated / sheared maps exercise negative coordinates and all four border cases
+    t = get_affine_transform(np.array([w / 2., h / 2.], np.float32), max(h, w) * 0.7, 25, [inp_w, inp_h])
+    np.testing.assert_array_equal(_run(img, t, inp_w, inp_h), oimage.pre_process_image(img, t, inp_w, inp_h, MEAN, STD))
+
+
+def test_detector_pre_process_returns_the_reference_contract():
+    """Detector.pre_process -> (images [1|2,3,H,W] float32 tensor, meta with the reference's keys); the class is
+    not instantiated (that needs a GPU): the method only reads opt / mean / std."""
+    import torch
+    from centertrack_amd.detector import Detector
+    fake = types.SimpleNamespace(opt=types.SimpleNamespace(input_h=128, input_w=160, down_ratio=4, fix_res=True,
+                                                           fix_short=0, pad=31, flip_test=True),
+                                 mean=MEAN, std=STD, rest_focal_length=1200)
+    img = np.random.RandomState(3).randint(0, 256, (360, 480, 3)).astype(np.uint8)
+    images, meta = Detector.pre_process(fake, img, 1.0, {'pre_dets': []})
+    assert isinstance(images, torch.Tensor) and images.dtype == torch.float32 and tuple(images.shape) == (2, 3, 128, 160)
+    assert torch.equal(images[1], torch.flip(images[0], [2]))
+    for k in ('calib', 'c', 's', 'height', 'width', 'out_height', 'out_width', 'inp_height', 'inp_width', 'trans_input',
+              'trans_output', 'pre_dets'):
+        assert k in meta
+    want = oimage.pre_process_image(img, meta['trans_input'], 160, 128, MEAN, STD, True)
+    np.testing.assert_array_equal(images.numpy(), want)
