@@ -109,3 +109,32 @@ def test_flip_test_runs_and_matches_oracle(device):
         np.testing.assert_array_equal(gd['xs'][0, :n], od['xs'][0, :n])
         np.testing.assert_array_equal(gd['clses'][0, :n], od['clses'][0, :n])
         assert [int(r['tracking_id']) for r in ret['results']] == [int(r['tracking_id']) for r in want]
+
+
+def test_run_on_raw_uint8_frames(device):
+    """Detector.run(ndarray) = pre_process (host) + the hot path: same tracks as the oracle fed with the
+    oracle's own restatement of the pre-processing."""
+    from centertrack_amd import scenarios as S
+    from centertrack_amd.detector import MEAN, STD, Detector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    from oracle import detector as odet, image as oimage
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
+                      input_h=cfg['H'], input_w=cfg['W'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    det = Detector(opt, model=model)
+    oracle = odet.Detector(odet.default_opt(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
+                                            input_h=cfg['H'], input_w=cfg['W']), sd, cfg['heads'])
+    rs = np.random.RandomState(5)
+    base = rs.randint(0, 256, (cfg['orig_h'], cfg['orig_w'] + 24, 3)).astype(np.uint8)
+    for t in range(3):
+        frame = np.ascontiguousarray(base[:, 8 * t:8 * t + cfg['orig_w']])
+        ret = det.run(frame)
+        images, meta = det.pre_process(frame, 1.0)
+        want_img = oimage.pre_process_image(frame, meta['trans_input'], cfg['W'], cfg['H'], MEAN, STD)
+        np.testing.assert_array_equal(images.numpy(), want_img)
+        want = oracle.run(torch.from_numpy(want_img), dict(meta))
+        assert len(want) > 0
+        _check_frame(ret['results'], want, t, 'raw frames')
