@@ -37,3 +37,4 @@ extern "C" int ct_set_tuning(const char *key, int value)
     ct_set_error("ct_set_tuning: unknown key '%s'", key ? key : "(null)");
     return CT_ERR_ARG;
 }
+

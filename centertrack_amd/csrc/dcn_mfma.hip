@@ -82,6 +82,21 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
     const float *omn = FUSE ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
 
+    if (FUSE) {
+        // ---- offset / mask conv of this tile (all input channels, whatever K range this split owns) ----
+        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a,
+                                        [&](int mt, int nt, f32x4 sum) {
+                                            const int co = nt * 16 + (lane & 15);
+                                            const float b = (co < 27) ? a.b_off[co] : 0.0f;
+#pragma unroll
+                                            for (int e = 0; e < 4; ++e) {
+                                                float v = sum[e] + b;
+                                                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
+                                                om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
+                                            }
+                                        });
+        __syncthreads();
+    }
     // ---- B fragment addressing (set up first so that the weights of step 0 are in flight while
     //      the sampling table is built) --------------------------------------------------------
     const int li = lane & 15, lg = lane >> 4;
@@ -101,21 +116,6 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
                 b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
         }
     };
-    if (FUSE) {
-        // ---- offset / mask conv of this tile (all input channels, whatever K range this split owns) ----
-        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a,
-                                        [&](int mt, int nt, f32x4 sum) {
-                                            const int co = nt * 16 + li;
-                                            const float b = (co < 27) ? a.b_off[co] : 0.0f;
-#pragma unroll
-                                            for (int e = 0; e < 4; ++e) {
-                                                float v = sum[e] + b;
-                                                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
-                                                om_lds[(mt * 16 + lg * 4 + e) * 32 + co] = v;
-                                            }
-                                        });
-        __syncthreads();
-    }
     f32x4 bq[2][NKK][WN];
     load_b(bq[0], min(c_begin, a.nchunks - 1), 0);
 

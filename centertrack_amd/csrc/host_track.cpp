@@ -16,6 +16,8 @@
 
 #include <vector>
 
+#include <xmmintrin.h>
+
 #include "centertrack_hip.h"
 
 void ct_set_error(const char *fmt, ...);
@@ -31,6 +33,10 @@ struct Tracker {
     int max_age;
     int id_count;
     std::vector<ct_track> tracks;
+    // per-step scratch (kept to avoid heap traffic on the frame loop)
+    std::vector<ct_track> scratch_dets, scratch_ret;
+    std::vector<float> scratch_t;
+    std::vector<int> scratch_dm, scratch_tm;
 };
 
 inline void xform(const float *m, float x, float y, float *ox, float *oy)
@@ -104,7 +110,8 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
         return -1;
     }
     // ---- post-process: stop at the first score < out_thresh, keep score > out_thresh ----
-    std::vector<ct_track> dets;
+    std::vector<ct_track> &dets = tr->scratch_dets;
+    dets.clear();
     dets.reserve(K);
     for (int j = 0; j < K; ++j) {
         const float *r = rows + (size_t)j * F;
@@ -133,34 +140,59 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
     }
     const int N = (int)dets.size(), M = (int)tr->tracks.size();
     // ---- association (tracker.py:28-57, 129-138) ----
-    std::vector<double> dist((size_t)N * (M > 0 ? M : 1));
-    std::vector<float> tsize(M), isize(N);
-    for (int m = 0; m < M; ++m) tsize[m] = area(tr->tracks[m].bbox);
-    for (int i = 0; i < N; ++i) {
-        isize[i] = area(dets[i].bbox);
-        const float px = dets[i].ct[0] + dets[i].tracking[0], py = dets[i].ct[1] + dets[i].tracking[1];
-        for (int m = 0; m < M; ++m) {
-            const float dx = tr->tracks[m].ct[0] - px, dy = tr->tracks[m].ct[1] - py;
-            const float d2 = dx * dx + dy * dy;
-            const bool invalid = (d2 > tsize[m]) || (d2 > isize[i]) || (dets[i].cls != tr->tracks[m].cls);
-            dist[(size_t)i * M + m] = (double)d2 + (invalid ? 1e18 : 0.0);
-        }
+    // dist[i][m] = float32 squared distance, + 1e18 (promoting to float64) when gated out; greedy_assignment
+    // walks the detections in score order, takes the FIRST minimum of its row and, if it is < 1e16, overwrites
+    // that track's column with 1e18.  The matrix is not materialised: a row is evaluated when its detection is
+    // visited and an assigned track simply reads as 1e18 (identical values, identical first-minimum choice).
+    // (structure-of-arrays copy of the tracks so that the distance row vectorises; a key of +inf stands for the
+    //  reference's ">= 1e18" entries: gated-out pairs, already assigned tracks and -- never reached in practice --
+    //  valid pairs with d2 >= 1e16, which greedy_assignment rejects too)
+    std::vector<float> &soa = tr->scratch_t;
+    const int MP = (M + 3) & ~3;                       // padded to the SSE width (pads are never available)
+    soa.assign((size_t)6 * (MP > 0 ? MP : 4), 0.0f);
+    float *tcx = soa.data(), *tcy = tcx + MP, *tsz = tcy + MP, *tcl = tsz + MP, *key = tcl + MP, *avail = key + MP;
+    for (int m = 0; m < M; ++m) {
+        tcx[m] = tr->tracks[m].ct[0];
+        tcy[m] = tr->tracks[m].ct[1];
+        tsz[m] = area(tr->tracks[m].bbox);
+        tcl[m] = (float)tr->tracks[m].cls;
+        avail[m] = 1.0f;
     }
-    std::vector<int> det_match(N, -1), trk_match(M, -1);
-    if (M > 0) {
-        for (int i = 0; i < N; ++i) {
+    std::vector<int> &det_match = tr->scratch_dm, &trk_match = tr->scratch_tm;
+    det_match.assign(N, -1);
+    trk_match.assign(M, -1);
+    const float INF = __builtin_inff();
+    const __m128 vinf = _mm_set1_ps(INF), vbig = _mm_set1_ps(1e16f), vone = _mm_set1_ps(1.0f);
+    for (int i = 0; i < N && M > 0; ++i) {
+        const __m128 isz = _mm_set1_ps(area(dets[i].bbox));
+        const __m128 px = _mm_set1_ps(dets[i].ct[0] + dets[i].tracking[0]);
+        const __m128 py = _mm_set1_ps(dets[i].ct[1] + dets[i].tracking[1]);
+        const __m128 cls = _mm_set1_ps((float)dets[i].cls);
+        __m128 vmin = vinf;
+        for (int m = 0; m < MP; m += 4) {
+            const __m128 dx = _mm_sub_ps(_mm_loadu_ps(tcx + m), px), dy = _mm_sub_ps(_mm_loadu_ps(tcy + m), py);
+            const __m128 d2 = _mm_add_ps(_mm_mul_ps(dx, dx), _mm_mul_ps(dy, dy));      // (no fused multiply-add)
+            __m128 ok = _mm_and_ps(_mm_cmpngt_ps(d2, _mm_loadu_ps(tsz + m)), _mm_cmpngt_ps(d2, isz));
+            ok = _mm_and_ps(ok, _mm_cmpeq_ps(cls, _mm_loadu_ps(tcl + m)));
+            ok = _mm_and_ps(ok, _mm_cmpeq_ps(_mm_loadu_ps(avail + m), vone));
+            ok = _mm_and_ps(ok, _mm_cmplt_ps(d2, vbig));
+            const __m128 k = _mm_or_ps(_mm_and_ps(ok, d2), _mm_andnot_ps(ok, vinf));
+            _mm_storeu_ps(key + m, k);
+            vmin = _mm_min_ps(vmin, k);
+        }
+        float lanes[4];
+        _mm_storeu_ps(lanes, vmin);
+        const float bv = fminf(fminf(lanes[0], lanes[1]), fminf(lanes[2], lanes[3]));
+        if (bv < INF) {
             int best = 0;
-            double bv = dist[(size_t)i * M];
-            for (int m = 1; m < M; ++m)
-                if (dist[(size_t)i * M + m] < bv) { bv = dist[(size_t)i * M + m]; best = m; }
-            if (bv < 1e16) {
-                for (int k = 0; k < N; ++k) dist[(size_t)k * M + best] = 1e18;
-                det_match[i] = best;
-                trk_match[best] = i;
-            }
+            while (key[best] != bv) ++best;                                            // first minimum, like numpy argmin
+            det_match[i] = best;
+            trk_match[best] = i;
+            avail[best] = 0.0f;
         }
     }
-    std::vector<ct_track> ret;
+    std::vector<ct_track> &ret = tr->scratch_ret;
+    ret.clear();
     ret.reserve(N + M);
     for (int i = 0; i < N; ++i)
         if (det_match[i] >= 0) {
@@ -186,13 +218,13 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
             t.row = -1;
             ret.push_back(t);
         }
-    tr->tracks = ret;
-    const int n = (int)ret.size();
+    tr->tracks.swap(ret);
+    const int n = (int)tr->tracks.size();
     if (n > cap) {
         ct_set_error("ct_tracker_step: %d results exceed the output capacity %d", n, cap);
         return -1;
     }
-    if (n > 0) memcpy(out, ret.data(), sizeof(ct_track) * n);
+    if (n > 0) memcpy(out, tr->tracks.data(), sizeof(ct_track) * n);
     return n;
 }
 

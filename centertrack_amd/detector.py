@@ -15,7 +15,9 @@ configs 3-5): B independent video streams advance one frame per call, each with 
 ``Tracker`` / ``pre_images`` state; streams never mix (frames of one stream stay
 sequential).  ``Detector`` is the B = 1 case.
 """
+import ctypes
 import math
+import os
 import time
 
 import numpy as np
@@ -70,6 +72,37 @@ def render_pre_hm(tracks, meta, pre_thresh, out=None, with_hm=True):
     return hm, inds
 
 
+class _HipGraph(object):
+    """One captured frame (ct_graph_begin / ct_graph_end); ``replay()`` enqueues it on the current stream."""
+
+    def __init__(self, fn):
+        lib = _lib.load()
+        side = torch.cuda.Stream()                 # (the legacy default stream cannot be captured)
+        side.wait_stream(torch.cuda.current_stream())
+        sp = ctypes.c_void_p(side.cuda_stream)
+        with torch.cuda.stream(side):
+            _lib.check(lib.ct_graph_begin(sp), 'ct_graph_begin')
+            try:
+                fn()
+            finally:
+                self.exec = lib.ct_graph_end(sp)
+        torch.cuda.current_stream().wait_stream(side)
+        if not self.exec:
+            raise _lib.CTError('ct_graph_end failed: %s' % lib.ct_last_error().decode())
+        self._lib = lib
+
+    def replay(self):
+        rc = self._lib.ct_graph_launch(self.exec, _lib.stream_ptr())
+        if rc:
+            _lib.check(rc, 'ct_graph_launch')
+
+    def __del__(self):
+        try:
+            self._lib.ct_graph_destroy(self.exec)
+        except Exception:
+            pass
+
+
 class StreamDetector(object):
     """B independent streams, one frame each per ``step``."""
 
@@ -96,7 +129,7 @@ class StreamDetector(object):
                            and not getattr(opt, 'zero_pre_hm', False))
         self.fast = [fast_track.FastTracker(opt.new_thresh, getattr(opt, 'max_age', -1), opt.K)
                      for _ in range(self.B)] if self.native else None
-        self._trans_cache = {}
+        self._last_dets = None
         self.started = [False] * self.B
         self.gather_fn = None      # optional hook: called with the packed device rows [B,K,F] (multi-GPU all-gather)
         self._ctx = None
@@ -123,6 +156,7 @@ class StreamDetector(object):
         dec_heads = {k: v for k, v in merged.items() if k != 'hm'}
         ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
         ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
+        ctx['host_rows'] = ctx['host_out'].numpy()
         ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if (with_hm and not self.native) else None
         render = self.native and with_hm
         if render:
@@ -143,10 +177,16 @@ class StreamDetector(object):
         ctx['frames'] = [torch.zeros_like(x_in), torch.zeros_like(x_in) if img_in is not None else None]
         ctx['parity'] = 0
         ctx['graphs'] = [None, None]
+        ctx['raw'] = False
 
-        def device_frame(parity=0):
+        def device_frame(parity=0, with_copies=False):
+            """all device work of one frame; ``with_copies``: also the H2D of the prior-heat-map blobs and the D2H
+            of the packed detections (fixed pinned buffers), so that a captured frame is ONE graph launch"""
             cur = ctx['frames'][parity if img_in is not None else 0]
             prev = ctx['frames'][parity ^ 1] if img_in is not None else None
+            if with_copies and render:
+                _lib.check(_lib.load().ct_memcpy_async(ctx['pc_dev'].data_ptr(), ctx['pc_host'].data_ptr(),
+                                                       ctx['pc_host'].numel() * 4, 1, _lib.stream_ptr()), 'H2D')
             if render:
                 _lib.check(_lib.load().ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
                                                         fast_track.MAX_BLOBS, self.B, H, W, hm_in.data_ptr(),
@@ -157,6 +197,9 @@ class StreamDetector(object):
             if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:
                 merged['tracking'].zero_()
             ctx['decoder'].run()
+            if with_copies:
+                _lib.check(_lib.load().ct_memcpy_async(ctx['host_out'].data_ptr(), ctx['decoder'].out.data_ptr(),
+                                                       ctx['host_out'].numel() * 4, 2, _lib.stream_ptr()), 'D2H')
 
         ctx['device_frame'] = device_frame
         if self.use_graph:
@@ -168,11 +211,18 @@ class StreamDetector(object):
                     device_frame(0)           # warm-up (lazy module loads must not happen in capture)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
+                # only C-ABI launches inside device_frame (no torch op): capture / replay straight through HIP
+                raw = (not self.flip and not getattr(opt, 'zero_tracking', False)
+                       and os.environ.get('CENTERTRACK_RAW_GRAPH', '1') != '0')
                 for par in ((0, 1) if img_in is not None else (0,)):
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        device_frame(par)
+                    if raw:
+                        g = _HipGraph(lambda: device_frame(par, True))
+                    else:
+                        g = torch.cuda.CUDAGraph()
+                        with torch.cuda.graph(g):
+                            device_frame(par)
                     ctx['graphs'][par] = g
+                ctx['raw'] = raw
             except Exception as e:             # capture is an optimisation; eager launches are the same kernels
                 print('centertrack_amd: HIP graph capture failed (%s); using eager launches' % e)
                 ctx['graphs'] = [None, None]
@@ -209,7 +259,7 @@ class StreamDetector(object):
         x_in, img_in, hm_in = ctx['plan']['inputs']
         if self.flip:
             images = torch.cat((images, torch.flip(images, [3])), 0)
-        x_dev = images.to(self.device, non_blocking=True)
+        x_dev = images if images.device == self.device else images.to(self.device, non_blocking=True)
         tracking = bool(getattr(opt, 'tracking', False))
         if tracking:
             for s in range(B):
@@ -240,7 +290,8 @@ class StreamDetector(object):
                     m = metas[s]
                     ch[s], _ = self.fast[s].prehm_params(opt.pre_thresh, m['trans_input'], m['inp_width'],
                                                          m['inp_height'], out=ph[s])
-                ctx['pc_dev'].copy_(ctx['pc_host'], non_blocking=True)
+                if not ctx['raw']:                             # (the raw graph carries this copy itself)
+                    ctx['pc_dev'].copy_(ctx['pc_host'], non_blocking=True)
             elif hm_in is not None:
                 hh = ctx['host_hm']
                 for s in range(B):
@@ -252,7 +303,11 @@ class StreamDetector(object):
             for s in range(B):
                 self.started[s] = True
         par = ctx['parity'] if img_in is not None else 0
-        ctx['frames'][par].copy_(x_dev)
+        fr = ctx['frames'][par]
+        if ctx['raw'] and x_dev.is_contiguous() and x_dev.dtype == torch.float32 and x_dev.shape == fr.shape:
+            _lib.load().ct_memcpy_async(fr.data_ptr(), x_dev.data_ptr(), fr.numel() * 4, 0, _lib.stream_ptr())
+        else:
+            fr.copy_(x_dev)
         t1 = time.time()
         if ctx['graphs'][par] is not None:
             ctx['graphs'][par].replay()
@@ -262,27 +317,33 @@ class StreamDetector(object):
             ctx['parity'] ^= 1                                 # this frame is the next step's pre_img
         if self.gather_fn is not None:
             self.gather_fn(ctx['decoder'].out)
-        ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)
-        torch.cuda.current_stream().synchronize()
+        if ctx['raw']:                                         # (the D2H of the rows is the graph's last node)
+            _lib.check(_lib.load().ct_stream_synchronize(_lib.stream_ptr()), 'ct_stream_synchronize')
+        else:
+            ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
         t2 = time.time()
-        rows = ctx['host_out'].numpy()
-        dets = ctx['decoder'].unpack(rows)
-        self.last_dets = dets
+        rows = ctx['host_rows']
+        self._last_dets = None                                 # unpacked on demand (last_dets)
         all_results = []
         t_post = t_track = 0.0
         if self.native:
             ta = time.time()
             for s in range(B):
                 m = metas[s]
-                key = (float(m['c'][0]), float(m['c'][1]), tuple(np.atleast_1d(m['s']).tolist()),
-                       m['out_width'], m['out_height'])
-                tinv = self._trans_cache.get(key)
-                if tinv is None:
+                # float32 inverse output affine (post_process.py:30), cached in the meta dict while its c / s
+                # objects stay the same
+                cached = m.get('_trans_inv')
+                ident = (id(m['c']), id(m['s']), m['out_width'], m['out_height'])
+                if cached is None or cached[0] != ident:
                     tinv = np.ascontiguousarray(get_affine_transform(
                         m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1).astype(np.float32))
-                    self._trans_cache[key] = tinv
+                    m['_trans_inv'] = (ident, tinv)
+                else:
+                    tinv = cached[1]
                 all_results.append(self.fast[s].step(rows[s], ctx['row_layout'], opt.out_thresh, tinv).copy())
             t_track = time.time() - ta
+        dets = None if self.native else self.last_dets
         for s in (range(B) if not self.native else []):
             ta = time.time()
             meta = metas[s]
@@ -302,6 +363,13 @@ class StreamDetector(object):
             timers.update({'pre': t1 - t0, 'net': t2 - t1, 'dec': 0.0, 'post': t_post, 'merge': 0.0,
                            'track': t_track})
         return all_results
+
+    @property
+    def last_dets(self):
+        """the reference's ``dets`` dict (decode.py:99-180) of the last step, as numpy views of the packed rows"""
+        if self._last_dets is None and self._ctx is not None:
+            self._last_dets = self._ctx['decoder'].unpack(self._ctx['host_rows'])
+        return self._last_dets
 
     def reset_tracking(self, stream=None):
         for s in (range(self.B) if stream is None else [stream]):

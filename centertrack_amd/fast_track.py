@@ -36,6 +36,7 @@ class FastTracker(object):
         self.h = ctypes.c_void_p(self.lib.ct_tracker_create(float(new_thresh), int(max_age)))
         self.cap = 2 * K + 64
         self.buf = np.zeros(self.cap, TRACK_DTYPE)
+        self._buf_ptr = self.buf.ctypes.data
         self.params = np.zeros((MAX_BLOBS, 3), np.int32)
 
     def __del__(self):
@@ -56,7 +57,7 @@ class FastTracker(object):
         of the structured result array (valid until the next call)."""
         K, F = rows.shape
         n = self.lib.ct_tracker_step(self.h, rows.ctypes.data, K, F, ctypes.byref(lay), float(out_thresh),
-                                     trans_inv.ctypes.data, self.buf.ctypes.data, self.cap)
+                                     trans_inv.ctypes.data, self._buf_ptr, self.cap)
         if n < 0:
             _lib.check(1, 'ct_tracker_step')
         return self.buf[:n]

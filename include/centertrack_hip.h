@@ -208,6 +208,16 @@ int ct_tracker_step(void *tracker, const float *rows, int K, int F, const ct_row
 int ct_tracker_prehm_params(void *tracker, float pre_thresh, const double *trans_input, int inp_w, int inp_h,
                             int *params, int cap);
 
+/* ---- runtime helpers of the per-frame host loop (no reference equivalent: they replace the torch
+ * dispatcher on the four runtime calls a frame needs).  ct_graph_begin/end capture everything enqueued on
+ * `stream` in between (the launches of one frame) into an executable HIP graph; ct_graph_launch replays it. */
+int ct_graph_begin(void *stream);
+void *ct_graph_end(void *stream);               /* executable graph handle, NULL on error */
+int ct_graph_launch(void *graph_exec, void *stream);
+void ct_graph_destroy(void *graph_exec);
+int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kind /*0 D2D, 1 H2D, 2 D2H*/, void *stream);
+int ct_stream_synchronize(void *stream);
+
 /* ---- image pre-processing (CPU, like the reference's: it runs in DataLoader worker processes) -----
  * Replaces the cv2.warpAffine + normalise + HWC->CHW (+ flipped copy) of Detector.pre_process
  * (src/lib/detector.py:207-239).  img: HOST u8 [h, w, channels] (row pitch `stride` bytes); trans: float64
