@@ -1,22 +1,38 @@
-"""Host-side post-processing: output-grid detections -> original-image coordinates.
+"""Host-side post-processing: decoded detections on the output grid -> original-image coordinates.
 
-Same contract as the reference ``generic_post_process`` (src/lib/utils/post_process.py:
-21-91, non-pose heads) with its 3D helpers (src/lib/utils/ddd_utils.py:91-136): takes the
-decode dict of numpy arrays ``[B,K,...]``, walks each image's detections in score order,
-stops at the first ``score < out_thresh`` and returns per image a list of dicts
-(``score, class, ct, tracking, bbox, [dep, dim, alpha, loc, rot_y, ...]``).  The float32
-inverse affine and the per-detection 2x3 @ 3xn products keep the reference's shapes so the
-values (and everything the tracker derives from them) are bit-identical."""
+Python form of the host step the native path runs in C++ (``ct_tracker_step``); it serves the branches the
+native tracker does not cover (``--hungarian``, ``--public_det``, ``pre_dets``) and every 3D field.  Same
+contract as the reference's ``generic_post_process`` (src/lib/utils/post_process.py:21-91, non-pose heads)
+with the 3D helpers of src/lib/utils/ddd_utils.py:91-136: input = the decode dict of numpy arrays
+``[B,K,...]``; output = per image a list of dicts (``score, class, ct, tracking, bbox, [dep, dim, alpha,
+loc, rot_y, nuscenes_att, velocity]``) for the detections ahead of the first ``score < out_thresh``.
+Every point goes through the same float32 ``[2,3] @ [3,1]`` product as in the reference, so the values (and
+what the tracker derives from them) are bit-identical.
+"""
 import numpy as np
 
 from .image import get_affine_transform, transform_preds_with_trans
 
 
+class _GridToImage(object):
+    """float32 inverse affine of one image (output grid -> original image), post_process.py:30"""
+
+    def __init__(self, c, s, out_w, out_h):
+        self.m = get_affine_transform(c, s, 0, (out_w, out_h), inv=1).astype(np.float32)
+
+    def point(self, xy):
+        return transform_preds_with_trans(np.asarray(xy).reshape(1, 2), self.m).reshape(2)
+
+    def box(self, x0y0x1y1):
+        return transform_preds_with_trans(np.asarray(x0y0x1y1).reshape(2, 2), self.m).reshape(4)
+
+
 def get_alpha(rot):
-    idx = rot[:, 1] > rot[:, 5]
-    alpha1 = np.arctan2(rot[:, 2], rot[:, 3]) + (-0.5 * np.pi)
-    alpha2 = np.arctan2(rot[:, 6], rot[:, 7]) + (0.5 * np.pi)
-    return alpha1 * idx + alpha2 * (1 - idx)
+    """observation angle from the 8-bin rotation vector (post_process.py:12-19)"""
+    use_first = rot[:, 1] > rot[:, 5]
+    from_first = np.arctan2(rot[:, 2], rot[:, 3]) + (-0.5 * np.pi)
+    from_second = np.arctan2(rot[:, 6], rot[:, 7]) + (0.5 * np.pi)
+    return from_first * use_first + from_second * (1 - use_first)
 
 
 def unproject_2d_to_3d(pt_2d, depth, P):
@@ -41,45 +57,47 @@ def ddd2locrot(center, alpha, dim, depth, calib):
     return loc, alpha2rot_y(alpha, center[0], calib[0, 2], calib[0, 0])
 
 
+def _lift_to_3d(item, fields, j, to_img, calib):
+    """3D branch (post_process.py:59-80): amodal centre -> location / yaw"""
+    if 'amodel_offset' in fields:
+        grid_ct = fields['bboxes'][j].reshape(2, 2).mean(axis=0) + fields['amodel_offset'][j]
+        ct = to_img.point(grid_ct).tolist()
+    else:
+        b = item['bbox']
+        ct = [(b[0] + b[2]) / 2, (b[1] + b[3]) / 2]
+    item['ct'] = ct
+    item['loc'], item['rot_y'] = ddd2locrot(ct, item['alpha'], item['dim'], item['dep'], calib)
+
+
 def generic_post_process(opt, dets, c, s, h, w, num_classes=None, calibs=None, height=-1, width=-1):
     if 'scores' not in dets:
         return [{}], [{}]
-    ret = []
-    has3d = all(k in dets for k in ('rot', 'dep', 'dim'))
-    for i in range(len(dets['scores'])):
-        trans = get_affine_transform(c[i], s[i], 0, (w, h), inv=1).astype(np.float32)
-        scores = dets['scores'][i]
-        below = np.nonzero(scores < opt.out_thresh)[0]
-        n = int(below[0]) if len(below) else len(scores)
-        preds = []
-        for j in range(n):
-            ct_out = dets['cts'][i][j]
-            item = {'score': scores[j], 'class': int(dets['clses'][i][j]) + 1,
-                    'ct': transform_preds_with_trans(ct_out.reshape(1, 2), trans).reshape(2)}
-            if 'tracking' in dets:
-                moved = transform_preds_with_trans((dets['tracking'][i][j] + ct_out).reshape(1, 2), trans)
-                item['tracking'] = moved.reshape(2) - item['ct']
-            if 'bboxes' in dets:
-                item['bbox'] = transform_preds_with_trans(dets['bboxes'][i][j].reshape(2, 2), trans).reshape(4)
-            if 'dep' in dets:
-                item['dep'] = dets['dep'][i][j]
-            if 'dim' in dets:
-                item['dim'] = dets['dim'][i][j]
-            if 'rot' in dets:
-                item['alpha'] = get_alpha(dets['rot'][i][j:j + 1])[0]
-            if has3d:
-                if 'amodel_offset' in dets:
-                    ct3 = dets['bboxes'][i][j].reshape(2, 2).mean(axis=0) + dets['amodel_offset'][i][j]
-                    ct = transform_preds_with_trans(ct3.reshape(1, 2), trans).reshape(2).tolist()
-                else:
-                    bbox = item['bbox']
-                    ct = [(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2]
-                item['ct'] = ct
-                item['loc'], item['rot_y'] = ddd2locrot(ct, item['alpha'], item['dim'], item['dep'], calibs[i])
-            preds.append(item)
-        for key in ('nuscenes_att', 'velocity'):
-            if key in dets:
-                for j in range(len(preds)):
-                    preds[j][key] = dets[key][i][j]
-        ret.append(preds)
-    return ret
+    want_3d = all(k in dets for k in ('rot', 'dep', 'dim'))
+    per_image = []
+    for i, scores in enumerate(dets['scores']):
+        to_img = _GridToImage(c[i], s[i], w, h)
+        fields = {k: v[i] for k, v in dets.items()}
+        low = np.nonzero(scores < opt.out_thresh)[0]
+        count = int(low[0]) if len(low) else len(scores)
+        found = []
+        for j in range(count):
+            grid_ct = fields['cts'][j]
+            item = {'score': scores[j], 'class': int(fields['clses'][j]) + 1, 'ct': to_img.point(grid_ct)}
+            if 'tracking' in fields:
+                item['tracking'] = to_img.point(fields['tracking'][j] + grid_ct) - item['ct']
+            if 'bboxes' in fields:
+                item['bbox'] = to_img.box(fields['bboxes'][j])
+            for k in ('dep', 'dim'):
+                if k in fields:
+                    item[k] = fields[k][j]
+            if 'rot' in fields:
+                item['alpha'] = get_alpha(fields['rot'][j:j + 1])[0]
+            if want_3d:
+                _lift_to_3d(item, fields, j, to_img, calibs[i])
+            found.append(item)
+        for k in ('nuscenes_att', 'velocity'):
+            if k in fields:
+                for j, item in enumerate(found):
+                    item[k] = fields[k][j]
+        per_image.append(found)
+    return per_image

@@ -1,134 +1,134 @@
-"""Oracle: displacement-based greedy/Hungarian track association (numpy).
-TEST INFRASTRUCTURE ONLY.  Restates ``src/lib/utils/tracker.py`` (Tracker :6-127,
-greedy_assignment :129-138).  ``sklearn.utils.linear_assignment_`` (removed from
-modern sklearn) is restated with scipy's linear_sum_assignment, as the reference's
-Hungarian branch only needs the optimal pairs.
-"""
-import copy
+"""Oracle: displacement-based track association on the CPU (numpy).
 
+TEST INFRASTRUCTURE ONLY (see oracle/__init__.py).  Restates the behaviour of the reference's
+``src/lib/utils/tracker.py`` -- ``Tracker.init_track`` (:11-22), ``Tracker.step`` (:28-127) and
+``greedy_assignment`` (:129-138) -- as small functions over numpy arrays; pinned against the imported
+reference by tests/golden/make_golden.py (tracker.json).  ``sklearn.utils.linear_assignment_`` (gone from
+modern sklearn) is replaced by scipy's ``linear_sum_assignment`` for the ``--hungarian`` branch.
+
+Semantics that matter for bit-identical IDs:
+  * cost[i, j] = float32 squared distance between (ct + tracking) of detection i and ct of track j; a pair
+    is gated out (cost + 1e18, which promotes the matrix to float64) when the distance exceeds either box
+    area or the classes differ;
+  * greedy: detections in input (= score) order, each takes the first minimum of its row if < 1e16 and
+    retires that column;
+  * output order: matched detections (detection order), then new tracks (detection order, ids counted
+    up), then surviving unmatched tracks (track order).
+"""
 import numpy as np
 
 
-def linear_assignment(cost):
-    from scipy.optimize import linear_sum_assignment
-    r, c = linear_sum_assignment(cost)
-    return np.stack([r, c], axis=1)
+def _box_area(items):
+    return np.array([(b['bbox'][2] - b['bbox'][0]) * (b['bbox'][3] - b['bbox'][1]) for b in items], np.float32)
+
+
+def _classes(items):
+    return np.array([b['class'] for b in items], np.int32)
+
+
+def cost_matrix(dets, tracks):
+    """float64 [N, M] gated cost and the float32 predicted centres / detection areas it was built from."""
+    n, m = len(dets), len(tracks)
+    moved = np.array([d['ct'] + d['tracking'] for d in dets], np.float32)
+    prev = np.array([t['ct'] for t in tracks], np.float32)
+    d2 = ((prev.reshape(1, -1, 2) - moved.reshape(-1, 1, 2)) ** 2).sum(axis=2)
+    det_area, trk_area = _box_area(dets), _box_area(tracks)
+    gated = ((d2 > trk_area.reshape(1, m)) + (d2 > det_area.reshape(n, 1)) +
+             (_classes(dets).reshape(n, 1) != _classes(tracks).reshape(1, m))) > 0
+    return d2 + gated * 1e18, moved, det_area
 
 
 def greedy_assignment(dist):
-    """tracker.py:129-138"""
-    matched = []
-    if dist.shape[1] == 0:
-        return np.array(matched, np.int32).reshape(-1, 2)
-    for i in range(dist.shape[0]):
-        j = dist[i].argmin()
-        if dist[i][j] < 1e16:
-            dist[:, j] = 1e18
-            matched.append([i, j])
-    return np.array(matched, np.int32).reshape(-1, 2)
+    """pairs [[det, track], ...]; mutates ``dist`` (matched columns are retired with 1e18)"""
+    pairs = []
+    if dist.shape[1] > 0:
+        for det in range(dist.shape[0]):
+            trk = dist[det].argmin()
+            if dist[det][trk] < 1e16:
+                pairs.append([det, trk])
+                dist[:, trk] = 1e18
+    return np.array(pairs, np.int32).reshape(-1, 2)
+
+
+def hungarian_assignment(dist):
+    from scipy.optimize import linear_sum_assignment
+    dist[dist > 1e18] = 1e18
+    rows, cols = linear_sum_assignment(dist)
+    return np.stack([rows, cols], axis=1)
 
 
 class Tracker(object):
     def __init__(self, new_thresh, max_age=-1, hungarian=False, public_det=False):
-        self.new_thresh = new_thresh
-        self.max_age = max_age
-        self.hungarian = hungarian
-        self.public_det = public_det
+        self.new_thresh, self.max_age = new_thresh, max_age
+        self.hungarian, self.public_det = hungarian, public_det
         self.reset()
 
-    def init_track(self, results):
-        """tracker.py:11-22"""
-        for item in results:
-            if item['score'] > self.new_thresh:
-                self.id_count += 1
-                item['active'] = 1
-                item['age'] = 1
-                item['tracking_id'] = self.id_count
-                if 'ct' not in item:
-                    bbox = item['bbox']
-                    item['ct'] = [(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2]
-                self.tracks.append(item)
-
     def reset(self):
-        self.id_count = 0
-        self.tracks = []
+        self.id_count, self.tracks = 0, []
+
+    def _birth(self, det):
+        """a detection becomes a new track if it is confident enough; returns it or None"""
+        if not det['score'] > self.new_thresh:
+            return None
+        self.id_count += 1
+        det.update(tracking_id=self.id_count, age=1, active=1)
+        return det
+
+    def init_track(self, results):
+        for det in results:
+            if self._birth(det) is not None:
+                if 'ct' not in det:
+                    x0, y0, x1, y1 = det['bbox']
+                    det['ct'] = [(x0 + x1) / 2, (y0 + y1) / 2]
+                self.tracks.append(det)
 
     def step(self, results, public_det=None):
-        """tracker.py:28-127"""
-        N = len(results)
-        M = len(self.tracks)
-        dets = np.array([det['ct'] + det['tracking'] for det in results], np.float32)
-        track_size = np.array([((t['bbox'][2] - t['bbox'][0]) * (t['bbox'][3] - t['bbox'][1]))
-                               for t in self.tracks], np.float32)
-        track_cat = np.array([t['class'] for t in self.tracks], np.int32)
-        item_size = np.array([((it['bbox'][2] - it['bbox'][0]) * (it['bbox'][3] - it['bbox'][1]))
-                              for it in results], np.float32)
-        item_cat = np.array([it['class'] for it in results], np.int32)
-        tracks = np.array([pre['ct'] for pre in self.tracks], np.float32)
-        dist = (((tracks.reshape(1, -1, 2) - dets.reshape(-1, 1, 2)) ** 2).sum(axis=2))
-        invalid = ((dist > track_size.reshape(1, M)) + (dist > item_size.reshape(N, 1)) +
-                   (item_cat.reshape(N, 1) != track_cat.reshape(1, M))) > 0
-        dist = dist + invalid * 1e18
-        if self.hungarian:
-            dist[dist > 1e18] = 1e18
-            matched_indices = linear_assignment(dist)
-        else:
-            matched_indices = greedy_assignment(copy.deepcopy(dist))
-        unmatched_dets = [d for d in range(dets.shape[0]) if not (d in matched_indices[:, 0])]
-        unmatched_tracks = [d for d in range(tracks.shape[0]) if not (d in matched_indices[:, 1])]
-        if self.hungarian:
-            matches = []
-            for m in matched_indices:
-                if dist[m[0], m[1]] > 1e16:
-                    unmatched_dets.append(m[0])
-                    unmatched_tracks.append(m[1])
+        dist, moved, det_area = cost_matrix(results, self.tracks)
+        n, m = len(results), len(self.tracks)
+        pairs = hungarian_assignment(dist) if self.hungarian else greedy_assignment(dist.copy())
+        lone_dets = [i for i in range(n) if i not in pairs[:, 0]]
+        lone_tracks = [j for j in range(m) if j not in pairs[:, 1]]
+        if self.hungarian:                       # optimal pairs may still be gated out
+            kept = []
+            for i, j in pairs:
+                if dist[i, j] > 1e16:
+                    lone_dets.append(i)
+                    lone_tracks.append(j)
                 else:
-                    matches.append(m)
-            matches = np.array(matches).reshape(-1, 2)
+                    kept.append([i, j])
+            pairs = np.array(kept).reshape(-1, 2)
+        out = []
+        for i, j in pairs:                       # continued tracks keep their id
+            det, old = results[i], self.tracks[j]
+            det.update(tracking_id=old['tracking_id'], age=1, active=old['active'] + 1)
+            out.append(det)
+        if self.public_det and len(lone_dets) > 0:
+            out.extend(self._births_near_public(results, moved, det_area, lone_dets, public_det))
         else:
-            matches = matched_indices
-        ret = []
-        for m in matches:
-            track = results[m[0]]
-            track['tracking_id'] = self.tracks[m[1]]['tracking_id']
-            track['age'] = 1
-            track['active'] = self.tracks[m[1]]['active'] + 1
-            ret.append(track)
-        if self.public_det and len(unmatched_dets) > 0:
-            pub_dets = np.array([d['ct'] for d in public_det], np.float32)
-            dist3 = ((dets.reshape(-1, 1, 2) - pub_dets.reshape(1, -1, 2)) ** 2).sum(axis=2)
-            matched_dets = [d for d in range(dets.shape[0]) if not (d in unmatched_dets)]
-            dist3[matched_dets] = 1e18
-            for j in range(len(pub_dets)):
-                i = dist3[:, j].argmin()
-                if dist3[i, j] < item_size[i]:
-                    dist3[i, :] = 1e18
-                    track = results[i]
-                    if track['score'] > self.new_thresh:
-                        self.id_count += 1
-                        track['tracking_id'] = self.id_count
-                        track['age'] = 1
-                        track['active'] = 1
-                        ret.append(track)
-        else:
-            for i in unmatched_dets:
-                track = results[i]
-                if track['score'] > self.new_thresh:
-                    self.id_count += 1
-                    track['tracking_id'] = self.id_count
-                    track['age'] = 1
-                    track['active'] = 1
-                    ret.append(track)
-        for i in unmatched_tracks:
-            track = self.tracks[i]
-            if track['age'] < self.max_age:
-                track['age'] += 1
-                track['active'] = 0
-                bbox = track['bbox']
-                ct = track['ct']
-                v = [0, 0]
-                track['bbox'] = [bbox[0] + v[0], bbox[1] + v[1], bbox[2] + v[0], bbox[3] + v[1]]
-                track['ct'] = [ct[0] + v[0], ct[1] + v[1]]
-                ret.append(track)
-        self.tracks = ret
-        return ret
+            out.extend(t for t in (self._birth(results[i]) for i in lone_dets) if t is not None)
+        for j in lone_tracks:                    # unmatched tracks coast while young enough
+            old = self.tracks[j]
+            if old['age'] < self.max_age:
+                old['age'] += 1
+                old['active'] = 0
+                old['bbox'] = [old['bbox'][0] + 0, old['bbox'][1] + 0, old['bbox'][2] + 0, old['bbox'][3] + 0]
+                old['ct'] = [old['ct'][0] + 0, old['ct'][1] + 0]
+                out.append(old)
+        self.tracks = out
+        return out
+
+    def _births_near_public(self, results, moved, det_area, lone_dets, public_det):
+        """MOT public-detection protocol: a track may only start at the unmatched detection nearest to a public
+        detection, and only if that distance is below the detection's area."""
+        pub = np.array([p['ct'] for p in public_det], np.float32)
+        d3 = ((moved.reshape(-1, 1, 2) - pub.reshape(1, -1, 2)) ** 2).sum(axis=2)
+        d3[[i for i in range(moved.shape[0]) if i not in lone_dets]] = 1e18
+        born = []
+        for col in range(len(pub)):
+            i = d3[:, col].argmin()
+            if d3[i, col] < det_area[i]:
+                d3[i, :] = 1e18
+                t = self._birth(results[i])
+                if t is not None:
+                    born.append(t)
+        return born
