@@ -102,7 +102,7 @@ def _dcn_key(d):
                                        d.Cin, d.Cout)
 
 
-_REG_BN = [16, 32, 64, 128, 64, 32]          # couts per workgroup of the row-tiled shapes 0..5
+_REG_BN = [16, 32, 64, 128, 64, 32, 16, 16]  # couts per workgroup of the row-tiled shapes 0..7
 _KS = [(2, 2, 4), (1, 2, 4), (1, 2, 8), (2, 4, 4), (2, 2, 8)]
 
 

@@ -344,7 +344,7 @@ int make_plan(const ct_conv_desc *d, Plan *p)
     p->Ho = (d->H + 2 * pad - d->ks) / d->stride + 1;
     p->Wo = (d->W + 2 * pad - d->ks) / d->stride + 1;
     p->NT = ct_cdiv(d->Cout, 16);
-    static const int kTH[6] = {16, 8, 4, 4, 2, 4}, kBN[6] = {16, 32, 64, 128, 64, 32};
+    static const int kTH[8] = {16, 8, 4, 4, 2, 4, 8, 4}, kBN[8] = {16, 32, 64, 128, 64, 32, 16, 16};
     p->tilesX = ct_cdiv(p->Wo, 16);
     auto tiles_of = [&](int cfg) {
         return (long)d->N * p->tilesX * ct_cdiv(p->Ho, kTH[cfg]) * ct_cdiv(d->Cout, kBN[cfg]);
@@ -356,7 +356,7 @@ int make_plan(const ct_conv_desc *d, Plan *p)
         if (tiles_of(2) < ct_tune_get(CT_TUNE_CONV_SMALL_TILES) || tiles_of(2) >= 2048) p->cfg = 4;
     }
     if (ct_tune_get(CT_TUNE_CONV_CFG) >= 0) p->cfg = ct_tune_get(CT_TUNE_CONV_CFG);
-    if (d->algo >= 1 && d->algo <= 6) p->cfg = d->algo - 1;
+    if (d->algo >= 1 && d->algo <= 8) p->cfg = d->algo - 1;
     else if (d->algo != 0 && !(d->algo >= 101 && d->algo < 101 + kNumKs)) CT_FAIL_ARG("ct_conv2d: unknown algo %d", d->algo);
     p->pipe = ct_tune_get(CT_TUNE_CONV_PIPE);
     p->TH = kTH[p->cfg];
@@ -455,6 +455,7 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 
 // tile configurations: {WGM, WGN, WM, WN} -> TH = WGM*WM rows x 16 px, BN = 16*WGN*WN couts
 //   0: 256 px x 16   1: 128 px x 32   2: 64 px x 64   3: 64 px x 128   4: 32 px x 64   5: 64 px x 32
+//   6: 128 px x 16   7: 64 px x 16
 template <int KS, int STRIDE, int NKK, int PIPE>
 int launch_tile2(int cfg, const ConvArgs &a, dim3 grid, hipStream_t s)
 {
@@ -464,6 +465,8 @@ int launch_tile2(int cfg, const ConvArgs &a, dim3 grid, hipStream_t s)
     case 2: return launch_cfg<KS, STRIDE, 2, 2, 2, 2, NKK, PIPE>(a, grid, s);
     case 3: return launch_cfg<KS, STRIDE, 2, 2, 2, 4, NKK, PIPE>(a, grid, s);
     case 4: return launch_cfg<KS, STRIDE, 1, 4, 2, 1, NKK, PIPE>(a, grid, s);
+    case 6: return launch_cfg<KS, STRIDE, 4, 1, 2, 1, NKK, PIPE>(a, grid, s);
+    case 7: return launch_cfg<KS, STRIDE, 4, 1, 1, 1, NKK, PIPE>(a, grid, s);
     default: return launch_cfg<KS, STRIDE, 2, 2, 2, 1, NKK, PIPE>(a, grid, s);
     }
 }

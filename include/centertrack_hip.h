@@ -76,7 +76,7 @@ typedef struct ct_conv_desc {
     int dep_lo, dep_hi; float depth_scale;
     float *workspace; size_t workspace_bytes;   /* split-K partials; may be NULL (no split) */
     int split_k;                                /* 0 = choose automatically */
-    int algo;                                   /* 0 = heuristic; 1..6 = tile shape 0..5 of the row-tiled
+    int algo;                                   /* 0 = heuristic; 1..8 = tile shape 0..7 of the row-tiled
                                                    kernel; 101..105 = K-split-in-workgroup shape 0..4
                                                    (CT_ERR_ARG if the shape cannot run this layer); 201..207 =
                                                    Winograd F(2x2,3x3) with 64px x 64 / 64 x 32 / 128 x 32 /

@@ -101,6 +101,22 @@ def test_conv2d_matches_torch(device, case):
     assert float(ob[..., :4].min()) == -7.0 and float(ob[..., 4 + Cout:].min()) == -7.0, 'wrote outside its slice'
 
 
+@pytest.mark.parametrize('algo,N,H,W,Cin,Cout,ks,stride', [(7, 1, 19, 37, 16, 16, 3, 1), (8, 2, 9, 21, 16, 16, 3, 1),
+                                                         (7, 1, 16, 32, 16, 32, 3, 2), (8, 1, 8, 8, 64, 27, 3, 1),
+                                                         (1, 1, 20, 20, 16, 16, 3, 1), (5, 1, 6, 10, 64, 64, 1, 1)])
+def test_conv2d_forced_row_tile_shapes(device, algo, N, H, W, Cin, Cout, ks, stride):
+    """every row-tiled shape the autotuner may pick (ct_conv_desc.algo 1..8) computes the same convolution"""
+    from centertrack_amd import ops
+    x = _rand(N, Cin, H, W, seed=70)
+    w = _rand(Cout, Cin, ks, ks, seed=71, scale=(Cin * ks * ks) ** -0.5)
+    shift = _rand(Cout, seed=72)
+    y = F.relu(F.conv2d(x, w, shift, stride=stride, padding=ks // 2))
+    out = ops.conv2d(ops.view_from_nchw(x.to(device)), ops.pack_weight(w.to(device)), Cout, ks, stride,
+                     shift=shift.to(device), relu=True, split_k=1, algo=algo)
+    torch.cuda.synchronize()
+    _close(out.to_nchw(), y, msg='row-tiled algo %d' % algo)
+
+
 KS_CASES = [
     # ks-config id, N, H, W, Cin, Cout, ks, stride, split_k
     (0, 1, 9, 21, 128, 128, 3, 1, 0),      # 32px x 32co, 4 waves; ragged edges
