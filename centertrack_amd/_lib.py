@@ -147,6 +147,11 @@ def load():
     lib.ct_graph_destroy.argtypes = [p]
     lib.ct_memcpy_async.argtypes = [p, p, sz, i, p]
     lib.ct_stream_synchronize.argtypes = [p]
+    # CENTERTRACK_TUNE="key=value,key=value": launch-heuristic knobs of ct_set_tuning (A/B runs)
+    for kv in filter(None, os.environ.get('CENTERTRACK_TUNE', '').split(',')):
+        k, _, v = kv.partition('=')
+        if lib.ct_set_tuning(k.strip().encode(), int(v)) != 0:
+            raise CTError('CENTERTRACK_TUNE: %s' % lib.ct_last_error().decode())
     _lib = lib
     return lib
 

@@ -28,7 +28,7 @@ struct ConvArgs {
     const float *x;
     const float *wp;
     int N, H, W, Cin, ldx;
-    int tilesX, tilesY, coutBlocks;
+    int tilesX, tilesY, coutBlocks, xcdPer;
     int NT;          // CoutPad / 16
     int nchunks;     // Cin / (16*NKK)
     int chunksPerSplit;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     const int wm = wave / WGN, wn = wave % WGN;
 
     int bid = blockIdx.x;
-    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
     extern __shared__ __attribute__((aligned(16))) float lds[];
     const int lane = threadIdx.x & 63;
     int bid = blockIdx.x;
-    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
@@ -560,7 +560,7 @@ extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
     ConvArgs a;
     a.x = d->x; a.wp = d->w_packed;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-    a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.coutBlocks = p.coutBlocks;
+    a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.coutBlocks = p.coutBlocks; a.xcdPer = ct_xcd_per(p.coutBlocks);
     a.NT = p.NT; a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit;
     a.ws = p.splits > 1 ? d->workspace : nullptr;
     a.wsCout = p.NT * 16;

@@ -29,8 +29,32 @@ static inline int ct_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // tuning knobs (ct_set_tuning); defaults chosen from MI355X measurements, see DESIGN.md
 enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,
-       CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_COUNT };
+       CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_COUNT };
 int ct_tune_get(int key);
+
+// XCD-aware decode of the linear workgroup id into (cout block, pixel-tile index).  Workgroups are dealt to
+// the 8 XCDs round-robin (id % 8) and each XCD has its own 4 MB L2, so with `per` = coutBlocks / 8 > 0
+// XCD x only ever touches the weights of cout blocks {x, x+8, ..}: 1/8 of the packed weights per L2
+// instead of all of them (heads: 5.2 MB of Winograd weights, level 5: 9.4 MB).  per == 0: plain order.
+static inline int ct_xcd_per(int coutBlocks)
+{
+    return (ct_tune_get(CT_TUNE_XCD_REMAP) && coutBlocks >= 16 && (coutBlocks & 7) == 0) ? (coutBlocks >> 3) : 0;
+}
+#ifdef __HIPCC__
+__device__ __forceinline__ int ct_block_cout(int &bid, int coutBlocks, int per)
+{
+    int cb;
+    if (per) {
+        const int j = bid >> 3;
+        cb = (bid & 7) + 8 * (j % per);
+        bid = j / per;
+    } else {
+        cb = bid % coutBlocks;
+        bid /= coutBlocks;
+    }
+    return cb;
+}
+#endif
 
 // Epilogue description shared by the conv / dcn / split-K-reduce kernels.
 struct EpiArgs {

@@ -24,7 +24,7 @@ struct WinoArgs {
     const float *x;
     const float *up;          // packed U
     int N, H, W, Cin, ldx;
-    int tilesX, tilesY, coutBlocks;
+    int tilesX, tilesY, coutBlocks, xcdPer;
     int NT;                   // CoutPad / 16
     int nchunks;              // Cin / 64
     EpiArgs epi;
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256 * KS) void wino_conv_kernel(WinoArgs a)
     const int li = lane & 15, lg = lane >> 4;
 
     int bid = blockIdx.x;
-    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
@@ -210,6 +210,9 @@ __global__ __launch_bounds__(256 * KS) void wino_conv_kernel(WinoArgs a)
     // T[q][nt]: q=0: M0+M1+M2, q=1: M1-M2-M3   (this wave's row r)
     float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
     constexpr int TN = WM * WN;
+    float *ybuf = lds + KS * 4 * 2 * TN * 256;      // per-wave 32 x 16 transpose slabs behind the exchange buffer
+    const bool wide = (a.epi.Cout % 4 == 0) && (a.epi.ldy % 4 == 0) && (!a.epi.res || a.epi.ldr % 4 == 0) &&
+                      (((uintptr_t)a.epi.y & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
     const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
@@ -239,7 +242,40 @@ __global__ __launch_bounds__(256 * KS) void wino_conv_kernel(WinoArgs a)
             const f32x4 y0 = t[0] + t[1] + t[2];
             const f32x4 y1 = t[1] - t[2] - t[3];
             const int co = (nt0 + nt) * 16 + li;
-            if (co < a.epi.Cout) {
+            if (wide) {
+                // 32 pixels x 16 couts of this job: transpose through this wave's private LDS slab so that a lane
+                // stores 4 consecutive couts of one pixel as ONE 16-byte store (the epilogue of a short-K layer
+                // like the heads conv is store-issue bound: 8 dword stores per lane become 2 dwordx4 stores)
+                float *yb = ybuf + (tid >> 6) * (32 * 16);
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const int tile = lg * 4 + ee;
+                    yb[(tile * 2 + 0) * 16 + li] = y0[ee];
+                    yb[(tile * 2 + 1) * 16 + li] = y1[ee];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int item = lane + 64 * h2;              // (tile*2 + p) * 4 + cout quad
+                    const int cq = item & 3, tp = item >> 2;
+                    const int tile = tp >> 1, pp = tp & 1;
+                    const int oy = oy0 + 4 * mt + 2 * (tile >> 3) + pp;
+                    const int ox = ox0 + 2 * (tile & 7) + q;
+                    const int c4 = (nt0 + nt) * 16 + cq * 4;
+                    if (oy < a.epi.Ho && ox < a.epi.Wo && c4 < a.epi.Cout) {
+                        const f32x4 raw = *reinterpret_cast<const f32x4 *>(yb + tp * 16 + cq * 4);
+                        const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
+                        const f32x4 sc4 = a.epi.scale ? *reinterpret_cast<const f32x4 *>(a.epi.scale + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                        const f32x4 sh4 = a.epi.shift ? *reinterpret_cast<const f32x4 *>(a.epi.shift + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        const f32x4 r4 = a.epi.res ? *reinterpret_cast<const f32x4 *>(a.epi.res + pix * a.epi.ldr + c4)
+                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 o;
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_value(a.epi, raw[i], c4 + i, sc4[i], sh4[i], r4[i]);
+                        *reinterpret_cast<f32x4 *>(a.epi.y + pix * a.epi.ldy + c4) = o;
+                    }
+                }
+            } else if (co < a.epi.Cout) {
                 const float sc = a.epi.scale ? a.epi.scale[co] : 1.0f;
                 const float sh = a.epi.shift ? a.epi.shift[co] : 0.0f;
 #pragma unroll
@@ -290,7 +326,7 @@ int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
     using C = WCfg<WM>;
     auto k = wino_conv_kernel<WM, WN, KS, MULTI>;
     const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
-    const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256);
+    const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256 + 4 * KS * 32 * 16);
     const size_t lds = patch > exch ? patch : exch;
     static bool attr_set = false;
     if (!attr_set) {
@@ -337,7 +373,7 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     WinoArgs a;
     a.x = d->x; a.up = d->w_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN);
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN); a.xcdPer = ct_xcd_per(a.coutBlocks);
     a.NT = ct_cdiv(d->Cout, 16); a.nchunks = d->Cin / 64;
     a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = d->res; a.epi.y = d->y;
     a.epi.ldr = d->ldr; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;

@@ -47,6 +47,9 @@ def main():
     ap.add_argument('--batch', type=int, default=1)
     ap.add_argument('--size', type=int, default=512)
     ap.add_argument('--reps', type=int, default=30)
+    ap.add_argument('--layers', default='', help='substring filter on the layer name')
+    ap.add_argument('--xcd', action='store_true', help='A/B of the XCD-aware workgroup order only')
+    ap.add_argument('--no-dcn', action='store_true')
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device('cuda:0')
@@ -78,6 +81,12 @@ def main():
                 ('old/cfg2', dict(conv_ks=-2, conv_cfg=2)), ('old/cfg4', dict(conv_ks=-2, conv_cfg=4)),
                 ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('w64x32', dict(algo=202)), ('w32/k2', dict(algo=205)), ('w32/k4', dict(algo=206)),
                 ('w16/k4', dict(algo=207))]
+    if args.xcd:
+        variants = [('auto', {}), ('auto/x0', dict(xcd_remap=0)), ('ks1', dict(conv_ks=1)), ('ks1/x0', dict(conv_ks=1, xcd_remap=0)),
+                    ('old/cfg0', dict(conv_ks=-2, conv_cfg=0)), ('cfg0/x0', dict(conv_ks=-2, conv_cfg=0, xcd_remap=0)),
+                    ('w64x32', dict(algo=202)), ('w64x32/x0', dict(algo=202, xcd_remap=0)),
+                    ('w32/k2', dict(algo=205)), ('w32/k2/x0', dict(algo=205, xcd_remap=0))]
+    convs = [c for c in convs if args.layers in c[0]]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
     tot = {v[0]: 0.0 for v in variants}
     for name, cnt, H, Cin, Cout, ks, stride in convs:
@@ -90,10 +99,10 @@ def main():
         gf = 2.0 * ks * ks * Cin * Cout * N * Ho * Ho / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in variants:
-            tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1)
+            tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1, xcd_remap=1)
             algo = kw.get('algo', 0)
             tune(**{k: v for k, v in kw.items() if k != 'algo'})
-            if (kw.get('conv_cfg', -1) in (0, 1, 5) and Cout > 32 * 8) or (algo and (ks != 3 or stride != 1 or Cin % 64)):
+            if (kw.get('conv_cfg', -1) in (1, 5) and Cout > 32 * 8) or (algo and (ks != 3 or stride != 1 or Cin % 64)):
                 line += ' %12s' % '-'
                 continue
             ww = ops.pack_winograd(wraw) if algo else None        # (kept alive: the descriptor only holds its address)
@@ -107,7 +116,9 @@ def main():
         print(line)
         sys.stdout.flush()
     print('%-24s %3s %8s |' % ('SUM(us per frame)', '', '') + ''.join(' %12.1f' % tot[v[0]] for v in variants))
-    tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1)
+    tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1, xcd_remap=1)
+    if args.no_dcn:
+        return
 
     dcns = [('dcn 512-256 @16', 1, S // 32, 512, 256), ('dcn 256-256 @32', 1, S // 16, 256, 256),
             ('dcn 256-128 @32', 2, S // 16, 256, 128), ('dcn 128-128 @64', 2, S // 8, 128, 128),
