@@ -81,7 +81,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_render_pre_hm',
            'ct_tracker_create', 'ct_tracker_destroy', 'ct_tracker_reset', 'ct_tracker_num_tracks',
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params',
-           'ct_preprocess_image', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
+           'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
            'ct_memcpy_async', 'ct_stream_synchronize']
 
 _lib = None
@@ -139,6 +139,8 @@ def load():
     lib.ct_tracker_step.argtypes = [p, p, i, i, ctypes.POINTER(RowLayout), ctypes.c_float, p, p, i]
     lib.ct_tracker_prehm_params.argtypes = [p, ctypes.c_float, p, i, i, p, i]
     lib.ct_preprocess_image.argtypes = [p, i, i, i, i, p, i, i, p, p, p, i]
+    lib.ct_preprocess_lut.argtypes = [p, p, i, p]
+    lib.ct_preprocess_device.argtypes = [p, i, i, i, i, p, i, i, p, p, p, p]
     lib.ct_graph_begin.argtypes = [p]
     lib.ct_graph_end.restype = p
     lib.ct_graph_end.argtypes = [p]

@@ -31,6 +31,7 @@ static inline int ct_cdiv(int a, int b) { return (a + b - 1) / b; }
 enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,
        CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_COUNT };
 int ct_tune_get(int key);
+void ct_affine_inverse(const double *trans, double *M);   // host_preprocess.cpp
 
 // XCD-aware decode of the linear workgroup id into (cout block, pixel-tile index).  Workgroups are dealt to
 // the 8 XCDs round-robin (id % 8) and each XCD has its own 4 MB L2, so with `per` = coutBlocks / 8 > 0

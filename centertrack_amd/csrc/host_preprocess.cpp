@@ -20,14 +20,11 @@ namespace {
 inline int cv_round(double v) { return (int)lrint(v); }        // saturate_cast<int>(double): round half to even
 }
 
-extern "C" int ct_preprocess_image(const uint8_t *img, int h, int w, int stride, int channels, const double *trans,
-                                   int dst_w, int dst_h, const float *mean, const float *stdv, float *out, int flip_copy)
+// dst -> src map of cv::warpAffine: the 2x3 forward map inverted with OpenCV's own sequence of float64 operations
+// (shared with the device path, csrc/preprocess.hip; this file is compiled with -ffp-contract=off)
+void ct_affine_inverse(const double *trans, double *M)
 {
-    if (!img || !trans || !mean || !stdv || !out) CT_FAIL_ARG("ct_preprocess_image: null pointer");
-    if (h <= 0 || w <= 0 || dst_w <= 0 || dst_h <= 0 || channels < 1 || channels > 4 || stride < w * channels)
-        CT_FAIL_ARG("ct_preprocess_image: bad shape");
-    // invert the 2x3 forward map exactly as cv::warpAffine does
-    double M[6] = {trans[0], trans[1], trans[2], trans[3], trans[4], trans[5]};
+    for (int i = 0; i < 6; ++i) M[i] = trans[i];
     double D = M[0] * M[4] - M[1] * M[3];
     D = D != 0 ? 1. / D : 0;
     const double A11 = M[4] * D, A22 = M[0] * D;
@@ -36,6 +33,16 @@ extern "C" int ct_preprocess_image(const uint8_t *img, int h, int w, int stride,
     const double b1 = -M[0] * M[2] - M[1] * M[5];
     const double b2 = -M[3] * M[2] - M[4] * M[5];
     M[2] = b1; M[5] = b2;
+}
+
+extern "C" int ct_preprocess_image(const uint8_t *img, int h, int w, int stride, int channels, const double *trans,
+                                   int dst_w, int dst_h, const float *mean, const float *stdv, float *out, int flip_copy)
+{
+    if (!img || !trans || !mean || !stdv || !out) CT_FAIL_ARG("ct_preprocess_image: null pointer");
+    if (h <= 0 || w <= 0 || dst_w <= 0 || dst_h <= 0 || channels < 1 || channels > 4 || stride < w * channels)
+        CT_FAIL_ARG("ct_preprocess_image: bad shape");
+    double M[6];
+    ct_affine_inverse(trans, M);
 
     const int AB_BITS = 10, AB_SCALE = 1 << AB_BITS, INTER_BITS = 5, INTER_TAB_SIZE = 1 << INTER_BITS;
     const int round_delta = AB_SCALE / INTER_TAB_SIZE / 2;

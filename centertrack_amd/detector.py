@@ -131,6 +131,12 @@ class StreamDetector(object):
                      for _ in range(self.B)] if self.native else None
         self._last_dets = None
         self.started = [False] * self.B
+        # device-side pre-processing of raw u8 frames (ct_preprocess_device): normalisation table + staging buffers
+        lut = np.empty((3, 256), np.float32)
+        mean, std = np.ascontiguousarray(MEAN.reshape(-1)), np.ascontiguousarray(STD.reshape(-1))
+        _lib.check(_lib.load().ct_preprocess_lut(mean.ctypes.data, std.ctypes.data, 3, lut.ctypes.data), 'ct_preprocess_lut')
+        self._lut = torch.from_numpy(lut).to(self.device)
+        self._raw_bufs = {}
         self.gather_fn = None      # optional hook: called with the packed device rows [B,K,F] (multi-GPU all-gather)
         self._ctx = None
 
@@ -231,6 +237,31 @@ class StreamDetector(object):
         self._ctx = ctx
         return ctx
 
+    def _warp_frame(self, s, image, meta, frames, H, W):
+        """upload the raw u8 frame of stream ``s`` and warp / normalise it into ``frames[s]`` (and the mirrored copy
+        into ``frames[B + s]`` under flip_test) on the device: detector.py:218-226 without the host warp"""
+        lib = _lib.load()
+        if image.dtype != np.uint8 or image.ndim != 3 or image.shape[2] != 3:
+            raise _lib.CTError('raw frames must be uint8 HxWx3 (got %s %s)' % (image.dtype, image.shape))
+        h, w, c = image.shape
+        if (int(meta['inp_height']), int(meta['inp_width'])) != (H, W):
+            raise _lib.CTError('all streams of a step must share the network input size')
+        need = h * w * c
+        bufs = self._raw_bufs.get(s)
+        if bufs is None or bufs[0].numel() < need:
+            bufs = (torch.empty(need, dtype=torch.uint8).pin_memory(),
+                    torch.empty(need, dtype=torch.uint8, device=self.device))
+            self._raw_bufs[s] = bufs
+        host, dev = bufs
+        host.numpy()[:need].reshape(h, w, c)[...] = image      # (pinned staging: the H2D below is a plain DMA)
+        st = _lib.stream_ptr()
+        _lib.check(lib.ct_memcpy_async(dev.data_ptr(), host.data_ptr(), need, 1, st), 'H2D')
+        trans = np.ascontiguousarray(meta['trans_input'], np.float64)
+        _lib.check(lib.ct_preprocess_device(dev.data_ptr(), h, w, w * c, c, trans.ctypes.data, W, H,
+                                            self._lut.data_ptr(), frames[s].data_ptr(),
+                                            frames[self.B + s].data_ptr() if self.flip else None, st),
+                   'ct_preprocess_device')
+
     def _flip_merge(self, outs, merged):
         """detector.py:311-332 (non-pose heads), for [B originals ; B flipped]."""
         B = self.B
@@ -248,18 +279,29 @@ class StreamDetector(object):
 
     # ---- one frame for every stream -------------------------------------------------------
     def step(self, images, metas, timers=None):
-        """images: float32 [B,3,H,W] (already normalised, like PrefetchDataset hands over);
+        """images: float32 [B,3,H,W] (already normalised, like PrefetchDataset hands over), or a list of B raw
+        uint8 HxWx3 frames, which are uploaded as bytes and warped / normalised on the device
+        (``ct_preprocess_device``, bit-identical to ``Detector.pre_process``);
         metas: list of B ``meta`` dicts (image.make_meta).  Returns a list of B result lists."""
         opt = self.opt
         t0 = time.time()
         B = self.B
-        assert images.shape[0] == B and len(metas) == B
-        H, W = int(images.shape[2]), int(images.shape[3])
+        raw_frames = isinstance(images, (list, tuple))
+        assert len(images) == B and len(metas) == B
+        if raw_frames:
+            H, W = int(metas[0]['inp_height']), int(metas[0]['inp_width'])
+        else:
+            H, W = int(images.shape[2]), int(images.shape[3])
         ctx = self._context(H, W)
         x_in, img_in, hm_in = ctx['plan']['inputs']
-        if self.flip:
-            images = torch.cat((images, torch.flip(images, [3])), 0)
-        x_dev = images if images.device == self.device else images.to(self.device, non_blocking=True)
+        if raw_frames:
+            x_dev = ctx['frames'][ctx['parity'] if img_in is not None else 0]
+            for s in range(B):
+                self._warp_frame(s, images[s], metas[s], x_dev, H, W)
+        else:
+            if self.flip:
+                images = torch.cat((images, torch.flip(images, [3])), 0)
+            x_dev = images if images.device == self.device else images.to(self.device, non_blocking=True)
         tracking = bool(getattr(opt, 'tracking', False))
         if tracking:
             for s in range(B):
@@ -270,7 +312,7 @@ class StreamDetector(object):
                             raise _lib.CTError('pre_dets need the Python host path: build the detector with native_host=False')
                         self.native, self.fast = False, None
                         self._ctx = None
-                        return self.step(images[:B], metas, timers)
+                        return self.step(images if raw_frames else images[:B], metas, timers)
                     if not self.native:
                         self.trackers[s].init_track(pre_dets)
             if img_in is not None:
@@ -304,7 +346,9 @@ class StreamDetector(object):
                 self.started[s] = True
         par = ctx['parity'] if img_in is not None else 0
         fr = ctx['frames'][par]
-        if ctx['raw'] and x_dev.is_contiguous() and x_dev.dtype == torch.float32 and x_dev.shape == fr.shape:
+        if x_dev is fr:
+            pass                                               # (raw frames were warped straight into it)
+        elif ctx['raw'] and x_dev.is_contiguous() and x_dev.dtype == torch.float32 and x_dev.shape == fr.shape:
             _lib.load().ct_memcpy_async(fr.data_ptr(), x_dev.data_ptr(), fr.numel() * 4, 0, _lib.stream_ptr())
         else:
             fr.copy_(x_dev)
@@ -415,13 +459,8 @@ class Detector(object):
         import ctypes
         opt = self.opt
         image = np.ascontiguousarray(image)
-        if image.dtype != np.uint8 or image.ndim != 3:
-            raise _lib.CTError('pre_process expects a uint8 HxWxC image (got %s %s)' % (image.dtype, image.shape))
         height, width, ch = image.shape
-        meta = make_meta(getattr(opt, 'input_h', -1), getattr(opt, 'input_w', -1), height, width,
-                         down_ratio=getattr(opt, 'down_ratio', 4), calib=input_meta.get('calib'),
-                         focal_length=self.rest_focal_length, fix_res=bool(getattr(opt, 'fix_res', True)),
-                         fix_short=getattr(opt, 'fix_short', 0), pad=getattr(opt, 'pad', 31))
+        meta = self.frame_meta(image, input_meta)
         inp_h, inp_w = meta['inp_height'], meta['inp_width']
         flip = bool(getattr(opt, 'flip_test', False))
         out = np.empty((2 if flip else 1, ch, inp_h, inp_w), np.float32)
@@ -433,11 +472,24 @@ class Detector(object):
             trans.ctypes.data_as(ctypes.c_void_p), inp_w, inp_h, mean.ctypes.data_as(ctypes.c_void_p),
             std.ctypes.data_as(ctypes.c_void_p), out.ctypes.data_as(ctypes.c_void_p), 1 if flip else 0),
             'ct_preprocess_image')
+        return torch.from_numpy(out), meta
+
+    def frame_meta(self, image, input_meta={}):
+        """the ``meta`` dict of detector.py:207-217,227-239 for a raw frame (c, s, trans_input, trans_output, calib,
+        sizes; ``pre_dets`` / ``cur_dets`` carried over) -- everything pre_process returns except the pixels"""
+        opt = self.opt
+        if image.dtype != np.uint8 or image.ndim != 3:
+            raise _lib.CTError('pre_process expects a uint8 HxWxC image (got %s %s)' % (image.dtype, image.shape))
+        height, width = image.shape[:2]
+        meta = make_meta(getattr(opt, 'input_h', -1), getattr(opt, 'input_w', -1), height, width,
+                         down_ratio=getattr(opt, 'down_ratio', 4), calib=input_meta.get('calib'),
+                         focal_length=self.rest_focal_length, fix_res=bool(getattr(opt, 'fix_res', True)),
+                         fix_short=getattr(opt, 'fix_short', 0), pad=getattr(opt, 'pad', 31))
         if 'pre_dets' in input_meta:
             meta['pre_dets'] = input_meta['pre_dets']
         if 'cur_dets' in input_meta:
             meta['cur_dets'] = input_meta['cur_dets']
-        return torch.from_numpy(out), meta
+        return meta
 
     def run(self, image_or_path_or_tensor, meta={}):
         start = time.time()
@@ -453,11 +505,14 @@ class Detector(object):
         elif torch.is_tensor(x):
             images = x
         elif isinstance(x, np.ndarray):                        # raw BGR frame (demo.py / README embedding)
-            images, meta = self.pre_process(x, 1.0, meta)
+            if getattr(self.opt, 'device_pre_process', True) and x.ndim == 3 and x.shape[2] == 3:
+                images, meta = [x], self.frame_meta(x, meta)   # u8 upload + warp on the device
+            else:
+                images, meta = self.pre_process(x, 1.0, meta)
         else:
             raise _lib.CTError('run() takes a uint8 image array, a normalised tensor + meta, or a pre-processed '
                                'dict; reading image files (cv2.imread) is left to the caller')
-        if images.shape[0] == 2 and self.impl.flip:
+        if torch.is_tensor(images) and images.shape[0] == 2 and self.impl.flip:
             images = images[0:1]                               # the flipped copy is rebuilt on device
         loaded = time.time()
         timers = {}

@@ -225,6 +225,18 @@ int ct_stream_synchronize(void *stream);
 int ct_preprocess_image(const uint8_t *img, int h, int w, int stride, int channels, const double *trans,
                         int dst_w, int dst_h, const float *mean, const float *stdv, float *out, int flip_copy);
 
+/* ---- the same pre-processing on the device (no reference equivalent: there the warp
+ * is cv2 on the CPU and the fp32 result is uploaded, detector.py:218-226,338).  A raw u8 frame is uploaded
+ * instead and warped / normalised / transposed (+ mirrored) by one kernel; results are bit-identical to
+ * ct_preprocess_image.  img: DEVICE u8 [h, w, channels] (row pitch `stride` bytes); trans: HOST float64 [2,3]
+ * trans_input; lut: DEVICE fp32 [channels][256], the normalisation table ct_preprocess_lut fills on the HOST
+ * (lut[c][v] = float(((double)v / 255. - mean[c]) / std[c])); out: DEVICE fp32 [channels, dst_h, dst_w];
+ * out_flip: optional DEVICE plane set of the same shape that receives the left-right mirrored copy
+ * (flip_test, detector.py:225-226) or NULL. */
+int ct_preprocess_lut(const float *mean, const float *stdv, int channels, float *lut_host);
+int ct_preprocess_device(const uint8_t *img, int h, int w, int stride, int channels, const double *trans,
+                         int dst_w, int dst_h, const float *lut, float *out, float *out_flip, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

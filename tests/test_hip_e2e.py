@@ -112,8 +112,9 @@ def test_flip_test_runs_and_matches_oracle(device):
 
 
 def test_run_on_raw_uint8_frames(device):
-    """Detector.run(ndarray) = pre_process (host) + the hot path: same tracks as the oracle fed with the
-    oracle's own restatement of the pre-processing."""
+    """Detector.run(ndarray) = u8 upload + device pre-processing (ct_preprocess_device) + the hot path: the
+    warped frame is bit-identical to the oracle's restatement of the pre-processing and to the host
+    pre_process, and the tracks equal the oracle's and those of a detector that pre-processes on the host."""
     from centertrack_amd import scenarios as S
     from centertrack_amd.detector import MEAN, STD, Detector, default_opt
     from centertrack_amd.model import DLASegHIP
@@ -125,6 +126,9 @@ def test_run_on_raw_uint8_frames(device):
     model = DLASegHIP(cfg['heads'])
     model.load_state_dict(sd)
     det = Detector(opt, model=model)
+    opt_host = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
+                           input_h=cfg['H'], input_w=cfg['W'], device_pre_process=False)
+    det_host = Detector(opt_host, model=model)
     oracle = odet.Detector(odet.default_opt(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
                                             input_h=cfg['H'], input_w=cfg['W']), sd, cfg['heads'])
     rs = np.random.RandomState(5)
@@ -135,6 +139,41 @@ def test_run_on_raw_uint8_frames(device):
         images, meta = det.pre_process(frame, 1.0)
         want_img = oimage.pre_process_image(frame, meta['trans_input'], cfg['W'], cfg['H'], MEAN, STD)
         np.testing.assert_array_equal(images.numpy(), want_img)
+        ctx = det.impl._ctx
+        np.testing.assert_array_equal(ctx['frames'][ctx['parity'] ^ 1].cpu().numpy(), want_img)   # device warp
         want = oracle.run(torch.from_numpy(want_img), dict(meta))
         assert len(want) > 0
         _check_frame(ret['results'], want, t, 'raw frames')
+        ret_host = det_host.run(frame)
+        assert [(r['tracking_id'], float(r['score']), list(map(float, r['bbox']))) for r in ret['results']] == \
+               [(r['tracking_id'], float(r['score']), list(map(float, r['bbox']))) for r in ret_host['results']]
+
+
+def test_raw_frame_streams_with_flip_equal_host_preprocessed_streams(device):
+    """2 streams x flip_test fed with raw u8 frames (device warp + mirrored copy) == the same streams fed with
+    the host pre_process output: identical ids, scores and boxes (the device frame buffers are bit-identical)."""
+    from centertrack_amd import weights as W
+    from centertrack_amd.detector import Detector, StreamDetector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    heads = W.KITTI_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=9, hm_gain=14.0)
+    opt = default_opt(heads, track_thresh=0.4, flip_test=True, input_h=64, input_w=160)
+    model = DLASegHIP(heads)
+    model.load_state_dict(sd)
+    B = 2
+    dev_det = StreamDetector(opt, model=model, num_streams=B)
+    host_det = StreamDetector(opt, model=model, num_streams=B)
+    helper = Detector(opt, model=model)
+    rs = np.random.RandomState(11)
+    base = rs.randint(0, 256, (2, 375, 1242 + 32, 3)).astype(np.uint8)
+    for t in range(3):
+        frames = [base[s][:, 8 * t:8 * t + 1242] for s in range(B)]           # (non-contiguous views)
+        pre = [helper.pre_process(f, 1.0) for f in frames]
+        metas = [dict(m) for _, m in pre]
+        got = dev_det.step(frames, [dict(m) for m in metas])
+        want = host_det.step(torch.cat([p[0][0:1] for p in pre], 0), metas)
+        cd, ch = dev_det._ctx, host_det._ctx
+        assert torch.equal(cd['frames'][cd['parity'] ^ 1], ch['frames'][ch['parity'] ^ 1])
+        for s in range(B):
+            assert [(int(r['tracking_id']), float(r['score'])) + tuple(map(float, r['bbox'])) for r in got[s]] == \
+                   [(int(r['tracking_id']), float(r['score'])) + tuple(map(float, r['bbox'])) for r in want[s]]

@@ -484,3 +484,74 @@ def test_render_pre_hm_matches_reference_golden(device, golden_dir):
         got = out.cpu().numpy()
         assert np.abs(got - ref).max() <= 1e-6, case['name']
         assert (got != ref).mean() < 1e-4
+
+
+# ---- device-side pre-processing ----------------------------------------------------
+def _preprocess_device(img, trans, dw, dh, flip, device):
+    from centertrack_amd import _lib
+    from centertrack_amd.detector import MEAN, STD
+    lib = _lib.load()
+    lut = np.empty((3, 256), np.float32)
+    mean, std = np.ascontiguousarray(MEAN.reshape(-1)), np.ascontiguousarray(STD.reshape(-1))
+    _lib.check(lib.ct_preprocess_lut(mean.ctypes.data, std.ctypes.data, 3, lut.ctypes.data))
+    lut_d = torch.from_numpy(lut).to(device)
+    img_d = torch.from_numpy(np.ascontiguousarray(img)).to(device)
+    out = torch.full((2 if flip else 1, 3, dh, dw), float('nan'), device=device)
+    trans = np.ascontiguousarray(trans, np.float64)
+    _lib.check(lib.ct_preprocess_device(img_d.data_ptr(), img.shape[0], img.shape[1], img.shape[1] * 3, 3,
+                                        trans.ctypes.data, dw, dh, lut_d.data_ptr(), out[0].data_ptr(),
+                                        out[1].data_ptr() if flip else None, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    return out.cpu().numpy()
+
+
+@pytest.mark.parametrize('h,w,inp_h,inp_w,flip', [(360, 480, 128, 160, False), (375, 1242, 96, 320, True),
+                                                   (120, 90, 64, 64, False), (33, 47, 64, 96, True),
+                                                   (1080, 1920, 544, 960, False), (37, 53, 37, 53, True)])
+def test_preprocess_device_is_bit_identical_to_oracle_and_host(device, h, w, inp_h, inp_w, flip):
+    """ct_preprocess_device == oracle/image.pre_process_image (numpy restatement of cv2.warpAffine + normalise)
+    == ct_preprocess_image (host), bit for bit; reference crop, a rotated / sheared map (negative coordinates,
+    all four border cases) and an up-scaling map."""
+    import ctypes
+    from centertrack_amd import _lib
+    from centertrack_amd.detector import MEAN, STD
+    from centertrack_amd.image import get_affine_transform, make_meta
+    from oracle import image as oimage
+    rs = np.random.RandomState(h + w)
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    meta = make_meta(inp_h, inp_w, h, w)
+    rot = get_affine_transform(np.array([w / 2., h / 2.], np.float32), max(h, w) * 0.7, 25, [inp_w, inp_h])
+    zoom = get_affine_transform(np.array([w / 3., h / 2.], np.float32), max(h, w) * 0.11, -7, [inp_w, inp_h])
+    for tag, t in (('crop', meta['trans_input']), ('rot', rot), ('zoom', zoom)):
+        got = _preprocess_device(img, t, inp_w, inp_h, flip, device)
+        want = oimage.pre_process_image(img, t, inp_w, inp_h, MEAN, STD, flip)
+        np.testing.assert_array_equal(got, want, err_msg=tag)
+        host = np.empty(want.shape, np.float32)            # (want may be a strided view: no empty_like)
+        t64 = np.ascontiguousarray(t, np.float64)
+        mean, std = np.ascontiguousarray(MEAN.reshape(-1)), np.ascontiguousarray(STD.reshape(-1))
+        _lib.check(_lib.load().ct_preprocess_image(img.ctypes.data_as(ctypes.c_void_p), h, w, img.strides[0], 3,
+                                                   t64.ctypes.data_as(ctypes.c_void_p), inp_w, inp_h,
+                                                   mean.ctypes.data_as(ctypes.c_void_p), std.ctypes.data_as(ctypes.c_void_p),
+                                                   host.ctypes.data_as(ctypes.c_void_p), int(flip)))
+        np.testing.assert_array_equal(got, host, err_msg=tag + ' (host)')
+
+
+def test_preprocess_device_known_answers(device):
+    """identity and integer shifts copy pixels exactly; a half-pixel shift rounds to nearest (test_preprocess.py)"""
+    from centertrack_amd.detector import MEAN, STD
+    norm = lambda u8: ((u8 / 255. - MEAN) / STD).astype(np.float32).transpose(2, 0, 1)[None]
+    rs = np.random.RandomState(0)
+    img = rs.randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    ident = np.array([[1, 0, 0], [0, 1, 0]], np.float64)
+    np.testing.assert_array_equal(_preprocess_device(img, ident, 53, 37, False, device), norm(img))
+    shift = np.array([[1, 0, 5], [0, 1, -3]], np.float64)
+    want = np.zeros_like(img)
+    want[:37 - 3, 5:] = img[3:, :53 - 5]
+    np.testing.assert_array_equal(_preprocess_device(img, shift, 53, 37, False, device), norm(want))
+    img2 = np.zeros((4, 6, 3), np.uint8)
+    img2[:, ::2] = 10
+    img2[:, 1::2] = 13
+    half = np.array([[1, 0, 0.5], [0, 1, 0]], np.float64)
+    want2 = np.full((4, 6, 3), 12, np.uint8)
+    want2[:, 0] = 5
+    np.testing.assert_array_equal(_preprocess_device(img2, half, 6, 4, False, device), norm(want2))

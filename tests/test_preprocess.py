@@ -75,6 +75,7 @@ def test_detector_pre_process_returns_the_reference_contract():
     fake = types.SimpleNamespace(opt=types.SimpleNamespace(input_h=128, input_w=160, down_ratio=4, fix_res=True,
                                                            fix_short=0, pad=31, flip_test=True),
                                  mean=MEAN, std=STD, rest_focal_length=1200)
+    fake.frame_meta = lambda image, im={}: Detector.frame_meta(fake, image, im)
     img = np.random.RandomState(3).randint(0, 256, (360, 480, 3)).astype(np.uint8)
     images, meta = Detector.pre_process(fake, img, 1.0, {'pre_dets': []})
     assert isinstance(images, torch.Tensor) and images.dtype == torch.float32 and tuple(images.shape) == (2, 3, 128, 160)
@@ -84,3 +85,15 @@ def test_detector_pre_process_returns_the_reference_contract():
         assert k in meta
     want = oimage.pre_process_image(img, meta['trans_input'], 160, 128, MEAN, STD, True)
     np.testing.assert_array_equal(images.numpy(), want)
+
+
+def test_normalisation_table_matches_the_float64_expression():
+    """ct_preprocess_lut (host; feeds the device kernel): lut[c][v] == float32((v / 255. - mean) / std)"""
+    lib = _lib.load()
+    lut = np.empty((3, 256), np.float32)
+    mean, std = np.ascontiguousarray(MEAN.reshape(-1)), np.ascontiguousarray(STD.reshape(-1))
+    assert lib.ct_preprocess_lut(mean.ctypes.data, std.ctypes.data, 3, lut.ctypes.data) == 0
+    v = np.arange(256, dtype=np.uint8).reshape(256, 1, 1).repeat(3, 2)          # "image" of 256 x 1 pixels
+    want = ((v / 255. - MEAN) / STD).astype(np.float32)[:, 0, :].T
+    np.testing.assert_array_equal(lut, want)
+    assert lib.ct_preprocess_lut(mean.ctypes.data, std.ctypes.data, 9, lut.ctypes.data) != 0
