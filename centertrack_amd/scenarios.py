@@ -228,3 +228,42 @@ def e2e_frames(cfg):
     for t in range(cfg['T']):
         img = base[:, :, 4 * t:4 * t + cfg['W']].contiguous().unsqueeze(0)
         yield img, dict(meta)
+
+
+def writer_case(seed=23):
+    """Synthetic tracking results of 2 videos (4 + 3 frames) for the result-writer tests: image-id keyed dict of
+    item lists like ``test.py`` collects (``results[img_id] = ret['results']``, test.py:99-110), the
+    ``videos`` / ``video_to_images`` tables the dataset classes hold (generic_dataset.py:590-602), KITTI class
+    names.  Items carry float32 numpy values like the post-process emits; some are inactive, ids are not
+    contiguous, the 3D fields are present on a few."""
+    rs = np.random.RandomState(seed)
+    videos = [{'id': 1, 'file_name': 'MOT17-02-FRCNN'}, {'id': 2, 'file_name': '0004'}]
+    video_to_images = {1: [], 2: []}
+    results = {}
+    img_id = 100
+    for vid, nframes in ((1, 4), (2, 3)):
+        ids = [7, 3, 12, 40]
+        for fidx in range(nframes):
+            img_id += 1
+            video_to_images[vid].append({'id': img_id, 'frame_id': fidx + 1, 'video_id': vid})
+            if vid == 1 and fidx == 2:
+                continue                                   # an image without results is skipped by the writers
+            items = []
+            for j, tid in enumerate(ids):
+                x0, y0 = rs.uniform(-20, 900), rs.uniform(-10, 500)
+                bw, bh = rs.uniform(5, 200), rs.uniform(5, 300)
+                it = {'score': np.float32(rs.uniform(0.3, 1.0)), 'class': int(rs.randint(1, 4)),
+                      'ct': np.array([x0 + bw / 2, y0 + bh / 2], np.float32),
+                      'tracking': rs.uniform(-3, 3, 2).astype(np.float32),
+                      'bbox': np.array([x0, y0, x0 + bw, y0 + bh], np.float32),
+                      'tracking_id': tid, 'age': 1, 'active': int(not (j == 1 and fidx == 1))}
+                if vid == 2 and j % 2 == 0:
+                    it.update({'dep': rs.uniform(3, 60, 1).astype(np.float32), 'alpha': float(rs.uniform(-3, 3)),
+                               'dim': rs.uniform(-0.5, 4, 3).astype(np.float32),
+                               'loc': rs.uniform(-30, 60, 3).astype(np.float32), 'rot_y': float(rs.uniform(-3, 3))})
+                items.append(it)
+            if fidx == 1:
+                ids = ids[:-1] + [55]                      # a track ends, a new id appears
+            results[img_id] = items
+    return {'videos': videos, 'video_to_images': video_to_images, 'results': results,
+            'kitti_class_name': ['Pedestrian', 'Car', 'Cyclist']}

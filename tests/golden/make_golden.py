@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 from centertrack_amd import weights as W  # noqa: E402
 from centertrack_amd.scenarios import (decode_cases, make_head_maps, postprocess_cases,  # noqa: E402
-                                        tracker_sequences, e2e_config)
+                                        tracker_sequences, e2e_config, writer_case)
 
 torch.set_num_threads(8)
 
@@ -182,8 +182,41 @@ def gen_pre_hm():
     print('pre_hm.npz', {k: v.shape for k, v in out.items()})
 
 
+def gen_writers():
+    """MOT.save_results (datasets/mot.py:52-83) and KITTITracking.save_results (datasets/kitti_tracking.py:51-97) of
+    the reference, run unmodified on writer_case(); pycocotools is stubbed (only imported, not used by the writers)"""
+    import copy
+    import tempfile
+    import types
+    for name in ('pycocotools', 'pycocotools.coco', 'pycocotools.cocoeval'):
+        m = types.ModuleType(name)
+        m.COCO = object
+        m.COCOeval = object
+        sys.modules[name] = m
+    sys.modules['cv2'].__dict__.setdefault('imread', None)
+    from dataset.datasets.mot import MOT
+    from dataset.datasets.kitti_tracking import KITTITracking
+    case = writer_case()
+    out = {}
+    for tag, cls, extra in (('mot', MOT, {'dataset_version': '17halfval'}),
+                            ('kitti', KITTITracking, {'class_name': case['kitti_class_name']})):
+        fake = types.SimpleNamespace(coco=types.SimpleNamespace(dataset={'videos': case['videos']}),
+                                     video_to_images=case['video_to_images'], **extra)
+        with tempfile.TemporaryDirectory() as d:
+            cls.save_results(fake, copy.deepcopy(case['results']), d)
+            files = {}
+            for root, _, names in os.walk(d):
+                for n in names:
+                    with open(os.path.join(root, n)) as f:
+                        files[os.path.relpath(os.path.join(root, n), d)] = f.read()
+        out[tag] = files
+    with open(os.path.join(HERE, 'writers.json'), 'w') as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print('writers.json', {k: {n: len(t.splitlines()) for n, t in v.items()} for k, v in out.items()})
+
+
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e']
+    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers']
     if 'model' in which:
         gen_model()
     if 'decode' in which:
@@ -196,3 +229,5 @@ if __name__ == '__main__':
         gen_pre_hm()
     if 'e2e' in which:
         gen_e2e()
+    if 'writers' in which:
+        gen_writers()

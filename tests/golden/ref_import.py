@@ -46,7 +46,7 @@ def install():
         sys.path.insert(0, lib)
     from oracle.image import get_affine_transform_3pt
     from oracle import dcn_v2 as oracle_dcn
-    from oracle.tracker import linear_assignment
+    from oracle.tracker import hungarian_assignment as linear_assignment
 
     def mod(name, **attrs):
         m = types.ModuleType(name)
