@@ -60,7 +60,20 @@ class DecodeDesc(ctypes.Structure):
                 ('heads', ctypes.c_void_p * NUM_HEADS),
                 ('out', ctypes.c_void_p), ('inds', ctypes.c_void_p),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
-                ('hm_batch_stride', ctypes.c_size_t), ('head_batch_stride', ctypes.c_size_t * NUM_HEADS)]
+                ('hm_batch_stride', ctypes.c_size_t), ('head_batch_stride', ctypes.c_size_t * NUM_HEADS),
+                ('out_stride', ctypes.c_int)]
+
+
+class PoseDesc(ctypes.Structure):
+    _fields_ = [('rows', ctypes.c_void_p), ('row_floats', ctypes.c_int), ('box_col', ctypes.c_int),
+                ('inds', ctypes.c_void_p),
+                ('B', ctypes.c_int), ('h', ctypes.c_int), ('w', ctypes.c_int), ('K', ctypes.c_int),
+                ('num_joints', ctypes.c_int),
+                ('hps', ctypes.c_void_p), ('hm_hp', ctypes.c_void_p), ('hp_offset', ctypes.c_void_p),
+                ('hps_batch_stride', ctypes.c_size_t), ('hm_hp_batch_stride', ctypes.c_size_t),
+                ('hp_offset_batch_stride', ctypes.c_size_t),
+                ('out', ctypes.c_void_p), ('out_stride', ctypes.c_int),
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
 class RowLayout(ctypes.Structure):
@@ -78,7 +91,8 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
            'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
-           'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_render_pre_hm',
+           'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_decode_pose_workspace_bytes',
+           'ct_decode_pose', 'ct_render_pre_hm',
            'ct_tracker_create', 'ct_tracker_destroy', 'ct_tracker_reset', 'ct_tracker_num_tracks',
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
@@ -126,6 +140,9 @@ def load():
     lib.ct_decode_workspace_bytes.restype = sz
     lib.ct_decode_workspace_bytes.argtypes = [ctypes.POINTER(DecodeDesc)]
     lib.ct_decode.argtypes = [ctypes.POINTER(DecodeDesc), p]
+    lib.ct_decode_pose_workspace_bytes.restype = sz
+    lib.ct_decode_pose_workspace_bytes.argtypes = [ctypes.POINTER(PoseDesc)]
+    lib.ct_decode_pose.argtypes = [ctypes.POINTER(PoseDesc), p]
     lib.ct_render_pre_hm.argtypes = [p, p, i, i, i, i, p, i, p]
     lib.ct_tracker_create.restype = p
     lib.ct_tracker_create.argtypes = [ctypes.c_float, i]

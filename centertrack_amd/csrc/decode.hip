@@ -507,7 +507,8 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     a2.hm_bs = a1.hm_bs;
     a2.out = d->out; a2.inds = (long long *)d->inds;
     a2.B = d->B; a2.C = d->C; a2.h = d->h; a2.w = d->w; a2.K = d->K; a2.nseg = nseg;
-    a2.F = ct_decode_row_floats(d);
+    a2.F = d->out_stride ? d->out_stride : ct_decode_row_floats(d);   // floats between consecutive rows
+    if (a2.F < ct_decode_row_floats(d)) CT_FAIL_ARG("ct_decode: out_stride %d < row floats", d->out_stride);
     const long M2 = (long)d->C * nseg * d->K;
     hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(M2 <= 2048 ? 256 : 1024), 0, s, a2);
     CT_CHECK_LAUNCH("ct_decode(stage 2)");

@@ -1,7 +1,8 @@
 """Drop-in for ``generic_decode`` (SURVEY.md boundary B3).
 
 ``generic_decode(output, K=100, opt=None) -> dict`` follows src/lib/model/decode.py:83-182
-(non-pose branches) with its helpers ``_nms`` / ``_topk`` / ``_tranpose_and_gather_feat``
+(incl. the pose branch :161-171 = ``_update_kps_with_hm`` + ``_topk_channel``, through
+``ct_decode_pose``) with its helpers ``_nms`` / ``_topk`` / ``_tranpose_and_gather_feat``
 (src/lib/model/utils.py:16-87): same keys, shapes and dtypes (``clses`` is float32,
 decode.py:100), ``output['tracking'] *= 0`` in place under ``opt.zero_tracking``, ``{}``
 when there is no ``'hm'``.  Underneath it is ONE ``ct_decode`` call (3x3 max NMS + exact
@@ -15,15 +16,12 @@ import torch
 
 from . import _lib, ops
 
-_UNSUPPORTED = ('hps', 'hm_hp', 'hp_offset')      # multi_pose branch, decode.py:161-171
+_POSE_HEADS = ('hps', 'hm_hp', 'hp_offset')        # multi_pose branch, decode.py:161-171
 
 
 def generic_decode(output, K=100, opt=None):
     if 'hm' not in output:
         return {}
-    for k in _UNSUPPORTED:
-        if k in output:
-            raise _lib.CTError('generic_decode: the pose head %r is not implemented on the HIP path' % k)
     if opt is not None and getattr(opt, 'zero_tracking', False):
         output['tracking'] *= 0
     hm = output['hm']
@@ -33,6 +31,9 @@ def generic_decode(output, K=100, opt=None):
         ok = t.stride(3) == 1 and t.stride(2) == t.shape[3] and (t.shape[1] == 1 or t.stride(1) == t.shape[2] * t.shape[3])
         return t if ok else t.contiguous()
     heads = {k: planes(v) for k, v in output.items() if k in _lib.HEAD_INDEX}
+    if 'hps' in output:
+        heads.update({k: (output[k].contiguous() if k == 'hm_hp' else planes(output[k])) for k in _POSE_HEADS
+                      if k in output})
     dec = ops.Decoder(planes(hm), heads, K)
     packed = dec.run()
     ret = dec.unpack(packed)

@@ -35,6 +35,8 @@ STD = np.array([0.28863828, 0.27408164, 0.27809835], dtype=np.float32).reshape(1
 REST_FOCAL_LENGTH = {'nuscenes': 1200, 'kitti': 721.5377, 'kitti_tracking': 721.5377}
 AVERAGE_FLIPS = ('hm', 'wh', 'dep', 'dim')
 NEG_AVERAGE_FLIPS = ('amodel_offset',)
+# left/right joint pairs of the COCO person key points (datasets/coco_hp.py:18-19)
+COCO_FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]
 
 
 def trans_bbox(bbox, trans, width, height):
@@ -126,7 +128,8 @@ class StreamDetector(object):
         # the reference-shaped Python path serves the Hungarian / public-detection / pre_dets branches
         self.native = bool(native_host and getattr(opt, 'tracking', False) and 'tracking' in opt.heads
                            and not getattr(opt, 'hungarian', False) and not getattr(opt, 'public_det', False)
-                           and not getattr(opt, 'zero_pre_hm', False))
+                           and not getattr(opt, 'zero_pre_hm', False)
+                           and 'hps' not in opt.heads)         # (key points ride on the Python host path)
         self.fast = [fast_track.FastTracker(opt.new_thresh, getattr(opt, 'max_age', -1), opt.K)
                      for _ in range(self.B)] if self.native else None
         self._last_dets = None
@@ -272,6 +275,19 @@ class StreamDetector(object):
             elif head in NEG_AVERAGE_FLIPS:
                 f = torch.flip(v[B:], [3])
                 f[:, 0::2] *= -1
+                torch.add(v[:B], f, out=merged[head])
+                merged[head].div_(2)
+            elif head in ('hps', 'hm_hp'):                     # flip_lr_off / flip_lr, model/utils.py:33-50
+                f = torch.flip(v[B:], [3])
+                perm = list(range(f.shape[1] // (2 if head == 'hps' else 1)))
+                for a, b in getattr(self.opt, 'flip_idx', COCO_FLIP_IDX):
+                    perm[a], perm[b] = perm[b], perm[a]
+                if head == 'hps':
+                    f = f.reshape(f.shape[0], -1, 2, f.shape[2], f.shape[3])[:, perm]
+                    f[:, :, 0] *= -1
+                    f = f.reshape(v[B:].shape)
+                else:
+                    f = f[:, perm]
                 torch.add(v[:B], f, out=merged[head])
                 merged[head].div_(2)
             else:

@@ -324,13 +324,13 @@ class DLASegHIP(torch.nn.Module):
         c0 = 0
         outputs = OrderedDict()
         for hname, c in self.heads.items():
-            if fuse_sigmoid and hname == 'hm':
+            if fuse_sigmoid and hname == 'hm':                 # (hm_hp -> per-head tail below: one sigmoid range per launch)
                 sig = (c0, c0 + c)
             if fuse_sigmoid and hname == 'dep':
                 dep = (c0, c0 + c)
             outputs[hname] = comb[:, c0:c0 + c]            # channel-slice views of the combined tensor
             c0 += c
-        if ctot <= 32:
+        if ctot <= 32 and 'hm_hp' not in self.heads:
             # few output channels (MOT 11, KITTI 9, nuScenes 30): one block-diagonal conv over the whole intermediate
             d = ops.make_conv_desc(mid, P['head2_w'], ctot, 1, 1, shift=P['head2_b'], out_nchw=comb, sig=sig, dep=dep,
                                    depth_scale=self.depth_scale)
@@ -343,7 +343,7 @@ class DLASegHIP(torch.nn.Module):
             for j, (hname, c) in enumerate(self.heads.items()):
                 o = torch.empty((N, c, feat.H, feat.W), device=dev)
                 wp, b = P[hname + '.2']
-                hsig = (0, c) if (fuse_sigmoid and hname == 'hm') else (0, 0)
+                hsig = (0, c) if (fuse_sigmoid and hname in ('hm', 'hm_hp')) else (0, 0)   # detector.py:300-304
                 hdep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
                 d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=hsig, dep=hdep,
                                        depth_scale=self.depth_scale)

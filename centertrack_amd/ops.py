@@ -229,7 +229,9 @@ def decode_layout(head_names):
 
 
 class Decoder(object):
-    """Pre-built ct_decode call for fixed shapes (graph-capture friendly)."""
+    """Pre-built ct_decode call (+ ct_decode_pose when the pose heads ``hps`` / ``hm_hp`` are given) for fixed
+    shapes (graph-capture friendly).  One packed buffer ``out`` [B,K,F]: the rows of ct_decode followed, for the
+    pose task, by the refined key points [2J] and ``kps_score`` [1]."""
 
     def __init__(self, hm, heads, K):
         lib = _lib.load()
@@ -249,7 +251,19 @@ class Decoder(object):
                 d.heads[_lib.HEAD_INDEX[name]] = t.data_ptr()
                 d.head_batch_stride[_lib.HEAD_INDEX[name]] = t.stride(0)
         self.layout, self.F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX])
-        assert lib.ct_decode_row_floats(ctypes.byref(d)) == self.F
+        F0 = self.F
+        assert lib.ct_decode_row_floats(ctypes.byref(d)) == F0
+        self.pose = None
+        if 'hps' in heads:                                 # pose branch, decode.py:161-171
+            J = heads['hps'].shape[1] // 2
+            if 'hm_hp' in heads:
+                if 'ltrb_amodal' in heads or not ({'wh', 'ltrb'} & set(heads)):
+                    raise _lib.CTError('the pose branch needs the wh / ltrb box (decode.py:45-57); box-less and '
+                                       'ltrb_amodal variants are not implemented')
+                self.layout = self.layout + [('hps', F0, 2 * J), ('kps_score', F0 + 2 * J, 1)]
+                self.F = F0 + 2 * J + 1
+            else:                                          # decode.py:80-81: no refinement, kps_score = kps
+                raise _lib.CTError('the pose branch without an hm_hp head is not implemented')
         self.out = torch.empty((B, K, self.F), dtype=torch.float32, device=hm.device)
         self.inds = torch.empty((B, K), dtype=torch.int64, device=hm.device)
         nbytes = lib.ct_decode_workspace_bytes(ctypes.byref(d))
@@ -257,11 +271,31 @@ class Decoder(object):
             _lib.check(1, 'ct_decode_workspace_bytes')
         self.ws = torch.empty(nbytes // 8, dtype=torch.int64, device=hm.device)
         d.out, d.inds = self.out.data_ptr(), self.inds.data_ptr()
+        d.out_stride = self.F
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
         self.desc = d
+        if 'hps' in heads:
+            hps, hm_hp = heads['hps'], heads['hm_hp']
+            off = heads.get('hp_offset', heads.get('reg'))
+            assert planes_ok(hps) and hm_hp.is_contiguous() and hm_hp.shape[1] == J and (off is None or planes_ok(off))
+            pd = _lib.PoseDesc()
+            pd.rows, pd.row_floats, pd.box_col, pd.inds = self.out.data_ptr(), self.F, 4, self.inds.data_ptr()
+            pd.B, pd.h, pd.w, pd.K, pd.num_joints = B, h, w, K, J
+            pd.hps, pd.hm_hp, pd.hp_offset = hps.data_ptr(), hm_hp.data_ptr(), _p(off)
+            pd.hps_batch_stride = hps.stride(0)
+            pd.hp_offset_batch_stride = off.stride(0) if off is not None else 0
+            pd.out, pd.out_stride = self.out.data_ptr() + 4 * F0, self.F
+            pbytes = lib.ct_decode_pose_workspace_bytes(ctypes.byref(pd))
+            if pbytes == 0:
+                _lib.check(1, 'ct_decode_pose_workspace_bytes')
+            self.pose_ws = torch.empty(pbytes // 8 + 1, dtype=torch.int64, device=hm.device)
+            pd.workspace, pd.workspace_bytes = self.pose_ws.data_ptr(), self.pose_ws.numel() * 8
+            self.pose = pd
 
     def run(self):
         _lib.check(_lib.load().ct_decode(ctypes.byref(self.desc), _lib.stream_ptr()), 'ct_decode')
+        if self.pose is not None:
+            _lib.check(_lib.load().ct_decode_pose(ctypes.byref(self.pose), _lib.stream_ptr()), 'ct_decode_pose')
         return self.out
 
     def unpack(self, packed):
@@ -269,6 +303,6 @@ class Decoder(object):
         ret = {}
         for name, s, wd in self.layout:
             v = packed[..., s:s + wd]
-            ret[name] = v[..., 0] if name in ('scores', 'clses', 'xs', 'ys') else v
+            ret[name] = v[..., 0] if name in ('scores', 'clses', 'xs', 'ys', 'kps_score') else v
         ret['cts'] = packed[..., 2:4]
         return ret

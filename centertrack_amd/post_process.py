@@ -2,9 +2,9 @@
 
 Python form of the host step the native path runs in C++ (``ct_tracker_step``); it serves the branches the
 native tracker does not cover (``--hungarian``, ``--public_det``, ``pre_dets``) and every 3D field.  Same
-contract as the reference's ``generic_post_process`` (src/lib/utils/post_process.py:21-91, non-pose heads)
+contract as the reference's ``generic_post_process`` (src/lib/utils/post_process.py:21-91)
 with the 3D helpers of src/lib/utils/ddd_utils.py:91-136: input = the decode dict of numpy arrays
-``[B,K,...]``; output = per image a list of dicts (``score, class, ct, tracking, bbox, [dep, dim, alpha,
+``[B,K,...]``; output = per image a list of dicts (``score, class, ct, tracking, bbox, [hps, dep, dim, alpha,
 loc, rot_y, nuscenes_att, velocity]``) for the detections ahead of the first ``score < out_thresh``.
 Every point goes through the same float32 ``[2,3] @ [3,1]`` product as in the reference, so the values (and
 what the tracker derives from them) are bit-identical.
@@ -25,6 +25,10 @@ class _GridToImage(object):
 
     def box(self, x0y0x1y1):
         return transform_preds_with_trans(np.asarray(x0y0x1y1).reshape(2, 2), self.m).reshape(4)
+
+    def points(self, flat_xy):
+        """[x0,y0,x1,y1,...] -> same layout in image coordinates (key points, post_process.py:51-54)"""
+        return transform_preds_with_trans(np.asarray(flat_xy).reshape(-1, 2), self.m).reshape(-1)
 
 
 def get_alpha(rot):
@@ -87,6 +91,8 @@ def generic_post_process(opt, dets, c, s, h, w, num_classes=None, calibs=None, h
                 item['tracking'] = to_img.point(fields['tracking'][j] + grid_ct) - item['ct']
             if 'bboxes' in fields:
                 item['bbox'] = to_img.box(fields['bboxes'][j])
+            if 'hps' in fields:
+                item['hps'] = to_img.points(fields['hps'][j])
             for k in ('dep', 'dim'):
                 if k in fields:
                     item[k] = fields[k][j]

@@ -29,6 +29,7 @@ def decode_cases():
         dict(name='coco_16x16', heads=W.COCO_HEADS, B=1, h=16, w=16, K=100, seed=3),
         dict(name='nusc_28x50', heads=W.NUSC_HEADS, B=3, h=28, w=50, K=64, seed=4),
         dict(name='mot_128x128', heads=W.MOT_HEADS, B=1, h=128, w=128, K=100, seed=5),
+        dict(name='pose_32x48', heads=W.POSE_HEADS, B=1, h=32, w=48, K=100, seed=6),   # (the reference's pose branch only runs at batch 1)
     ]
 
 
@@ -39,13 +40,17 @@ def make_head_maps(case):
     B, h, w = case['B'], case['h'], case['w']
     out = OrderedDict()
     for name, c in case['heads'].items():
-        if name == 'hm':
+        if name in ('hm', 'hm_hp'):
             v = torch.rand((B, c, h, w), generator=g, dtype=torch.float64)
             out[name] = (v ** 2 * 0.98 + 0.001).float()
-        elif name == 'reg':
+        elif name in ('reg', 'hp_offset'):
             out[name] = torch.rand((B, c, h, w), generator=g, dtype=torch.float64).float()
+        elif name == 'wh' and 'hps' in case['heads']:     # pose: boxes large enough that joints snap to heat-map peaks
+            out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 4 + 11).float()
         elif name == 'wh':
             out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 4 + 3).float()
+        elif name == 'hps':
+            out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 3).float()
         elif name == 'dep':
             out[name] = (torch.rand((B, c, h, w), generator=g, dtype=torch.float64) * 60 + 1).float()
         else:
@@ -96,7 +101,21 @@ def postprocess_cases():
                       height=375, width=1242,
                       calib=np.array([[721.5, 0, 609.6, 44.9], [0, 721.5, 172.9, 0.2], [0, 0, 1, 0.003]], np.float32),
                       dets=_sorted_dets(rs, K, ext2d, 9, 0.3)))
+    # key points (tracking,multi_pose): 17 joints per detection, post_process.py:51-54
+    extpose = dict(ext2d)
+    extpose['hps'] = lambda r, k: r.uniform(-5, 130, size=(k, 34)).astype(np.float32)
+    cases.append(dict(name='pose2d', out_thresh=0.3, num_classes=1, h=128, w=128,
+                      c=np.array([320., 240.], np.float32), s=640.0, height=480, width=640,
+                      calib=np.array([[1200., 0, 320, 0], [0, 1200., 240, 0], [0, 0, 1, 0]], np.float32),
+                      dets=_sorted_dets(rs, K, extpose, 12, 0.3)))
     return cases
+
+
+def pose_flip_inputs():
+    """flipped-image halves of the pose heads for the flip_lr / flip_lr_off parity check: hm_hp [1,17,6,10] and
+    hps [1,34,6,10]"""
+    g = torch.Generator().manual_seed(77)
+    return {'hm_hp': torch.rand((1, 17, 6, 10), generator=g), 'hps': torch.randn((1, 34, 6, 10), generator=g)}
 
 
 # ---------------------------------------------------------------------------- tracker

@@ -20,6 +20,9 @@ LEVELS = [1, 1, 1, 2, 2, 1]
 MOT_HEADS = OrderedDict([('hm', 1), ('reg', 2), ('wh', 2), ('tracking', 2), ('ltrb_amodal', 4)])
 KITTI_HEADS = OrderedDict([('hm', 3), ('reg', 2), ('wh', 2), ('tracking', 2)])
 COCO_HEADS = OrderedDict([('hm', 80), ('reg', 2), ('wh', 2), ('tracking', 2)])
+# tracking,multi_pose (opts.py:343-354; COCO person key points: 17 joints)
+POSE_HEADS = OrderedDict([('hm', 1), ('reg', 2), ('wh', 2), ('tracking', 2), ('hps', 34), ('hm_hp', 17),
+                          ('hp_offset', 2)])
 NUSC_HEADS = OrderedDict([('hm', 10), ('reg', 2), ('wh', 2), ('tracking', 2), ('dep', 1),
                           ('rot', 8), ('dim', 3), ('amodel_offset', 2)])
 
@@ -132,7 +135,7 @@ def make_synthetic_state_dict(heads=None, seed=317, off_std=0.01, hm_gain=1.0,
             fan_in = shape[1] * shape[2] * shape[3]
             sd[key] = uni(shape, (2.0 if kind == 'dcn_w' else 1.0) * math.sqrt(3.0 / fan_in))
         elif kind.startswith('head_out_w'):
-            gain = hm_gain if kind.endswith(':hm') else 1.0
+            gain = hm_gain if kind.endswith((':hm', ':hm_hp')) else 1.0
             sd[key] = uni(shape, gain / math.sqrt(shape[1]))
         elif kind in ('dcn_b', 'head_b'):
             sd[key] = nrm(shape, 0.1)

@@ -162,6 +162,7 @@ typedef struct ct_decode_desc {
     /* floats between consecutive images of hm / of each head map; 0 = densely packed ([B,c,h,w] contiguous).
      * Lets the head maps be channel slices of one wider NCHW tensor (all heads written by one conv launch). */
     size_t hm_batch_stride; size_t head_batch_stride[CT_NUM_HEADS];
+    int out_stride;            /* floats between consecutive rows of out; 0 = F (lets a wider row carry the pose fields) */
 } ct_decode_desc;
 /* row layout: score, cls, xs0, ys0, then for each present field in this order:
  * bbox[4] (if wh|ltrb|ltrb_amodal), bbox_amodal[4] (if ltrb_amodal), tracking[2], dep[1],
@@ -169,6 +170,28 @@ typedef struct ct_decode_desc {
 int ct_decode_row_floats(const ct_decode_desc *d);
 size_t ct_decode_workspace_bytes(const ct_decode_desc *d);
 int ct_decode(const ct_decode_desc *d, void *stream);
+
+/* ---- pose branch of the decode ------------------------------------
+ * Replaces the `'hps' in output` branch of generic_decode (src/lib/model/decode.py:161-171) with
+ * _update_kps_with_hm (decode.py:11-81, the `bboxes is not None` case) and _topk_channel
+ * (src/lib/model/utils.py:60-69).  Runs after ct_decode on the same frame: rows / inds are ct_decode's
+ * outputs (row pitch row_floats); box_col = column of the wh / ltrb box in a packed row (4 when present; a row that carries the
+ * ltrb_amodal box there instead is not accepted by the caller).  hps: NCHW [B,2J,h,w]; hm_hp: NCHW
+ * [B,J,h,w] post-sigmoid, densely packed; hp_offset: NCHW [B,2,h,w] (the hp_offset head, else the reg
+ * head, else NULL = +0.5).  out: [B,K,2J+1] = refined key points (x0,y0,x1,y1,...) then kps_score
+ * (with out_stride it may point into the packed rows themselves: one buffer, one D2H).
+ * Peaks of hm_hp with exactly equal scores rank lower pixel first (torch.topk: unspecified). */
+typedef struct ct_pose_desc {
+    const float *rows; int row_floats, box_col;
+    const int64_t *inds;
+    int B, h, w, K, num_joints;
+    const float *hps, *hm_hp, *hp_offset;
+    size_t hps_batch_stride, hm_hp_batch_stride, hp_offset_batch_stride;   /* floats between images; 0 = dense */
+    float *out; int out_stride;            /* floats between consecutive rows of out; 0 = 2J+1 */
+    void *workspace; size_t workspace_bytes;
+} ct_pose_desc;
+size_t ct_decode_pose_workspace_bytes(const ct_pose_desc *d);
+int ct_decode_pose(const ct_pose_desc *d, void *stream);
 
 /* ---- prior heat-map rendering on device ------------------------------------------------
  * Replaces the numpy Gaussian splatting + full-map H2D of Detector._get_additional_inputs

@@ -3,7 +3,7 @@
 Restates ``src/lib/detector.py``: run :55-172 (pre-processed-dict input path),
 _transform_scale :175-204 + the meta part of pre_process :207-239, _trans_bbox
 :242-251, _get_additional_inputs :254-290, _get_default_calib :293-297,
-_sigmoid_output :300-308, _flip_output :311-332 (non-pose heads), process
+_sigmoid_output :300-308, _flip_output :311-332, process
 :335-354 (the unconditional torch.cuda.synchronize() calls are dropped -- they
 crash on a GPU-less host), post_process :356-369, merge_outputs :371-377,
 reset_tracking :455-458.  Image warping (cv2.warpAffine) is out of the hot-path
@@ -132,14 +132,33 @@ def sigmoid_output(opt, output):
     """detector.py:300-308"""
     if 'hm' in output:
         output['hm'] = output['hm'].sigmoid_()
+    if 'hm_hp' in output:
+        output['hm_hp'] = output['hm_hp'].sigmoid_()
     if 'dep' in output:
         output['dep'] = 1. / (output['dep'].sigmoid() + 1e-6) - 1.
         output['dep'] *= opt.depth_scale
     return output
 
 
-def flip_output(output):
-    """detector.py:311-332 (non-pose heads)"""
+COCO_FLIP_IDX = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]   # coco_hp.py:18-19
+
+
+def mirror_joints(x, flip_idx, offsets):
+    """model/utils.py:33-50 (flip_lr / flip_lr_off): mirror a joint map left-right -- reverse the width axis,
+    exchange the left/right joints and, for offset maps (``offsets``: channels are (dx, dy) per joint),
+    negate dx."""
+    out = torch.flip(x, [3]).clone()
+    if offsets:
+        out = out.view(out.shape[0], -1, 2, out.shape[2], out.shape[3])
+        out[:, :, 0] *= -1
+    src = out.clone()
+    for a, b in flip_idx:
+        out[:, a], out[:, b] = src[:, b], src[:, a]
+    return out.reshape(x.shape)
+
+
+def flip_output(output, flip_idx=COCO_FLIP_IDX):
+    """detector.py:311-332"""
     average_flips = ['hm', 'wh', 'dep', 'dim']
     neg_average_flips = ['amodel_offset']
     single_flips = ['ltrb', 'nuscenes_att', 'velocity', 'ltrb_amodal', 'reg',
@@ -153,6 +172,10 @@ def flip_output(output):
             output[head] = (output[head][0:1] + flipped) / 2
         if head in single_flips:
             output[head] = output[head][0:1]
+        if head == 'hps':
+            output[head] = (output[head][0:1] + mirror_joints(output[head][1:2], flip_idx, True)) / 2
+        if head == 'hm_hp':
+            output[head] = (output[head][0:1] + mirror_joints(output[head][1:2], flip_idx, False)) / 2
     return output
 
 

@@ -61,6 +61,8 @@ def _one_detection(dets, i, j, trans, calib):
         item['tracking'] = moved - item['ct']
     if 'bboxes' in dets:
         item['bbox'] = _to_image(dets['bboxes'][i][j].reshape(2, 2), trans).reshape(4)
+    if 'hps' in dets:                                                  # post_process.py:51-54
+        item['hps'] = _to_image(dets['hps'][i][j].reshape(-1, 2), trans).reshape(-1)
     for k in ('dep', 'dim'):
         if has(k):
             item[k] = dets[k][i][j]

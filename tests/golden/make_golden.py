@@ -29,7 +29,7 @@ import torch  # noqa: E402
 
 from centertrack_amd import weights as W  # noqa: E402
 from centertrack_amd.scenarios import (decode_cases, make_head_maps, postprocess_cases,  # noqa: E402
-                                        tracker_sequences, e2e_config, writer_case)
+                                        tracker_sequences, e2e_config, writer_case, pose_flip_inputs)
 
 torch.set_num_threads(8)
 
@@ -182,6 +182,16 @@ def gen_pre_hm():
     print('pre_hm.npz', {k: v.shape for k, v in out.items()})
 
 
+def gen_pose_flip():
+    """flip_lr / flip_lr_off of the reference (model/utils.py:33-50) on pose_flip_inputs(), COCO flip_idx"""
+    from model.utils import flip_lr, flip_lr_off
+    flip_idx = [[1, 2], [3, 4], [5, 6], [7, 8], [9, 10], [11, 12], [13, 14], [15, 16]]   # datasets/coco_hp.py:18-19
+    x = pose_flip_inputs()
+    np.savez_compressed(os.path.join(HERE, 'pose_flip.npz'), hm_hp=flip_lr(x['hm_hp'].clone(), flip_idx).numpy(),
+                        hps=flip_lr_off(x['hps'].clone(), flip_idx).numpy())
+    print('pose_flip.npz')
+
+
 def gen_writers():
     """MOT.save_results (datasets/mot.py:52-83) and KITTITracking.save_results (datasets/kitti_tracking.py:51-97) of
     the reference, run unmodified on writer_case(); pycocotools is stubbed (only imported, not used by the writers)"""
@@ -216,7 +226,7 @@ def gen_writers():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers']
+    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers', 'poseflip']
     if 'model' in which:
         gen_model()
     if 'decode' in which:
@@ -231,3 +241,5 @@ if __name__ == '__main__':
         gen_e2e()
     if 'writers' in which:
         gen_writers()
+    if 'poseflip' in which:
+        gen_pose_flip()

@@ -177,3 +177,50 @@ def test_raw_frame_streams_with_flip_equal_host_preprocessed_streams(device):
         for s in range(B):
             assert [(int(r['tracking_id']), float(r['score'])) + tuple(map(float, r['bbox'])) for r in got[s]] == \
                    [(int(r['tracking_id']), float(r['score'])) + tuple(map(float, r['bbox'])) for r in want[s]]
+
+
+@pytest.mark.parametrize('flip', [False, True])
+def test_pose_tracking_stream_matches_oracle(device, flip):
+    """tracking,multi_pose (hps / hm_hp / hp_offset heads) end to end: forward, sigmoid on
+    both heat-maps, flip-test merge with the left/right joint exchange, decode + key-point refinement
+    (ct_decode_pose), post-process, tracker -- against the oracle detector frame by frame."""
+    from centertrack_amd import weights as W
+    from centertrack_amd.detector import Detector, default_opt
+    from centertrack_amd.image import make_meta
+    from centertrack_amd.model import DLASegHIP
+    from oracle import detector as odet
+    heads = W.POSE_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=21, hm_gain=14.0)
+    sd['wh.2.bias'] = torch.full_like(sd['wh.2.bias'], 14.0)          # boxes wide enough for joints to snap
+    sd['hps.2.weight'] = sd['hps.2.weight'] * 6
+    opt = default_opt(heads, track_thresh=0.3, flip_test=flip, input_h=64, input_w=96)
+    model = DLASegHIP(heads)
+    model.load_state_dict(sd)
+    det = Detector(opt, model=model)
+    assert not det.impl.native                                        # key points ride on the Python host path
+    oopt = odet.default_opt(track_thresh=0.3, flip_test=flip, input_h=64, input_w=96, num_classes=1)
+    oracle = odet.Detector(oopt, sd, heads)
+    meta = make_meta(64, 96, 480, 720)
+    g = torch.Generator().manual_seed(5)
+    snapped = 0
+    for t in range(3):
+        img = torch.randn((1, 3, 64, 96), generator=g)
+        ret = det.run(img, dict(meta))
+        want = oracle.run(torch.cat((img, torch.flip(img, [3])), 0) if flip else img, dict(meta))
+        od, gd = oracle.last_dets, det.impl.last_dets
+        n = int((od['scores'][0] >= oopt.out_thresh).sum())
+        assert n > 0 and len(want) > 0
+        np.testing.assert_array_equal(gd['xs'][0, :n], od['xs'][0, :n])
+        np.testing.assert_array_equal(gd['ys'][0, :n], od['ys'][0, :n])
+        # a joint snaps or not on discrete decisions (peak > 0.2, inside the box, nearest peak): the forward's 1e-4
+        # differences may flip a borderline one, everything else agrees to the forward tolerance
+        bad = np.abs(gd['hps'][0, :n] - od['hps'][0, :n]) > 2e-2
+        assert bad.mean() <= 0.02, 'frame %d: %d of %d key-point coordinates differ' % (t, bad.sum(), bad.size)
+        np.testing.assert_allclose(gd['kps_score'][0, :n], od['kps_score'][0, :n], atol=2e-2)
+        assert [int(r['tracking_id']) for r in ret['results']] == [int(r['tracking_id']) for r in want]
+        for a, b in zip(ret['results'], want):
+            assert a['hps'].shape == (34,)
+            assert np.mean(np.abs(a['hps'] - b['hps']) > 0.2) <= 0.1                  # image pixels (x7.5 the grid)
+        reg = od['hps'][0, :n]
+        snapped += int(np.sum(np.abs(reg - np.round(reg)) > 0))                        # (only a sanity count)
+    assert snapped > 0

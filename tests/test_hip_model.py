@@ -19,12 +19,13 @@ def _report(name, got, want):
 
 @pytest.mark.parametrize('name,shape,off_std', [('mot', (1, 64, 96), 0.01), ('nusc', (2, 64, 64), 0.01),
                                                 ('mot', (1, 128, 160), 0.1), ('coco', (2, 64, 64), 0.01),
-                                                ('kitti', (1, 96, 128), 0.05)])
+                                                ('kitti', (1, 96, 128), 0.05), ('pose', (1, 64, 96), 0.01)])
 def test_forward_matches_oracle(device, golden_dir, name, shape, off_std):
     from centertrack_amd import weights as W
     from centertrack_amd.model import DLASegHIP
     from oracle import dla34
-    heads = {'mot': W.MOT_HEADS, 'nusc': W.NUSC_HEADS, 'coco': W.COCO_HEADS, 'kitti': W.KITTI_HEADS}[name]
+    heads = {'mot': W.MOT_HEADS, 'nusc': W.NUSC_HEADS, 'coco': W.COCO_HEADS, 'kitti': W.KITTI_HEADS,
+             'pose': W.POSE_HEADS}[name]
     sd = W.make_synthetic_state_dict(heads, seed=317, off_std=off_std)
     x, pre, hm = W.synthetic_inputs(*shape, seed=317)
     model = DLASegHIP(heads)

@@ -377,8 +377,52 @@ def test_decode_matches_oracle_and_golden(device, golden_dir):
         for k, v in want.items():
             if k == 'inds':
                 continue
+            if k == 'kps_score':       # score * mean over 17 joints: summation order of torch.mean is not restated
+                np.testing.assert_allclose(got[k], v.numpy(), rtol=1e-5, atol=1e-7, err_msg=case['name'] + '.kps_score')
+                np.testing.assert_allclose(got[k], g['%s.%s' % (case['name'], k)], rtol=1e-5, atol=1e-7)
+                continue
             np.testing.assert_array_equal(got[k], v.numpy(), err_msg='%s.%s' % (case['name'], k))
             np.testing.assert_array_equal(got[k], g['%s.%s' % (case['name'], k)], err_msg='golden %s.%s' % (case['name'], k))
+
+
+@pytest.mark.parametrize('B,h,w,K,offset', [(2, 24, 40, 100, 'hp_offset'), (3, 32, 32, 40, 'reg'), (1, 16, 24, 20, None)])
+def test_decode_pose_branch_variants(device, B, h, w, K, offset):
+    """pose branch beyond the reference's batch-1 golden case: batches (the reference's expand() only works at
+    batch 1; the oracle's per-image form extends it), the reg head as sub-pixel offset when there is no hp_offset
+    head, no offset head at all (+0.5), other K.  Key points exact (they are selections), kps_score to 1e-5."""
+    from collections import OrderedDict
+    from centertrack_amd import scenarios as S
+    from oracle import decode as odecode
+    heads = OrderedDict([('hm', 1), ('wh', 2), ('hps', 34), ('hm_hp', 17)])
+    if offset == 'hp_offset':
+        heads['reg'] = 2
+        heads['hp_offset'] = 2
+    elif offset == 'reg':
+        heads['reg'] = 2
+    case = dict(name='pose_var', heads=heads, B=B, h=h, w=w, K=K, seed=40 + B)
+    maps = S.make_head_maps(case)
+    maps['hm_hp'][:, 3] *= 0.15                       # a joint whose peaks are all weak: regressed joints kept
+    dec, got, inds = _decode_case(device, case, maps)
+    want = odecode.generic_decode({k: v.clone() for k, v in maps.items()}, K=K, return_inds=True)
+    np.testing.assert_array_equal(inds, want['inds'].numpy())
+    np.testing.assert_array_equal(got['hps'], want['hps'].numpy())
+    np.testing.assert_array_equal(got['bboxes'], want['bboxes'].numpy())
+    np.testing.assert_allclose(got['kps_score'], want['kps_score'].numpy(), rtol=1e-5, atol=1e-7)
+    kps = odecode.transpose_and_gather_feat(maps['hps'], want['inds']).view(B, K, 34).clone()
+    kps[..., 0::2] += want['xs'].view(B, K, 1)
+    kps[..., 1::2] += want['ys'].view(B, K, 1)
+    snapped = (kps.numpy() != got['hps'])
+    assert snapped.any() and not snapped[..., 6:8].any()      # joint 3 never snaps (all its peaks <= 0.2)
+
+
+def test_decode_pose_rejects_what_it_does_not_implement(device):
+    from centertrack_amd import _lib, ops
+    hm = torch.rand((1, 1, 16, 16), device=device)
+    hps, hm_hp = torch.randn((1, 34, 16, 16), device=device), torch.rand((1, 17, 16, 16), device=device)
+    with pytest.raises(_lib.CTError):                                  # no box head
+        ops.Decoder(hm, {'hps': hps, 'hm_hp': hm_hp}, 20)
+    with pytest.raises(_lib.CTError):                                  # no joint heat-map
+        ops.Decoder(hm, {'hps': hps, 'wh': torch.rand((1, 2, 16, 16), device=device)}, 20)
 
 
 def test_decode_nms_plateau_and_ties(device):

@@ -95,3 +95,25 @@ def test_native_tracker_reset_and_empty_frames():
     assert len(r) == 1 and int(r['tracking_id'][0]) == 1 and ft.id_count == 1
     ft.reset()
     assert ft.id_count == 0 and len(ft.tracks) == 0
+
+
+def test_python_post_process_matches_reference_golden(golden_dir):
+    """centertrack_amd.post_process.generic_post_process (the Python host path: 3D fields, key points) against
+    the reference's own outputs (tests/golden/post_process.json), every field bit-identical"""
+    import json
+    import os
+    import types
+    from centertrack_amd import scenarios as S
+    g = json.load(open(os.path.join(golden_dir, 'post_process.json')))
+    for case in S.postprocess_cases():
+        opt = types.SimpleNamespace(out_thresh=case['out_thresh'])
+        r = PP.generic_post_process(opt, {k: v.copy() for k, v in case['dets'].items()}, [case['c']], [case['s']],
+                                    case['h'], case['w'], case['num_classes'], [case['calib']], case['height'],
+                                    case['width'])[0]
+        ref = g[case['name']]
+        assert len(r) == len(ref)
+        for a, b in zip(r, ref):
+            assert sorted(a.keys()) == sorted(b.keys())
+            for k in a:
+                np.testing.assert_array_equal(np.asarray(a[k], np.float64), np.asarray(b[k], np.float64),
+                                              err_msg='%s.%s' % (case['name'], k))

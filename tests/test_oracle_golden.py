@@ -117,3 +117,12 @@ def test_e2e_detector_matches_reference(golden_dir):
                 np.testing.assert_allclose(np.asarray(a[k], np.float64), np.asarray(b[k], np.float64),
                                            rtol=1e-4, atol=1e-4, err_msg='frame %d %s' % (t, k))
             assert int(a['age']) == int(b['age']) and int(a['active']) == int(b['active'])
+
+
+def test_pose_flip_matches_reference(golden_dir):
+    """oracle mirror_joints == the reference's flip_lr (hm_hp) / flip_lr_off (hps), model/utils.py:33-50"""
+    from oracle import detector as odet
+    g = _load(golden_dir, 'pose_flip.npz')
+    x = S.pose_flip_inputs()
+    np.testing.assert_array_equal(odet.mirror_joints(x['hm_hp'], odet.COCO_FLIP_IDX, False).numpy(), g['hm_hp'])
+    np.testing.assert_array_equal(odet.mirror_joints(x['hps'], odet.COCO_FLIP_IDX, True).numpy(), g['hps'])
