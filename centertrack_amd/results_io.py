@@ -113,3 +113,21 @@ def read_mot_results(path):
                 continue
             frames.setdefault(int(p[0]), []).append((int(p[1]), float(p[2]), float(p[3]), float(p[4]), float(p[5])))
     return frames
+
+
+def public_dets_from_mot(lines, frame_base=0):
+    """MOTChallenge ``det.txt`` lines -> ``{frame_id + frame_base: [item, ...]}`` in the shape the detector takes
+    as ``meta['cur_dets']`` / ``meta['pre_dets']`` for ``--public_det`` (test.py:101-107): what
+    ``tools/convert_mot_det_to_results.py:31-56`` stores per image -- ``bbox`` [x1,y1,x2,y2] from the float32
+    parsed x,y,w,h, ``score`` 1, ``class`` 1, ``ct`` the box centre."""
+    import numpy as np
+    out = {}
+    for line in lines:
+        p = line.strip().split(',')
+        if len(p) < 6:
+            continue
+        x, y, w, h = (float(np.float32(v)) for v in p[2:6])
+        bbox = [x, y, x + w, y + h]
+        out.setdefault(int(float(p[0])) + frame_base, []).append(
+            {'bbox': bbox, 'score': 1.0, 'class': 1, 'ct': [(bbox[0] + bbox[2]) / 2, (bbox[1] + bbox[3]) / 2]})
+    return out

@@ -117,3 +117,25 @@ def test_python_post_process_matches_reference_golden(golden_dir):
             for k in a:
                 np.testing.assert_array_equal(np.asarray(a[k], np.float64), np.asarray(b[k], np.float64),
                                               err_msg='%s.%s' % (case['name'], k))
+
+
+def test_python_tracker_matches_reference_golden(golden_dir):
+    """centertrack_amd.tracker.Tracker (the Python host path that serves --hungarian, --public_det and pre_dets;
+    SURVEY.md 8f rank 4) on every reference sequence of tests/golden/tracker.json: greedy, gating by size and
+    class, max_age re-activation, Hungarian assignment, public-detection births -- ids / ages / active flags exact."""
+    import json
+    import os
+    from centertrack_amd import scenarios as S
+    g = json.load(open(os.path.join(golden_dir, 'tracker.json')))
+    names = set()
+    for seq in S.tracker_sequences():
+        tr = TR.Tracker(types.SimpleNamespace(**seq['opt']))
+        tr.init_track([dict(d) for d in seq.get('pre_dets', [])])
+        for t, fr in enumerate(seq['frames']):
+            dets = [{k: (np.array(v, np.float32) if isinstance(v, list) else v) for k, v in d.items()} for d in fr['dets']]
+            ret = tr.step(dets, fr.get('public_det'))
+            got = [{'tracking_id': int(x['tracking_id']), 'age': int(x['age']), 'active': int(x['active']),
+                    'score': float(x['score']), 'class': int(x['class'])} for x in ret]
+            assert got == g[seq['name']][t], (seq['name'], t)
+        names.add(seq['name'])
+    assert {'hungarian_cross', 'public_det', 'random_hungarian'} <= names

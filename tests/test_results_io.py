@@ -67,3 +67,13 @@ def test_mot_round_trip_and_edge_cases(tmp_path):
     with open(p, 'w') as f:
         f.write('\n'.join(lines) + '\n')
     assert results_io.read_mot_results(p) == {5: [(1, 10.0, 20.01, 20.0, 29.99)]}
+
+
+def test_public_detections_from_a_mot_det_file():
+    """tools/convert_mot_det_to_results.py:31-56 per line: float32-parsed x,y,w,h -> x1y1x2y2 box, score 1, class 1"""
+    lines = ['1,-1,100.5,20.25,30,60.5,0.93,-1,-1,-1', '1,-1,5,6,7,8,1,-1,-1,-1', '3,-1,0.1,0.2,0.3,0.4,0.5,-1,-1,-1', '']
+    d = results_io.public_dets_from_mot(lines, frame_base=300)
+    assert sorted(d) == [301, 303] and len(d[301]) == 2
+    assert d[301][0] == {'bbox': [100.5, 20.25, 130.5, 80.75], 'score': 1.0, 'class': 1, 'ct': [115.5, 50.5]}
+    x, y, w, h = (float(np.float32(v)) for v in (0.1, 0.2, 0.3, 0.4))
+    assert d[303][0]['bbox'] == [x, y, x + w, y + h]
