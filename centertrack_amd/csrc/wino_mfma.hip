@@ -54,7 +54,9 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 // the chip): 4*KS waves, wave (r, kp) contracts slabs kp*4/KS .. of every chunk for row r; the KS partial
 // results are summed (in kp order) by the output transform.
 template <int WM, int WN, int KS, bool MULTI>
-__global__ __launch_bounds__(256 * KS) void wino_conv_kernel(WinoArgs a)
+// (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
+__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS)))
+void wino_conv_kernel(WinoArgs a)
 {
     using C = WCfg<WM>;
     constexpr int NTHR = 256 * KS;

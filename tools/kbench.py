@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--layers', default='', help='substring filter on the layer name')
     ap.add_argument('--xcd', action='store_true', help='A/B of the XCD-aware workgroup order only')
     ap.add_argument('--no-dcn', action='store_true')
+    ap.add_argument('--variant', default='', help='run only this conv variant (e.g. w64x32)')
     args = ap.parse_args()
     lib = _lib.load()
     dev = torch.device('cuda:0')
@@ -87,6 +88,8 @@ def main():
                     ('w64x32', dict(algo=202)), ('w64x32/x0', dict(algo=202, xcd_remap=0)),
                     ('w32/k2', dict(algo=205)), ('w32/k2/x0', dict(algo=205, xcd_remap=0))]
     convs = [c for c in convs if args.layers in c[0]]
+    if args.variant:
+        variants = [v for v in variants if v[0] == args.variant]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
     tot = {v[0]: 0.0 for v in variants}
     for name, cnt, H, Cin, Cout, ks, stride in convs:
