@@ -123,6 +123,8 @@ def _conv_candidates(d):
     if d.w_winograd and d.ks == 3 and d.stride == 1 and d.Cin % 64 == 0 and not (d.flags & _lib.CT_OUT_NCHW):
         for algo in (201, 202, 203, 204, 205, 206, 207):   # Winograd F(2x2,3x3) tile / K-split shapes (centertrack_hip.h)
             cands.append((algo, 1))
+        if d.Cin == 64 and d.Cout >= 128:                   # 2 / 4 / 5 / 8 cout blocks per workgroup on one input transform
+            cands += [(208, 1), (209, 1), (210, 1), (211, 1)]
     return cands
 
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: kept in an SGPR
     const int wm = wave / WGN, wn = wave % WGN;
 
     int bid = blockIdx.x;
@@ -529,7 +529,7 @@ extern "C" int ct_pack_conv_weight(const float *w_oihw, float *packed, int Cout,
 
 extern "C" size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d)
 {
-    if (d && d->algo >= 201 && d->algo <= 207) return 0;
+    if (d && d->algo >= 201 && d->algo <= 211) return 0;
     Plan p;
     ct_conv_desc t = *d;
     float dummy;
@@ -543,7 +543,7 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream);       // wino_mfma.
 
 extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
 {
-    if (d && d->algo >= 201 && d->algo <= 207) {
+    if (d && d->algo >= 201 && d->algo <= 211) {
         if (!d->x || !d->y) CT_FAIL_ARG("ct_conv2d: null pointer");
         if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_conv2d: input view must be 16-byte aligned (ld %% 4 == 0)");
         return ct_conv2d_winograd(d, stream);

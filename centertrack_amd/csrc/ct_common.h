@@ -73,6 +73,13 @@ struct EpiArgs {
 
 __device__ __forceinline__ float ct_sigmoid(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
+// scale / shift / residual / ReLU only (kernels whose host entry rejects the sigmoid and depth transforms)
+__device__ __forceinline__ float ct_epilogue_plain(const EpiArgs &e, float v, float sc, float sh, float r)
+{
+    v = v * sc + sh + r;
+    return (e.flags & CT_RELU) ? fmaxf(v, 0.0f) : v;
+}
+
 // Apply scale/shift/residual/activation to one accumulator value of channel `co`.
 __device__ __forceinline__ float ct_epilogue_value(const EpiArgs &e, float v, int co, float sc, float sh,
                                                    float r)

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: kept in an SGPR
     const int wm = wave / WGN, wn = wave % WGN;
 
     int bid = blockIdx.x;

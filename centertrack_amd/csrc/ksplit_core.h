@@ -44,7 +44,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;                       // = K slab inside a chunk
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = K slab inside a chunk (uniform: SGPR)
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
 
     int goff[C::NR], loff[C::NR];

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __shared__ int tab[ST_KTOT];
 
     const int tid = threadIdx.x;
-    const int lane = tid & 63, wave = tid >> 6;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int li = lane & 15, lg = lane >> 4;
     int bid = blockIdx.x;
     const int tx = bid % a.tilesX; bid /= a.tilesX;

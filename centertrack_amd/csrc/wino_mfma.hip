@@ -53,17 +53,25 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 // KS = K-split inside the workgroup for the deep levels (32x32 / 16x16 maps have too few pixel tiles to fill
 // the chip): 4*KS waves, wave (r, kp) contracts slabs kp*4/KS .. of every chunk for row r; the KS partial
 // results are summed (in kp order) by the output transform.
-template <int WM, int WN, int KS, bool MULTI>
+// NB > 1 (single chunk = 64 input channels, no K split): the workgroup walks NB consecutive cout blocks with the
+// same pixel tile.  The patch is staged and input-transformed ONCE (the 16 transformed fragments of a lane stay
+// in 64 VGPRs), every further block costs only its B loads, MFMAs and output transform -- for a short-K layer
+// like the heads conv (64 -> 1280) the per-block VALU work drops from ~6 to ~3 instructions per MFMA.
+template <int WM, int WN, int KS, bool MULTI, int NB = 1>
 // (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
-__global__ __launch_bounds__(256 * KS) __attribute__((amdgpu_waves_per_eu((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS)))
+__global__ __launch_bounds__(256 * KS)
+__attribute__((amdgpu_waves_per_eu(NB > 1 ? 3 : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
 void wino_conv_kernel(WinoArgs a)
 {
+    static_assert(NB == 1 || (!MULTI && KS == 1), "NB > 1 is a single-chunk, unsplit shape");
     using C = WCfg<WM>;
     constexpr int NTHR = 256 * KS;
     constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS;
     constexpr int W_NR = (W_ITEMS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, kp = tid >> 8;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index: uniform, kept in an SGPR
+    const int wave = wv & 3, kp = wv >> 2;
     const int li = lane & 15, lg = lane >> 4;
 
     int bid = blockIdx.x;
@@ -129,14 +137,53 @@ void wino_conv_kernel(WinoArgs a)
     constexpr int MT_OFF = 4 * W_PW * 16;            // floats between the patches of consecutive m-tiles
 
     // ---- B side ----------------------------------------------------------------------------------------
-    const int nt0 = cb * WN;
     const int NCH16 = a.Cin >> 4;
+    const size_t slab_stride = (size_t)a.NT << 8;
+    constexpr int SPK = 4 / KS;                     // slabs of a chunk per K part
+    constexpr int S = 16 / KS, D = 3, R = 4;       // steps per chunk and wave, B prefetched 3 steps ahead, ring of 4
+    float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
+    constexpr int TN = WM * WN;
+    float *ybuf = lds + KS * 4 * 2 * TN * 256;      // per-wave 32 x 16 transpose slabs behind the exchange buffer
+    const bool wide = (a.epi.Cout % 4 == 0) && (a.epi.ldy % 4 == 0) && (!a.epi.res || a.epi.ldr % 4 == 0) &&
+                      (((uintptr_t)a.epi.y & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
+    const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
+
+    // input transform of slab kk of the current LDS buffer: rows combined first, then the four column combinations
+    auto transform = [&](f32x4 (&v)[WM][4], const float *buf, int kk) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt) {
+            f32x4 e[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 d1 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + mt * MT_OFF + pa[0][j]);
+                const f32x4 d2 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + mt * MT_OFF + pa[1][j]);
+                e[j] = d1 + rs2 * d2;
+            }
+            v[mt][0] = e[0] - e[2];
+            v[mt][1] = e[1] + e[2];
+            v[mt][2] = e[2] - e[1];
+            v[mt][3] = e[1] - e[3];
+        }
+    };
+
+    f32x4 vall[NB > 1 ? 4 : 1][WM][4];             // NB > 1: all four slabs of the (single) chunk, transformed once
+    if (NB > 1) {
+        stage_load(0);
+        stage_store(0);
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < (NB > 1 ? 4 : 1); ++kk) transform(vall[kk], lds, kk);
+        __syncthreads();                            // the patch is dead from here on: its LDS becomes the exchange buffer
+    }
+
+#pragma unroll 1
+    for (int nb = 0; nb < NB; ++nb) {
+    const int nt0 = (cb * NB + nb) * WN;
+    if (NB > 1 && nt0 >= a.NT) break;               // (uniform: cout blocks past the end of a ragged Cout)
     const float *bptr[WN];
 #pragma unroll
     for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.up + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;
     // step s of a chunk (for this wave) = (slab kp*SPK + (s>>2), column c = s&3); position = wave*4 + c
-    constexpr int SPK = 4 / KS;                     // slabs of a chunk per K part
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int s) {
         const int c = s & 3, kk = kp * SPK + (s >> 2);
         const size_t slab = (size_t)(wave * 4 + c) * NCH16 + (size_t)min(chunk, a.nchunks - 1) * 4 + kk;
@@ -152,8 +199,24 @@ void wino_conv_kernel(WinoArgs a)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt) acc[mt][c][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    constexpr int S = 16 / KS, D = 3, R = 4;       // steps per chunk and wave, B prefetched 3 steps ahead, ring of 4
-    {
+    if (NB > 1) {
+        f32x4 breg[R][WN];
+#pragma unroll
+        for (int p = 0; p < D; ++p) load_b(breg[p], 0, p);
+#pragma unroll
+        for (int s = 0; s < 16; ++s) {
+            load_b(breg[(s + D) % R], 0, (s + D) & 15);          // (the last D prefetches re-read valid slabs)
+            __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+            for (int ee = 0; ee < 4; ++ee)
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt)
+                        acc[mt][s & 3][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(vall[(NB > 1) ? (s >> 2) : 0][mt][s & 3][ee],
+                                                                                 breg[s % R][nt][ee], acc[mt][s & 3][nt], 0, 0, 0);
+        }
+    } else {
         stage_load(0);
         f32x4 breg[R][WN];
 #pragma unroll
@@ -171,22 +234,8 @@ void wino_conv_kernel(WinoArgs a)
 #pragma unroll
             for (int ks = 0; ks < SPK; ++ks) {
                 const int kk = kp * SPK + ks;
-                // input transform of this slab: rows combined first, then the four column combinations
                 f32x4 v[WM][4];
-#pragma unroll
-                for (int mt = 0; mt < WM; ++mt) {
-                    f32x4 e[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const f32x4 d1 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + mt * MT_OFF + pa[0][j]);
-                        const f32x4 d2 = *reinterpret_cast<const f32x4 *>(buf + kk * W_SLAB + mt * MT_OFF + pa[1][j]);
-                        e[j] = d1 + rs2 * d2;
-                    }
-                    v[mt][0] = e[0] - e[2];
-                    v[mt][1] = e[1] + e[2];
-                    v[mt][2] = e[2] - e[1];
-                    v[mt][3] = e[1] - e[3];
-                }
+                transform(v, buf, kk);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int s = ks * 4 + c;
@@ -210,12 +259,6 @@ void wino_conv_kernel(WinoArgs a)
 
     // ---- output transform: columns in registers ... ---------------------------------------------------
     // T[q][nt]: q=0: M0+M1+M2, q=1: M1-M2-M3   (this wave's row r)
-    float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
-    constexpr int TN = WM * WN;
-    float *ybuf = lds + KS * 4 * 2 * TN * 256;      // per-wave 32 x 16 transpose slabs behind the exchange buffer
-    const bool wide = (a.epi.Cout % 4 == 0) && (a.epi.ldy % 4 == 0) && (!a.epi.res || a.epi.ldr % 4 == 0) &&
-                      (((uintptr_t)a.epi.y & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
-    const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
@@ -229,7 +272,7 @@ void wino_conv_kernel(WinoArgs a)
     // ... rows across the waves: Y[0][q] = T0+T1+T2, Y[1][q] = T1-T2-T3; 2*WM*WN (q, mt, nt) jobs over 4 waves
 #pragma unroll
     for (int w0 = 0; w0 < 2 * TN; w0 += 4 * KS) {
-        const int job = w0 + (tid >> 6);
+        const int job = w0 + wv;
         if (job < 2 * TN) {
             const int q = job & 1, tn = job >> 1;
             const int mt = tn / WN, nt = tn - mt * WN;
@@ -248,7 +291,7 @@ void wino_conv_kernel(WinoArgs a)
                 // 32 pixels x 16 couts of this job: transpose through this wave's private LDS slab so that a lane
                 // stores 4 consecutive couts of one pixel as ONE 16-byte store (the epilogue of a short-K layer
                 // like the heads conv is store-issue bound: 8 dword stores per lane become 2 dwordx4 stores)
-                float *yb = ybuf + (tid >> 6) * (32 * 16);
+                float *yb = ybuf + wv * (32 * 16);
 #pragma unroll
                 for (int ee = 0; ee < 4; ++ee) {
                     const int tile = lg * 4 + ee;
@@ -273,7 +316,7 @@ void wino_conv_kernel(WinoArgs a)
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
                         f32x4 o;
 #pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_value(a.epi, raw[i], c4 + i, sc4[i], sh4[i], r4[i]);
+                        for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_plain(a.epi, raw[i], sc4[i], sh4[i], r4[i]);
                         *reinterpret_cast<f32x4 *>(a.epi.y + pix * a.epi.ldy + c4) = o;
                     }
                 }
@@ -290,13 +333,15 @@ void wino_conv_kernel(WinoArgs a)
                         if (oy < a.epi.Ho && ox < a.epi.Wo) {
                             const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
                             const float r = a.epi.res ? a.epi.res[pix * a.epi.ldr + co] : 0.0f;
-                            a.epi.y[pix * a.epi.ldy + co] = ct_epilogue_value(a.epi, p ? y1[ee] : y0[ee], co, sc, sh, r);
+                            a.epi.y[pix * a.epi.ldy + co] = ct_epilogue_plain(a.epi, p ? y1[ee] : y0[ee], sc, sh, r);
                         }
                     }
                 }
             }
         }
     }
+    if (NB > 1) __syncthreads();                    // every job has read the exchange buffer: the next block may overwrite it
+    }                                               // (cout block nb)
 }
 
 // U[pos][co][ci] = (G g G^T)[r][c], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -322,11 +367,11 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, floa
     p[idx] = u;
 }
 
-template <int WM, int WN, int KS, bool MULTI>
+template <int WM, int WN, int KS, bool MULTI, int NB = 1>
 int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
     using C = WCfg<WM>;
-    auto k = wino_conv_kernel<WM, WN, KS, MULTI>;
+    auto k = wino_conv_kernel<WM, WN, KS, MULTI, NB>;
     const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
     const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256 + 4 * KS * 32 * 16);
     const size_t lds = patch > exch ? patch : exch;
@@ -369,13 +414,16 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_conv2d: the Winograd algo writes NHWC only");
     if (d->sig_hi > d->sig_lo || d->dep_hi > d->dep_lo) CT_FAIL_ARG("ct_conv2d: the Winograd algo has no sigmoid epilogue");
     // algo 201: 64 px x 64 couts, 202: 64 x 32, 203: 128 x 32, 204: 128 x 16 per workgroup of 4 waves;
-    // 205 / 206: 64 x 32 with K split over 2 / 4 wave groups (8 / 16 waves), 207: 64 x 16 with K split 4
+    // 205 / 206: 64 x 32 with K split over 2 / 4 wave groups (8 / 16 waves), 207: 64 x 16 with K split 4;
+    // 208..211: 64 x 32 walking 2 / 4 / 5 / 8 cout blocks per workgroup on one input transform (Cin == 64 only)
     const int WM = (d->algo == 203 || d->algo == 204) ? 2 : 1;
     const int WN = (d->algo == 201) ? 4 : ((d->algo == 204 || d->algo == 207) ? 1 : 2);
+    const int NB = d->algo == 208 ? 2 : (d->algo == 209 ? 4 : (d->algo == 210 ? 5 : (d->algo == 211 ? 8 : 1)));
+    if (NB > 1 && d->Cin != 64) CT_FAIL_ARG("ct_conv2d: algo %d is for Cin == 64 (got %d)", d->algo, d->Cin);
     WinoArgs a;
     a.x = d->x; a.up = d->w_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN); a.xcdPer = ct_xcd_per(a.coutBlocks);
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN * NB); a.xcdPer = ct_xcd_per(a.coutBlocks);
     a.NT = ct_cdiv(d->Cout, 16); a.nchunks = d->Cin / 64;
     a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = d->res; a.epi.y = d->y;
     a.epi.ldr = d->ldr; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;
@@ -392,6 +440,10 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     case 204: rc = launch_wino<2, 1, 1>(a, grid, st); break;
     case 205: rc = launch_wino<1, 2, 2>(a, grid, st); break;
     case 206: rc = launch_wino<1, 2, 4>(a, grid, st); break;
+    case 208: rc = launch_wino2<1, 2, 1, false, 2>(a, grid, st); break;
+    case 209: rc = launch_wino2<1, 2, 1, false, 4>(a, grid, st); break;
+    case 210: rc = launch_wino2<1, 2, 1, false, 5>(a, grid, st); break;
+    case 211: rc = launch_wino2<1, 2, 1, false, 8>(a, grid, st); break;
     default: rc = launch_wino<1, 1, 4>(a, grid, st); break;
     }
     CT_CHECK_LAUNCH("ct_conv2d(winograd)");

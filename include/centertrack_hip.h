@@ -78,10 +78,12 @@ typedef struct ct_conv_desc {
     int split_k;                                /* 0 = choose automatically */
     int algo;                                   /* 0 = heuristic; 1..8 = tile shape 0..7 of the row-tiled
                                                    kernel; 101..105 = K-split-in-workgroup shape 0..4
-                                                   (CT_ERR_ARG if the shape cannot run this layer); 201..207 =
+                                                   (CT_ERR_ARG if the shape cannot run this layer); 201..211 =
                                                    Winograd F(2x2,3x3) with 64px x 64 / 64 x 32 / 128 x 32 /
                                                    128 x 16 (pixels x couts) per workgroup, 205..207: 64 x 32
-                                                   / 64 x 32 / 64 x 16 with K split over 2 / 4 / 4 wave groups
+                                                   / 64 x 32 / 64 x 16 with K split over 2 / 4 / 4 wave groups,
+                                                   208..211: 64 x 32 walking 2 / 4 / 5 / 8 cout blocks per workgroup
+                                                   on one input transform (Cin == 64)
                                                    (3x3 stride 1, Cin % 64 == 0, NHWC output, needs w_winograd);
                                                    picked per layer by the host-side autotuner */
     const float *w_winograd;                    /* ct_pack_winograd_weight() of the same OIHW weight, or NULL */

@@ -162,7 +162,9 @@ def test_conv2d_ksplit_kernel_matches_torch(device, case):
                                                  (202, 1, 5, 7, 256, 96), (201, 1, 12, 20, 64, 1280), (203, 2, 13, 21, 64, 80),
                                                  (203, 1, 8, 16, 128, 64), (204, 1, 10, 18, 192, 40), (204, 1, 16, 16, 64, 27),
                                                  (205, 1, 9, 17, 128, 96), (206, 1, 8, 8, 256, 64), (207, 2, 4, 4, 512, 48),
-                                                 (206, 1, 8, 16, 64, 32)])
+                                                 (206, 1, 8, 16, 64, 32), (208, 1, 12, 20, 64, 1280), (208, 2, 9, 21, 64, 80),
+                                                 (209, 1, 16, 32, 64, 256), (209, 2, 5, 7, 64, 176), (209, 1, 8, 16, 64, 48),
+                                                 (210, 1, 12, 20, 64, 1280), (210, 2, 7, 9, 64, 200), (211, 1, 16, 16, 64, 304)])
 def test_conv2d_winograd_matches_torch(device, algo, N, H, W, Cin, Cout):
     """Winograd F(2x2,3x3) conv (ct_conv2d algo 201 / 202) == torch fp32 conv + BN + residual + ReLU; ragged
     edges, several chunks, Cout not a multiple of the tile.  Tolerance 5e-4 abs on O(1) outputs (the transforms

@@ -81,7 +81,8 @@ def main():
                 ('ks2', dict(conv_ks=2)), ('ks3', dict(conv_ks=3)), ('ks4', dict(conv_ks=4)),
                 ('old/cfg2', dict(conv_ks=-2, conv_cfg=2)), ('old/cfg4', dict(conv_ks=-2, conv_cfg=4)),
                 ('old/cfg3', dict(conv_ks=-2, conv_cfg=3)), ('w64x32', dict(algo=202)), ('w32/k2', dict(algo=205)), ('w32/k4', dict(algo=206)),
-                ('w16/k4', dict(algo=207))]
+                ('w16/k4', dict(algo=207)), ('w32/nb2', dict(algo=208)), ('w32/nb4', dict(algo=209)),
+                ('w32/nb5', dict(algo=210)), ('w32/nb8', dict(algo=211))]
     if args.xcd:
         variants = [('auto', {}), ('auto/x0', dict(xcd_remap=0)), ('ks1', dict(conv_ks=1)), ('ks1/x0', dict(conv_ks=1, xcd_remap=0)),
                     ('old/cfg0', dict(conv_ks=-2, conv_cfg=0)), ('cfg0/x0', dict(conv_ks=-2, conv_cfg=0, xcd_remap=0)),
@@ -105,7 +106,7 @@ def main():
             tune(conv_cfg=-1, conv_pipe=1, conv_small_tiles=256, splitk_target=512, conv_ks=-1, xcd_remap=1)
             algo = kw.get('algo', 0)
             tune(**{k: v for k, v in kw.items() if k != 'algo'})
-            if (kw.get('conv_cfg', -1) in (1, 5) and Cout > 32 * 8) or (algo and (ks != 3 or stride != 1 or Cin % 64)):
+            if (kw.get('conv_cfg', -1) in (1, 5) and Cout > 32 * 8) or (algo and (ks != 3 or stride != 1 or Cin % 64 or (algo >= 208 and Cin != 64))):
                 line += ' %12s' % '-'
                 continue
             ww = ops.pack_winograd(wraw) if algo else None        # (kept alive: the descriptor only holds its address)
