@@ -52,6 +52,9 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--cpu-frames', type=int, default=3)
     ap.add_argument('--hm-gain', type=float, default=11.0)
+    ap.add_argument('--pcie', action='store_true',
+                    help='also report the PCIe-inclusive rates (pinned host fp32 frames; raw u8 1080p frames with the '
+                         'device-side pre-processing) under "pcie_inclusive" -- never the headline value')
     return ap.parse_args()
 
 
@@ -261,6 +264,28 @@ def main():
                 if tb is not None:
                     out['roofline']['traffic'] = round(tb)
                     out['roofline']['traffic_source'] = src
+        if args.pcie and world == 1:
+            # the boundary of the reference hands over HOST frames (PrefetchDataset, test.py:22-51): same loop with the
+            # H2D copy inside the step, and with raw u8 1080p frames warped / normalised on the device
+            det2 = StreamDetector(opt, model=model, num_streams=B, use_graph=not args.no_graph)
+            pinned = [f.pin_memory() for f in frames_cpu]
+            raw = [np.random.RandomState(t).randint(0, 256, (1080, 1920 + 8, 3)).astype(np.uint8) for t in range(2)]
+            rmeta = make_meta(cfg['H'], cfg['W'], 1080, 1920)
+            modes = {'host_fp32_pinned_frames': lambda i: det2.step(pinned[i % T], metas),
+                     'raw_u8_1080p_frames_device_preprocess':
+                         lambda i: det2.step([raw[i & 1][:, 4 * (i % 3):4 * (i % 3) + 1920]] * B, [rmeta] * B)}
+            out['pcie_inclusive'] = {}
+            for name, fn in modes.items():
+                det2.reset_tracking()
+                for i in range(args.warmup):
+                    fn(i)
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for i in range(args.steps):
+                    fn(i)
+                torch.cuda.synchronize()
+                out['pcie_inclusive'][name] = round(B * args.steps / (time.perf_counter() - t1), 2)
+            out['pcie_inclusive']['unit'] = 'frames/s'
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg, heads, sd, [f[0:1] for f in frames_cpu], metas, opt_kw,
