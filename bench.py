@@ -296,6 +296,7 @@ def main():
         print(json.dumps(out))
         sys.stdout.flush()
     parallel.barrier()
+    parallel.shutdown()
 
 
 if __name__ == '__main__':

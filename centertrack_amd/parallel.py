@@ -71,3 +71,10 @@ def max_over_ranks(value):
     t = torch.tensor([value], dtype=torch.float64, device=dev)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def shutdown():
+    """tear the process group down (end of a torchrun job): avoids the NCCL/RCCL "process group was not
+    destroyed" teardown path"""
+    if dist.is_available() and dist.is_initialized():
+        dist.destroy_process_group()
