@@ -94,7 +94,8 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_decode_pose_workspace_bytes',
            'ct_decode_pose', 'ct_render_pre_hm',
            'ct_tracker_create', 'ct_tracker_destroy', 'ct_tracker_reset', 'ct_tracker_num_tracks',
-           'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params',
+           'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
+           'ct_tracker_step_public', 'ct_tracker_step_dets',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
            'ct_memcpy_async', 'ct_stream_synchronize']
 
@@ -155,6 +156,11 @@ def load():
     lib.ct_tracker_get_tracks.argtypes = [p, p, i]
     lib.ct_tracker_step.argtypes = [p, p, i, i, ctypes.POINTER(RowLayout), ctypes.c_float, p, p, i]
     lib.ct_tracker_prehm_params.argtypes = [p, ctypes.c_float, p, i, i, p, i]
+    lib.ct_linear_assignment.argtypes = [p, i, i, p, p]
+    lib.ct_tracker_set_mode.argtypes = [p, i, i]
+    lib.ct_tracker_init_tracks.argtypes = [p, p, i]
+    lib.ct_tracker_step_public.argtypes = [p, p, i, i, ctypes.POINTER(RowLayout), ctypes.c_float, p, p, i, p, i]
+    lib.ct_tracker_step_dets.argtypes = [p, p, i, p, i, p, i]
     lib.ct_preprocess_image.argtypes = [p, i, i, i, i, p, i, i, p, p, p, i]
     lib.ct_preprocess_lut.argtypes = [p, p, i, p]
     lib.ct_preprocess_device.argtypes = [p, i, i, i, i, p, i, i, p, p, p, p]

@@ -4,16 +4,21 @@
 // float64 promotion points so that track IDs are bit-identical:
 //   generic_post_process      src/lib/utils/post_process.py:21-91 (2D fields + the ddd centre)
 //   Detector.merge_outputs    src/lib/detector.py:371-377
-//   Tracker.step / greedy     src/lib/utils/tracker.py:28-138 (private detections, greedy)
+//   Tracker.init_track / step src/lib/utils/tracker.py:13-127 (greedy_assignment :129-138, the --hungarian branch
+//                             :52-55,63-73 and the --public_det branch :83-101)
 //   Detector._get_additional_inputs / _trans_bbox / gaussian_radius
 //                             src/lib/detector.py:242-290, src/lib/utils/image.py:105-126
-// The Hungarian and public-detection branches stay on the Python path (tracker.py there).
+// --hungarian: the reference calls sklearn's removed linear_assignment_; every modern environment (and the golden
+// vectors) substitutes scipy.optimize.linear_sum_assignment, whose rectangular solver (shortest augmenting paths,
+// D. F. Crouse 2016) is restated in ct_linear_assignment below, including its tie-breaking, because which of several
+// equally gated-out pairs gets "matched" decides the order in which new track ids are handed out.
 // Compiled with -ffp-contract=off: every float32 product/sum is rounded separately, like
 // numpy's element-wise arithmetic.
 #include <math.h>
 #include <stdint.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include <xmmintrin.h>
@@ -32,11 +37,13 @@ struct Tracker {
     float new_thresh;
     int max_age;
     int id_count;
+    int hungarian = 0, public_det = 0;
     std::vector<ct_track> tracks;
     // per-step scratch (kept to avoid heap traffic on the frame loop)
     std::vector<ct_track> scratch_dets, scratch_ret;
     std::vector<float> scratch_t;
     std::vector<int> scratch_dm, scratch_tm;
+    std::vector<double> scratch_cost;
 };
 
 inline void xform(const float *m, float x, float y, float *ox, float *oy)
@@ -66,7 +73,123 @@ double gaussian_radius(long height, long width)
     return r < r3 ? r : r3;
 }
 
+// One shortest augmenting path from free row `i` (Crouse's algorithm as scipy's rectangular solver runs it): columns
+// are scanned in the order of `remaining` (filled back to front), a tie on the smallest reduced cost prefers a column
+// that is still free.  Returns the sink column, or -1 for an infeasible matrix.
+long augmenting_path(long nc, const double *cost, std::vector<double> &u, std::vector<double> &v, std::vector<long> &path,
+                     std::vector<long> &row4col, std::vector<double> &shortest, long i, std::vector<char> &SR,
+                     std::vector<char> &SC, std::vector<long> &remaining, double *p_min)
+{
+    double min_val = 0;
+    long num_remaining = nc;
+    for (long it = 0; it < nc; ++it) remaining[it] = nc - it - 1;
+    std::fill(SR.begin(), SR.end(), 0);
+    std::fill(SC.begin(), SC.end(), 0);
+    std::fill(shortest.begin(), shortest.end(), INFINITY);
+    long sink = -1;
+    while (sink == -1) {
+        long index = -1;
+        double lowest = INFINITY;
+        SR[i] = 1;
+        for (long it = 0; it < num_remaining; ++it) {
+            const long j = remaining[it];
+            const double r = min_val + cost[i * nc + j] - u[i] - v[j];
+            if (r < shortest[j]) {
+                path[j] = i;
+                shortest[j] = r;
+            }
+            if (shortest[j] < lowest || (shortest[j] == lowest && row4col[j] == -1)) {
+                lowest = shortest[j];
+                index = it;
+            }
+        }
+        min_val = lowest;
+        if (min_val == INFINITY) return -1;
+        const long j = remaining[index];
+        if (row4col[j] == -1) sink = j;
+        else i = row4col[j];
+        SC[j] = 1;
+        remaining[index] = remaining[--num_remaining];
+    }
+    *p_min = min_val;
+    return sink;
+}
+
+// rows[k], cols[k], k < min(nr, nc): minimum-cost assignment of the nr x nc matrix, pairs sorted by row
+int lsap(long nr, long nc, const double *cost_in, long *rows, long *cols)
+{
+    if (nr == 0 || nc == 0) return 0;
+    const bool transpose = nc < nr;                 // a tall matrix is solved transposed
+    std::vector<double> temp;
+    const double *cost = cost_in;
+    if (transpose) {
+        temp.resize((size_t)nr * nc);
+        for (long i = 0; i < nr; ++i)
+            for (long j = 0; j < nc; ++j) temp[(size_t)j * nr + i] = cost_in[(size_t)i * nc + j];
+        std::swap(nr, nc);
+        cost = temp.data();
+    }
+    for (size_t k = 0; k < (size_t)nr * nc; ++k)
+        if (cost[k] != cost[k] || cost[k] == -INFINITY) return -1;
+    std::vector<double> u(nr, 0.0), v(nc, 0.0), shortest(nc);
+    std::vector<long> path(nc, -1), col4row(nr, -1), row4col(nc, -1), remaining(nc);
+    std::vector<char> SR(nr), SC(nc);
+    for (long cur = 0; cur < nr; ++cur) {
+        double min_val;
+        const long sink = augmenting_path(nc, cost, u, v, path, row4col, shortest, cur, SR, SC, remaining, &min_val);
+        if (sink < 0) return -1;
+        u[cur] += min_val;
+        for (long i = 0; i < nr; ++i)
+            if (SR[i] && i != cur) u[i] += min_val - shortest[col4row[i]];
+        for (long j = 0; j < nc; ++j)
+            if (SC[j]) v[j] -= min_val - shortest[j];
+        long j = sink;
+        while (true) {
+            const long i = path[j];
+            row4col[j] = i;
+            std::swap(col4row[i], j);
+            if (i == cur) break;
+        }
+    }
+    if (transpose) {
+        // (rows of the transposed problem are the original columns: report pairs sorted by original row)
+        std::vector<long> order(nr);
+        for (long i = 0; i < nr; ++i) order[i] = i;
+        std::stable_sort(order.begin(), order.end(), [&](long a, long b) { return col4row[a] < col4row[b]; });
+        for (long k = 0; k < nr; ++k) {
+            rows[k] = col4row[order[k]];
+            cols[k] = order[k];
+        }
+    } else {
+        for (long i = 0; i < nr; ++i) {
+            rows[i] = i;
+            cols[i] = col4row[i];
+        }
+    }
+    return (int)nr;
+}
+
 }  // namespace
+
+extern "C" int ct_linear_assignment(const double *cost, int nr, int nc, int *rows, int *cols)
+{
+    if ((!cost && nr > 0 && nc > 0) || nr < 0 || nc < 0 || !rows || !cols) {
+        ct_set_error("ct_linear_assignment: bad argument");
+        return -1;
+    }
+    const int n = nr < nc ? nr : nc;
+    std::vector<long> r(n > 0 ? n : 1), c(n > 0 ? n : 1);
+    const int got = lsap(nr, nc, cost, r.data(), c.data());
+    if (got < 0) {
+        ct_set_error("ct_linear_assignment: infeasible or invalid cost matrix");
+        return -1;
+    }
+    for (int k = 0; k < got; ++k) {
+        rows[k] = (int)r[k];
+        cols[k] = (int)c[k];
+    }
+    return got;
+}
 
 extern "C" void *ct_tracker_create(float new_thresh, int max_age)
 {
@@ -97,20 +220,13 @@ extern "C" int ct_tracker_get_tracks(void *h, ct_track *out, int cap)
     return (int)t->tracks.size();
 }
 
-extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
-                               const float *trans_inv, ct_track *out, int cap)
+namespace {
+
+// packed decode rows -> image-space detections (generic_post_process + merge_outputs): stop at the first
+// score < out_thresh, keep score > out_thresh
+void rows_to_dets(const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh, const float *trans_inv,
+                  std::vector<ct_track> &dets)
 {
-    Tracker *tr = static_cast<Tracker *>(h);
-    if (!tr || !rows || !lay || !trans_inv || !out) {
-        ct_set_error("ct_tracker_step: null pointer");
-        return -1;
-    }
-    if (lay->cts < 0 || lay->tracking < 0 || lay->bbox < 0) {
-        ct_set_error("ct_tracker_step: rows need cts, tracking and bbox fields");
-        return -1;
-    }
-    // ---- post-process: stop at the first score < out_thresh, keep score > out_thresh ----
-    std::vector<ct_track> &dets = tr->scratch_dets;
     dets.clear();
     dets.reserve(K);
     for (int j = 0; j < K; ++j) {
@@ -138,8 +254,12 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
         }
         if (score > out_thresh) dets.push_back(d);
     }
+}
+
+// greedy_assignment (tracker.py:129-138) over the implicit distance matrix: det_match / trk_match
+void match_greedy(Tracker *tr, const std::vector<ct_track> &dets, std::vector<int> &det_match, std::vector<int> &trk_match)
+{
     const int N = (int)dets.size(), M = (int)tr->tracks.size();
-    // ---- association (tracker.py:28-57, 129-138) ----
     // dist[i][m] = float32 squared distance, + 1e18 (promoting to float64) when gated out; greedy_assignment
     // walks the detections in score order, takes the FIRST minimum of its row and, if it is < 1e16, overwrites
     // that track's column with 1e18.  The matrix is not materialised: a row is evaluated when its detection is
@@ -158,9 +278,6 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
         tcl[m] = (float)tr->tracks[m].cls;
         avail[m] = 1.0f;
     }
-    std::vector<int> &det_match = tr->scratch_dm, &trk_match = tr->scratch_tm;
-    det_match.assign(N, -1);
-    trk_match.assign(M, -1);
     const float INF = __builtin_inff();
     const __m128 vinf = _mm_set1_ps(INF), vbig = _mm_set1_ps(1e16f), vone = _mm_set1_ps(1.0f);
     for (int i = 0; i < N && M > 0; ++i) {
@@ -191,6 +308,68 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
             avail[best] = 0.0f;
         }
     }
+}
+
+// Tracker.step (tracker.py:28-127) on image-space detections; returns the number of tracks or -1
+int associate(Tracker *tr, std::vector<ct_track> &dets, const float *public_cts, int n_public, ct_track *out, int cap)
+{
+    const int N = (int)dets.size(), M = (int)tr->tracks.size();
+    std::vector<int> &det_match = tr->scratch_dm, &trk_match = tr->scratch_tm;
+    det_match.assign(N, -1);
+    trk_match.assign(M, -1);
+    // births / carried-over tracks follow the ORDER of the reference's unmatched lists: never-assigned entries in
+    // index order, then (Hungarian only) the pairs the solver assigned although they are gated out, in row order
+    std::vector<int> late_dets, late_tracks;
+    if (!tr->hungarian) {
+        match_greedy(tr, dets, det_match, trk_match);
+    } else if (N > 0 && M > 0) {
+        // float64 matrix exactly as numpy builds it: float32 d2, + 1e18 where gated out, clamped to 1e18 (:44-54)
+        std::vector<double> &cost = tr->scratch_cost;
+        cost.resize((size_t)N * M);
+        for (int i = 0; i < N; ++i) {
+            const float px = dets[i].ct[0] + dets[i].tracking[0], py = dets[i].ct[1] + dets[i].tracking[1];
+            const float isz = area(dets[i].bbox);
+            for (int m = 0; m < M; ++m) {
+                const ct_track &t = tr->tracks[m];
+                const float dx = t.ct[0] - px, dy = t.ct[1] - py;
+                const float d2 = dx * dx + dy * dy;
+                const bool invalid = d2 > area(t.bbox) || d2 > isz || dets[i].cls != t.cls;
+                double v = (double)d2 + (invalid ? 1e18 : 0.0);
+                if (v > 1e18) v = 1e18;
+                cost[(size_t)i * M + m] = v;
+            }
+        }
+        const int n = N < M ? N : M;
+        std::vector<long> r(n), c(n);
+        if (lsap(N, M, cost.data(), r.data(), c.data()) < 0) {
+            ct_set_error("ct_tracker_step: the assignment problem is infeasible (non-finite distances)");
+            return -1;
+        }
+        std::vector<char> det_seen(N, 0), trk_seen(M, 0);
+        for (int k = 0; k < n; ++k) {
+            det_seen[r[k]] = 1;
+            trk_seen[c[k]] = 1;
+            if (cost[(size_t)r[k] * M + c[k]] > 1e16) {
+                late_dets.push_back((int)r[k]);
+                late_tracks.push_back((int)c[k]);
+            } else {
+                det_match[r[k]] = (int)c[k];
+                trk_match[c[k]] = (int)r[k];
+            }
+        }
+    }
+    std::vector<int> unmatched_dets, unmatched_tracks;
+    {
+        std::vector<char> late_d(N, 0), late_t(M, 0);
+        for (int i : late_dets) late_d[i] = 1;
+        for (int m : late_tracks) late_t[m] = 1;
+        for (int i = 0; i < N; ++i)
+            if (det_match[i] < 0 && !late_d[i]) unmatched_dets.push_back(i);
+        for (int m = 0; m < M; ++m)
+            if (trk_match[m] < 0 && !late_t[m]) unmatched_tracks.push_back(m);
+        unmatched_dets.insert(unmatched_dets.end(), late_dets.begin(), late_dets.end());
+        unmatched_tracks.insert(unmatched_tracks.end(), late_tracks.begin(), late_tracks.end());
+    }
     std::vector<ct_track> &ret = tr->scratch_ret;
     ret.clear();
     ret.reserve(N + M);
@@ -202,16 +381,46 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
             d.active = tr->tracks[det_match[i]].active + 1;
             ret.push_back(d);
         }
-    for (int i = 0; i < N; ++i)
-        if (det_match[i] < 0 && dets[i].score > tr->new_thresh) {
+    auto birth = [&](int i) {
+        if (dets[i].score > tr->new_thresh) {
             ct_track d = dets[i];
             d.tracking_id = ++tr->id_count;
             d.age = 1;
             d.active = 1;
             ret.push_back(d);
         }
-    for (int m = 0; m < M; ++m)
-        if (trk_match[m] < 0 && tr->tracks[m].age < tr->max_age) {
+    };
+    if (tr->public_det && !unmatched_dets.empty()) {
+        // tracker.py:83-101: new tracks only where a provided detection is closest to an unmatched detection
+        // and within its box size; float32 arithmetic like numpy's
+        if (n_public > 0 && !public_cts) {
+            ct_set_error("ct_tracker_step: public-detection mode needs the frame's public detections");
+            return -1;
+        }
+        std::vector<float> d3((size_t)N * (n_public > 0 ? n_public : 1));
+        std::vector<char> is_unmatched(N, 0);
+        for (int i : unmatched_dets) is_unmatched[i] = 1;
+        for (int i = 0; i < N; ++i) {
+            const float px = dets[i].ct[0] + dets[i].tracking[0], py = dets[i].ct[1] + dets[i].tracking[1];
+            for (int j = 0; j < n_public; ++j) {
+                const float dx = px - public_cts[2 * j], dy = py - public_cts[2 * j + 1];
+                d3[(size_t)i * n_public + j] = is_unmatched[i] ? dx * dx + dy * dy : 1e18f;
+            }
+        }
+        for (int j = 0; j < n_public; ++j) {
+            int bi = 0;
+            for (int i = 1; i < N; ++i)
+                if (d3[(size_t)i * n_public + j] < d3[(size_t)bi * n_public + j]) bi = i;     // first minimum
+            if (d3[(size_t)bi * n_public + j] < area(dets[bi].bbox)) {
+                for (int q = 0; q < n_public; ++q) d3[(size_t)bi * n_public + q] = 1e18f;
+                birth(bi);
+            }
+        }
+    } else {
+        for (int i : unmatched_dets) birth(i);
+    }
+    for (int m : unmatched_tracks)
+        if (tr->tracks[m].age < tr->max_age) {
             ct_track t = tr->tracks[m];
             t.age += 1;
             t.active = 0;
@@ -226,6 +435,74 @@ extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const c
     }
     if (n > 0) memcpy(out, tr->tracks.data(), sizeof(ct_track) * n);
     return n;
+}
+
+}  // namespace
+
+extern "C" int ct_tracker_set_mode(void *h, int hungarian, int public_det)
+{
+    Tracker *tr = static_cast<Tracker *>(h);
+    if (!tr) {
+        ct_set_error("ct_tracker_set_mode: null tracker");
+        return -1;
+    }
+    tr->hungarian = hungarian ? 1 : 0;
+    tr->public_det = public_det ? 1 : 0;
+    return 0;
+}
+
+extern "C" int ct_tracker_init_tracks(void *h, const ct_track *items, int n)
+{
+    Tracker *tr = static_cast<Tracker *>(h);
+    if (!tr || (n > 0 && !items) || n < 0) {
+        ct_set_error("ct_tracker_init_tracks: bad argument");
+        return -1;
+    }
+    for (int i = 0; i < n; ++i)                    // tracker.py:13-26 (ct is given by the caller: the box centre if absent)
+        if (items[i].score > tr->new_thresh) {
+            ct_track t = items[i];
+            t.tracking_id = ++tr->id_count;
+            t.age = 1;
+            t.active = 1;
+            t.row = -1;
+            tr->tracks.push_back(t);
+        }
+    return (int)tr->tracks.size();
+}
+
+extern "C" int ct_tracker_step_public(void *h, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
+                                      const float *trans_inv, const float *public_cts, int n_public, ct_track *out,
+                                      int cap)
+{
+    Tracker *tr = static_cast<Tracker *>(h);
+    if (!tr || !rows || !lay || !trans_inv || !out) {
+        ct_set_error("ct_tracker_step: null pointer");
+        return -1;
+    }
+    if (lay->cts < 0 || lay->tracking < 0 || lay->bbox < 0) {
+        ct_set_error("ct_tracker_step: rows need cts, tracking and bbox fields");
+        return -1;
+    }
+    rows_to_dets(rows, K, F, lay, out_thresh, trans_inv, tr->scratch_dets);
+    return associate(tr, tr->scratch_dets, public_cts, n_public, out, cap);
+}
+
+extern "C" int ct_tracker_step(void *h, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
+                               const float *trans_inv, ct_track *out, int cap)
+{
+    return ct_tracker_step_public(h, rows, K, F, lay, out_thresh, trans_inv, nullptr, 0, out, cap);
+}
+
+extern "C" int ct_tracker_step_dets(void *h, const ct_track *dets, int n, const float *public_cts, int n_public,
+                                    ct_track *out, int cap)
+{
+    Tracker *tr = static_cast<Tracker *>(h);
+    if (!tr || (n > 0 && !dets) || n < 0 || !out) {
+        ct_set_error("ct_tracker_step_dets: bad argument");
+        return -1;
+    }
+    tr->scratch_dets.assign(dets, dets + n);
+    return associate(tr, tr->scratch_dets, public_cts, n_public, out, cap);
 }
 
 extern "C" int ct_tracker_prehm_params(void *h, float pre_thresh, const double *trans_input, int inp_w, int inp_h,

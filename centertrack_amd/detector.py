@@ -124,13 +124,14 @@ class StreamDetector(object):
         self.flip = bool(getattr(opt, 'flip_test', False))
         self.use_graph = use_graph
         self.trackers = [Tracker(opt) for _ in range(self.B)]
-        # native host path (C++ post-process + greedy association + device-rendered prior heat-map);
-        # the reference-shaped Python path serves the Hungarian / public-detection / pre_dets branches
+        # native host path (C++ post-process + association incl. the Hungarian / public-detection / pre_dets branches
+        # + device-rendered prior heat-map); the reference-shaped Python path serves zero_pre_hm and the pose task
         self.native = bool(native_host and getattr(opt, 'tracking', False) and 'tracking' in opt.heads
-                           and not getattr(opt, 'hungarian', False) and not getattr(opt, 'public_det', False)
                            and not getattr(opt, 'zero_pre_hm', False)
                            and 'hps' not in opt.heads)         # (key points ride on the Python host path)
-        self.fast = [fast_track.FastTracker(opt.new_thresh, getattr(opt, 'max_age', -1), opt.K)
+        self.fast = [fast_track.FastTracker(opt.new_thresh, getattr(opt, 'max_age', -1), opt.K,
+                                            hungarian=getattr(opt, 'hungarian', False),
+                                            public_det=getattr(opt, 'public_det', False))
                      for _ in range(self.B)] if self.native else None
         self._last_dets = None
         self.started = [False] * self.B
@@ -324,11 +325,7 @@ class StreamDetector(object):
                 if not self.started[s]:                        # detector.py:97-103
                     pre_dets = metas[s].get('pre_dets', [])
                     if self.native and len(pre_dets) > 0:
-                        if any(self.started):
-                            raise _lib.CTError('pre_dets need the Python host path: build the detector with native_host=False')
-                        self.native, self.fast = False, None
-                        self._ctx = None
-                        return self.step(images if raw_frames else images[:B], metas, timers)
+                        self.fast[s].init_tracks(pre_dets)         # tracker.init_track, detector.py:101-102
                     if not self.native:
                         self.trackers[s].init_track(pre_dets)
             if img_in is not None:
@@ -401,7 +398,8 @@ class StreamDetector(object):
                     m['_trans_inv'] = (ident, tinv)
                 else:
                     tinv = cached[1]
-                all_results.append(self.fast[s].step(rows[s], ctx['row_layout'], opt.out_thresh, tinv).copy())
+                pub = m.get('cur_dets') if getattr(opt, 'public_det', False) else None    # detector.py:141-142
+                all_results.append(self.fast[s].step(rows[s], ctx['row_layout'], opt.out_thresh, tinv, pub).copy())
             t_track = time.time() - ta
         dets = None if self.native else self.last_dets
         for s in (range(B) if not self.native else []):

@@ -1,9 +1,9 @@
 """Native host path of one frame (ctypes over the CPU entry points of libcentertrack_hip):
-packed decode rows -> post-process -> threshold -> greedy association, and the prior
-heat-map blob parameters of the next frame.  Same semantics as ``post_process.py`` +
-``tracker.Tracker`` (the reference-shaped Python path, kept for the Hungarian /
-public-detection / pre_dets branches); results come back as a structured numpy array and are
-turned into the reference's list-of-dicts only on request."""
+packed decode rows -> post-process -> threshold -> association (greedy, or Hungarian /
+public-detection mode), and the prior heat-map blob parameters of the next frame.  Same
+semantics as ``post_process.py`` + ``tracker.Tracker`` (the reference-shaped Python path);
+results come back as a structured numpy array and are turned into the reference's
+list-of-dicts only on request."""
 import ctypes
 
 import numpy as np
@@ -28,12 +28,40 @@ def row_layout(layout):
     return lay
 
 
+def items_to_array(items):
+    """list of result dicts -> TRACK_DTYPE array (missing 'ct' = box centre, missing 'tracking' = 0)"""
+    arr = np.zeros(len(items), TRACK_DTYPE)
+    for i, it in enumerate(items):
+        arr[i]['score'] = it['score']
+        arr[i]['class'] = it.get('class', 1)
+        arr[i]['bbox'] = np.asarray(it['bbox'], np.float32)
+        if 'ct' in it:
+            arr[i]['ct'] = np.asarray(it['ct'], np.float32)
+        else:
+            b = it['bbox']
+            arr[i]['ct'] = [(b[0] + b[2]) / 2, (b[1] + b[3]) / 2]
+        if 'tracking' in it:
+            arr[i]['tracking'] = np.asarray(it['tracking'], np.float32)
+        arr[i]['row'] = -1
+    return arr
+
+
+def _public_centres(public_det):
+    if public_det is None or len(public_det) == 0:
+        return np.zeros((0, 2), np.float32)
+    return np.ascontiguousarray([d['ct'] for d in public_det], np.float32).reshape(-1, 2)
+
+
 class FastTracker(object):
     """One stream's tracker state in native code."""
 
-    def __init__(self, new_thresh, max_age, K):
+    def __init__(self, new_thresh, max_age, K, hungarian=False, public_det=False):
         self.lib = _lib.load()
         self.h = ctypes.c_void_p(self.lib.ct_tracker_create(float(new_thresh), int(max_age)))
+        self.public_det = bool(public_det)
+        if hungarian or public_det:
+            _lib.check(self.lib.ct_tracker_set_mode(self.h, int(bool(hungarian)), int(bool(public_det))),
+                       'ct_tracker_set_mode')
         self.cap = 2 * K + 64
         self.buf = np.zeros(self.cap, TRACK_DTYPE)
         self._buf_ptr = self.buf.ctypes.data
@@ -52,15 +80,40 @@ class FastTracker(object):
     def id_count(self):
         return self.lib.ct_tracker_id_count(self.h)
 
-    def step(self, rows, lay, out_thresh, trans_inv):
-        """rows: C-contiguous float32 [K,F] (host); trans_inv: float32 [2,3].  Returns a view
-        of the structured result array (valid until the next call)."""
+    def step(self, rows, lay, out_thresh, trans_inv, public_det=None):
+        """rows: C-contiguous float32 [K,F] (host); trans_inv: float32 [2,3]; public_det: the frame's provided
+        detections (list of dicts with 'ct', tracker.py:85) in public-detection mode.  Returns a view of the
+        structured result array (valid until the next call)."""
         K, F = rows.shape
-        n = self.lib.ct_tracker_step(self.h, rows.ctypes.data, K, F, ctypes.byref(lay), float(out_thresh),
-                                     trans_inv.ctypes.data, self._buf_ptr, self.cap)
+        if self.public_det:
+            pub = _public_centres(public_det)
+            n = self.lib.ct_tracker_step_public(self.h, rows.ctypes.data, K, F, ctypes.byref(lay), float(out_thresh),
+                                                trans_inv.ctypes.data, pub.ctypes.data, len(pub), self._buf_ptr,
+                                                self.cap)
+        else:
+            n = self.lib.ct_tracker_step(self.h, rows.ctypes.data, K, F, ctypes.byref(lay), float(out_thresh),
+                                         trans_inv.ctypes.data, self._buf_ptr, self.cap)
         if n < 0:
             _lib.check(1, 'ct_tracker_step')
         return self.buf[:n]
+
+    def step_dets(self, results, public_det=None):
+        """``Tracker.step(results, public_det)`` (tracker.py:28) on image-space detections: a list of dicts
+        (score, class, ct, tracking, bbox) or a TRACK_DTYPE array"""
+        dets = results if isinstance(results, np.ndarray) else items_to_array(results)
+        pub = _public_centres(public_det) if self.public_det else np.zeros((0, 2), np.float32)
+        n = self.lib.ct_tracker_step_dets(self.h, dets.ctypes.data, len(dets), pub.ctypes.data, len(pub),
+                                          self._buf_ptr, self.cap)
+        if n < 0:
+            _lib.check(1, 'ct_tracker_step_dets')
+        return self.buf[:n]
+
+    def init_tracks(self, results):
+        """``Tracker.init_track(results)`` (tracker.py:13-26): detections with score > new_thresh start tracks;
+        an item without 'ct' takes its box centre"""
+        dets = items_to_array(results)
+        if self.lib.ct_tracker_init_tracks(self.h, dets.ctypes.data, len(dets)) < 0:
+            _lib.check(1, 'ct_tracker_init_tracks')
 
     @property
     def tracks(self):

@@ -229,9 +229,27 @@ int ct_tracker_get_tracks(void *tracker, ct_track *out, int cap);
  * number of tracks written to out (<= cap) or -1 */
 int ct_tracker_step(void *tracker, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
                     const float *trans_inv, ct_track *out, int cap);
+/* Remaining branches of the reference's Tracker (src/lib/utils/tracker.py): hungarian != 0 = optimal assignment
+ * instead of greedy (:52-55,63-73, through ct_linear_assignment), public_det != 0 = new tracks only where one of
+ * the frame's provided detections supports them (:83-101); ct_tracker_init_tracks = init_track (:13-26: items with
+ * score > new_thresh start tracks; score, cls, ct, bbox are read); ct_tracker_step_public = ct_tracker_step with the
+ * frame's public detection centres (float32 [n_public,2], image coordinates; NULL / 0 otherwise);
+ * ct_tracker_step_dets = Tracker.step on detections that are already in image space (score, cls, ct, tracking, bbox). */
+int ct_tracker_set_mode(void *tracker, int hungarian, int public_det);
+int ct_tracker_init_tracks(void *tracker, const ct_track *items, int n);
+int ct_tracker_step_public(void *tracker, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
+                           const float *trans_inv, const float *public_cts, int n_public, ct_track *out, int cap);
+int ct_tracker_step_dets(void *tracker, const ct_track *dets, int n, const float *public_cts, int n_public,
+                         ct_track *out, int cap);
 /* (cx, cy, radius) int32 triples of the next frame's prior heat-map; trans_input float64 [2,3] */
 int ct_tracker_prehm_params(void *tracker, float pre_thresh, const double *trans_input, int inp_w, int inp_h,
                             int *params, int cap);
+
+/* Minimum-cost assignment of an nr x nc float64 cost matrix (row-major): what the reference's --hungarian branch
+ * gets from linear_assignment (src/lib/utils/tracker.py:2,55 -- sklearn's removed module, scipy's
+ * linear_sum_assignment in every current environment; same pairs, same tie-breaking).  rows / cols: min(nr, nc)
+ * pairs sorted by row; returns their number or -1. */
+int ct_linear_assignment(const double *cost, int nr, int nc, int *rows, int *cols);
 
 /* ---- runtime helpers of the per-frame host loop (no reference equivalent: they replace the torch
  * dispatcher on the four runtime calls a frame needs).  ct_graph_begin/end capture everything enqueued on

@@ -224,3 +224,37 @@ def test_pose_tracking_stream_matches_oracle(device, flip):
         reg = od['hps'][0, :n]
         snapped += int(np.sum(np.abs(reg - np.round(reg)) > 0))                        # (only a sanity count)
     assert snapped > 0
+
+
+@pytest.mark.parametrize('hungarian,public_det', [(True, False), (False, True), (True, True)])
+def test_native_host_path_serves_hungarian_public_det_and_pre_dets(device, hungarian, public_det):
+    """--hungarian / --public_det / meta['pre_dets'] through the native host path (ct_tracker_set_mode,
+    ct_tracker_step_public, ct_tracker_init_tracks) == the reference-shaped Python host path on the same frames:
+    identical ids, ages, active flags, scores and boxes."""
+    from centertrack_amd import scenarios as S
+    from centertrack_amd.detector import Detector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], hungarian=hungarian,
+                      public_det=public_det, max_age=2)
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    nat, pyt = Detector(opt, model=model), Detector(opt, model=model, native_host=False)
+    assert nat.impl.native and not pyt.impl.native
+    pre = None
+    for t, (img, meta) in enumerate(S.e2e_frames(cfg)):
+        m = dict(meta)
+        if t == 0:                                                   # tracks started from given detections
+            m['pre_dets'] = [{'score': 0.9, 'class': 1, 'bbox': [100., 80., 160., 200.], 'ct': [130., 140.]},
+                             {'score': 0.2, 'class': 1, 'bbox': [10., 10., 30., 40.], 'ct': [20., 25.]}]
+        if public_det:                                               # provided detections: last frame's results + one stray
+            m['cur_dets'] = ([{'ct': [float(r['ct'][0]) + 1.5, float(r['ct'][1]) - 1.0]} for r in pre[::2]] if pre else
+                             []) + [{'ct': [5., 5.]}]
+        a = nat.run(img, dict(m))['results']
+        b = pyt.run(img, dict(m))['results']
+        key = lambda r: (int(r['tracking_id']), int(r['age']), int(r['active']), float(np.float32(r['score']))) + \
+            tuple(float(np.float32(v)) for v in r['bbox'])      # (the native rows are float32)
+        assert [key(r) for r in a] == [key(r) for r in b], 'frame %d' % t
+        pre = b
+    assert nat.tracker.id_count == pyt.tracker.id_count and nat.tracker.id_count > 1

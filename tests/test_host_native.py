@@ -6,6 +6,7 @@ import types
 import numpy as np
 import pytest
 
+from centertrack_amd import _lib
 from centertrack_amd import fast_track as FT
 from centertrack_amd import image as IM
 from centertrack_amd import ops
@@ -139,3 +140,96 @@ def test_python_tracker_matches_reference_golden(golden_dir):
             assert got == g[seq['name']][t], (seq['name'], t)
         names.add(seq['name'])
     assert {'hungarian_cross', 'public_det', 'random_hungarian'} <= names
+
+
+def test_native_tracker_matches_reference_golden_all_modes(golden_dir):
+    """ct_tracker_step_dets / ct_tracker_init_tracks / ct_tracker_set_mode (native C++: greedy, Hungarian via
+    ct_linear_assignment, public-detection births, max_age, pre_dets) on every reference sequence of
+    tests/golden/tracker.json: ids / ages / active flags / order identical to the reference's Tracker"""
+    import json
+    import os
+    from centertrack_amd import scenarios as S
+    g = json.load(open(os.path.join(golden_dir, 'tracker.json')))
+    for seq in S.tracker_sequences():
+        o = seq['opt']
+        tr = FT.FastTracker(o['new_thresh'], o['max_age'], 128, hungarian=o['hungarian'], public_det=o['public_det'])
+        tr.init_tracks([dict(d) for d in seq.get('pre_dets', [])])
+        for t, fr in enumerate(seq['frames']):
+            ret = tr.step_dets([dict(d) for d in fr['dets']], fr.get('public_det'))
+            got = [{'tracking_id': int(x['tracking_id']), 'age': int(x['age']), 'active': int(x['active']),
+                    'score': float(x['score']), 'class': int(x['class'])} for x in ret]
+            want = [dict(w, score=float(np.float32(w['score']))) for w in g[seq['name']][t]]
+            assert got == want, (seq['name'], t)
+
+
+def test_linear_assignment_equals_scipy_including_ties():
+    """ct_linear_assignment == scipy.optimize.linear_sum_assignment pair for pair: random, heavily tied integer,
+    and 1e18-gated matrices (the tracker's), tall / wide / empty shapes"""
+    import ctypes
+    from scipy.optimize import linear_sum_assignment
+    lib = _lib.load()
+    rs = np.random.RandomState(0)
+    for it in range(1500):
+        nr, nc = rs.randint(0, 13), rs.randint(0, 13)
+        kind = it % 4
+        if kind == 0:
+            c = rs.uniform(0, 100, (nr, nc))
+        elif kind == 1:
+            c = rs.randint(0, 4, (nr, nc)).astype(np.float64)
+        elif kind == 2:
+            c = rs.uniform(0, 100, (nr, nc))
+            c[rs.uniform(size=(nr, nc)) < 0.6] = 1e18
+        else:
+            c = np.full((nr, nc), 1e18)
+            m = rs.uniform(size=(nr, nc)) < 0.2
+            c[m] = rs.uniform(0, 50, m.sum())
+        c = np.ascontiguousarray(c, np.float64)
+        r, cc = linear_sum_assignment(c)
+        R, C = np.zeros(13, np.int32), np.zeros(13, np.int32)
+        n = lib.ct_linear_assignment(c.ctypes.data, nr, nc, R.ctypes.data, C.ctypes.data)
+        assert n == len(r) and np.array_equal(R[:n], r) and np.array_equal(C[:n], cc), (nr, nc, kind)
+    bad = np.array([[1.0, np.nan]])
+    assert lib.ct_linear_assignment(bad.ctypes.data, 1, 2, R.ctypes.data, C.ctypes.data) == -1
+
+
+@pytest.mark.parametrize('hungarian,public_det,max_age', [(True, False, -1), (True, False, 3), (False, True, 2),
+                                                          (True, True, 2), (False, False, 4)])
+def test_native_tracker_equals_python_tracker_on_random_streams(hungarian, public_det, max_age):
+    """40-frame random streams (objects appearing / disappearing, clutter, mixed classes, public detections near
+    some objects): the native tracker and the reference-shaped Python tracker produce the same list frame by frame
+    (ids, ages, active flags, order, boxes)"""
+    rs = np.random.RandomState(17 + 2 * int(hungarian) + int(public_det) + max(max_age, 0))
+    opt = types.SimpleNamespace(new_thresh=0.4, max_age=max_age, hungarian=hungarian, public_det=public_det)
+    nat = FT.FastTracker(0.4, max_age, 128, hungarian=hungarian, public_det=public_det)
+    pyt = TR.Tracker(opt)
+    objs = [dict(p=rs.uniform(50, 900, 2), v=rs.normal(0, 6, 2), s=rs.uniform(15, 60), c=int(rs.randint(1, 3)))
+            for _ in range(14)]
+    births = 0
+    for t in range(40):
+        dets = []
+        for o in objs:
+            o['p'] = o['p'] + o['v']
+            if rs.uniform() < 0.85:                        # detected this frame
+                ct = (o['p'] + rs.normal(0, 1.5, 2)).astype(np.float32)
+                dets.append({'score': float(np.float32(rs.uniform(0.3, 1.0))), 'class': o['c'], 'ct': ct,
+                             'tracking': (-o['v'] + rs.normal(0, 1.0, 2)).astype(np.float32),
+                             'bbox': np.array([ct[0] - o['s'], ct[1] - o['s'], ct[0] + o['s'], ct[1] + o['s']], np.float32)})
+        for _ in range(rs.randint(0, 5)):                  # clutter
+            ct = rs.uniform(0, 1000, 2).astype(np.float32)
+            dets.append({'score': float(np.float32(rs.uniform(0.3, 0.9))), 'class': int(rs.randint(1, 3)), 'ct': ct,
+                         'tracking': rs.normal(0, 3, 2).astype(np.float32),
+                         'bbox': np.array([ct[0] - 20, ct[1] - 20, ct[0] + 20, ct[1] + 20], np.float32)})
+        dets.sort(key=lambda d: -d['score'])
+        pub = [{'ct': (o['p'] + rs.normal(0, 4, 2)).tolist()} for o in objs if rs.uniform() < 0.6] if public_det else None
+        if t % 13 == 12:
+            objs[rs.randint(len(objs))] = dict(p=rs.uniform(50, 900, 2), v=rs.normal(0, 6, 2), s=rs.uniform(15, 60),
+                                               c=int(rs.randint(1, 3)))
+        want = pyt.step([dict(d) for d in dets], pub)
+        got = nat.step_dets(dets, pub)
+        assert [int(x['tracking_id']) for x in got] == [int(x['tracking_id']) for x in want], t
+        assert [int(x['age']) for x in got] == [int(x['age']) for x in want]
+        assert [int(x['active']) for x in got] == [int(x['active']) for x in want]
+        for a, b in zip(got, want):
+            np.testing.assert_array_equal(a['bbox'], np.asarray(b['bbox'], np.float32))
+        births = max(births, nat.id_count)
+    assert births > 14 and nat.id_count == pyt.id_count
