@@ -469,22 +469,37 @@ def create_model(arch, head, head_conv, opt=None):
 
 
 def load_model(model, model_path, opt=None, optimizer=None):
-    """reference model.py:31-90 (inference part): ``{'epoch', 'state_dict'}`` checkpoint,
-    ``module.`` prefix stripped, unknown keys dropped, missing / mis-shaped keys keep init."""
+    """reference model.py:31-90 (inference part): ``{'epoch', 'state_dict'}`` checkpoint, ``module.`` prefix
+    stripped, unknown keys dropped, missing keys keep their initialisation; a parameter whose shape differs -- or,
+    under ``opt.reset_hm``, an ``hm*`` parameter with 80 / 1 rows -- is skipped, or with ``opt.reuse_hm`` cut /
+    padded along its first axis (a COCO-pretrained heat-map head reused for another class count, model.py:49-63)."""
     ckpt = torch.load(model_path, map_location='cpu')
     sd_in = ckpt['state_dict'] if 'state_dict' in ckpt else ckpt
+    if 'epoch' in ckpt:
+        print('loaded {}, epoch {}'.format(model_path, ckpt['epoch']))
     sd = {}
     for k, v in sd_in.items():
         sd[k[7:] if k.startswith('module') and not k.startswith('module_list') else k] = v
     own = model.state_dict()
+    reset_hm = bool(getattr(opt, 'reset_hm', False))
+    reuse_hm = bool(getattr(opt, 'reuse_hm', False))
     keep = {}
     for k, v in sd.items():
         if k in own:
-            if tuple(v.shape) == tuple(own[k].shape):
-                keep[k] = v
+            mismatch = tuple(v.shape) != tuple(own[k].shape)
+            if mismatch or (reset_hm and k.startswith('hm') and v.shape[0] in (80, 1)):
+                if reuse_hm and tuple(v.shape[1:]) == tuple(own[k].shape[1:]):
+                    print('Reusing parameter {}, required shape{}, loaded shape{}.'.format(
+                        k, tuple(own[k].shape), tuple(v.shape)))
+                    n = min(v.shape[0], own[k].shape[0])      # (the reference only ever cuts: `a < a` is never true)
+                    merged = own[k].clone()
+                    merged[:n] = v[:n]
+                    keep[k] = merged
+                else:
+                    print('Skip loading parameter {}, required shape{}, loaded shape{}.'.format(
+                        k, tuple(own[k].shape), tuple(v.shape)))
             else:
-                print('Skip loading parameter {}, required shape{}, loaded shape{}.'.format(
-                    k, tuple(own[k].shape), tuple(v.shape)))
+                keep[k] = v
         else:
             print('Drop parameter {}.'.format(k))
     for k in own:
