@@ -141,6 +141,7 @@ class StreamDetector(object):
         _lib.check(_lib.load().ct_preprocess_lut(mean.ctypes.data, std.ctypes.data, 3, lut.ctypes.data), 'ct_preprocess_lut')
         self._lut = torch.from_numpy(lut).to(self.device)
         self._raw_bufs = {}
+        self._carried = {}         # per stream: extras (3D fields) of tracks kept alive without a detection
         self.gather_fn = None      # optional hook: called with the packed device rows [B,K,F] (multi-GPU all-gather)
         self._ctx = None
 
@@ -434,12 +435,16 @@ class StreamDetector(object):
             self.trackers[s].reset()
             if self.fast is not None:
                 self.fast[s].reset()
+            self._carried.pop(s, None)
             self.started[s] = False
 
-    def results_as_dicts(self, results, stream=0):
-        """one stream's result of ``step`` as the reference's list of dicts"""
+    def results_as_dicts(self, results, stream=0, meta=None):
+        """one stream's result of ``step`` as the reference's list of dicts (``meta``: the frame's meta, whose
+        ``calib`` yields the 3D location / yaw of the ddd heads)"""
         if isinstance(results, np.ndarray):
-            return fast_track.as_dicts(results, self.last_dets, stream)
+            carried = self._carried.setdefault(stream, {})
+            return fast_track.as_dicts(results, self.last_dets, stream, None if meta is None else meta.get('calib'),
+                                       carried)
         return results
 
 
@@ -530,7 +535,7 @@ class Detector(object):
             images = images[0:1]                               # the flipped copy is rebuilt on device
         loaded = time.time()
         timers = {}
-        results = self.impl.results_as_dicts(self.impl.step(images, [meta], timers)[0], 0)
+        results = self.impl.results_as_dicts(self.impl.step(images, [meta], timers)[0], 0, meta)
         self.cnt += 1
         end = time.time()
         ret = {'results': results, 'tot': end - start, 'load': loaded - start, 'display': 0.0}

@@ -133,17 +133,43 @@ class FastTracker(object):
         return n, dst
 
 
-def as_dicts(arr, dets=None, stream=0):
-    """structured result array -> the reference's list of dicts (extra decode fields such as
-    dep / dim / rot are attached from ``dets`` via the source row when given)."""
+def as_dicts(arr, dets=None, stream=0, calib=None, carried=None):
+    """structured result array -> the reference's list of dicts.  Fields the native rows do not carry are attached
+    from ``dets`` (the decode dict of the frame) via the source row, like generic_post_process does
+    (post_process.py:56-88): dep, dim, the observation angle ``alpha`` from the 8-bin ``rot``, and with ``calib``
+    the 3D location / yaw (``loc``, ``rot_y``; the amodal centre is already the row's ``ct``), nuscenes_att,
+    velocity.  ``carried``: optional dict {tracking_id: extras} owned by the caller; tracks kept alive without a
+    detection (row < 0, ``max_age``) get back the extras of their last detection, as the reference's track dicts do."""
+    from .post_process import ddd2locrot, get_alpha
     out = []
+    alive = set()
     for r in arr:
         d = {'score': r['score'], 'class': int(r['class']), 'ct': r['ct'].copy(), 'tracking': r['tracking'].copy(),
              'bbox': r['bbox'].copy(), 'tracking_id': int(r['tracking_id']), 'age': int(r['age']),
              'active': int(r['active'])}
-        if dets is not None and r['row'] >= 0:
-            for k in ('dep', 'dim', 'rot', 'nuscenes_att', 'velocity'):
+        row = int(r['row'])
+        if dets is not None and row >= 0:
+            extras = {}
+            for k in ('dep', 'dim'):
                 if k in dets:
-                    d[k] = dets[k][stream][r['row']]
+                    extras[k] = dets[k][stream][row]
+            if 'rot' in dets:
+                extras['alpha'] = get_alpha(dets['rot'][stream][row:row + 1])[0]
+            if calib is not None and all(k in dets for k in ('rot', 'dep', 'dim')):
+                ct = d['ct'].tolist()                        # (ddd: the projected amodal / box centre, post_process.py:66-80)
+                d['ct'] = ct
+                extras['loc'], extras['rot_y'] = ddd2locrot(ct, extras['alpha'], extras['dim'], extras['dep'], calib)
+            for k in ('nuscenes_att', 'velocity'):
+                if k in dets:
+                    extras[k] = dets[k][stream][row]
+            d.update(extras)
+            if carried is not None:
+                carried[d['tracking_id']] = extras
+        elif carried is not None and d['tracking_id'] in carried:
+            d.update(carried[d['tracking_id']])
+        alive.add(d['tracking_id'])
         out.append(d)
+    if carried is not None:
+        for tid in [t for t in carried if t not in alive]:
+            del carried[tid]
     return out

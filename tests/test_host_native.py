@@ -233,3 +233,59 @@ def test_native_tracker_equals_python_tracker_on_random_streams(hungarian, publi
             np.testing.assert_array_equal(a['bbox'], np.asarray(b['bbox'], np.float32))
         births = max(births, nat.id_count)
     assert births > 14 and nat.id_count == pyt.id_count
+
+
+def test_native_results_as_dicts_carry_the_3d_fields_like_the_reference():
+    """ddd heads (nuScenes): the native rows + fast_track.as_dicts(dets, calib) give the dicts the reference's
+    generic_post_process + Tracker give -- dep, dim, alpha, loc, rot_y, amodal ct, also on tracks carried over
+    without a detection (max_age) -- so Detector.run()['results'] is complete on the native host path too."""
+    rs = np.random.RandomState(9)
+    names = ['reg', 'wh', 'tracking', 'dep', 'rot', 'dim', 'amodel_offset']
+    lay_list, F = ops.decode_layout(names)
+    lay = FT.row_layout(lay_list)
+    K = 40
+    meta = IM.make_meta(448, 800, 900, 1600)
+    calib = meta['calib']
+    trans = np.ascontiguousarray(IM.get_affine_transform(
+        meta['c'], meta['s'], 0, (meta['out_width'], meta['out_height']), inv=1).astype(np.float32))
+    opt = types.SimpleNamespace(out_thresh=0.3, new_thresh=0.3, max_age=2, hungarian=False, public_det=False)
+    ft, pt = FT.FastTracker(0.3, 2, K), TR.Tracker(opt)
+    off = {n: s for n, s, _ in lay_list}
+    carried = {}
+    objs = [dict(p=rs.uniform(20, 180, 2), v=rs.normal(0, 1.0, 2)) for _ in range(10)]
+    seen_carried = 0
+    for t in range(8):
+        rows = np.zeros((K, F), np.float32)
+        rows[:, 0] = np.sort(rs.uniform(0.05, 1, K).astype(np.float32))[::-1]
+        rows[:, 1] = rs.randint(0, 3, K)
+        for j in range(K):
+            o = objs[j % len(objs)]
+            c = np.floor(o['p'] + (0 if j < len(objs) else rs.normal(0, 30, 2)))
+            rows[j, 2:4] = c
+            half = rs.uniform(3, 9)
+            rows[j, off['bboxes']:off['bboxes'] + 4] = [c[0] - half, c[1] - half, c[0] + half, c[1] + half]
+            rows[j, off['tracking']:off['tracking'] + 2] = -o['v'] + rs.normal(0, 0.2, 2)
+            rows[j, off['dep']] = rs.uniform(3, 60)
+            rows[j, off['rot']:off['rot'] + 8] = rs.normal(0, 1, 8)
+            rows[j, off['dim']:off['dim'] + 3] = rs.uniform(0.5, 4, 3)
+            rows[j, off['amodel_offset']:off['amodel_offset'] + 2] = rs.normal(0, 1, 2)
+        if t in (3, 4):                                  # the strongest object goes undetected: its track is carried
+            rows[0, 0] = 0.01
+            rows[:, :] = rows[np.argsort(-rows[:, 0], kind='stable')]
+        for o in objs:
+            o['p'] = o['p'] + o['v']
+        dec = {n: (rows[None, :, s] if n in ('scores', 'clses', 'xs', 'ys') else rows[None, :, s:s + w])
+               for n, s, w in lay_list}
+        dec['cts'] = rows[None, :, 2:4]
+        got = FT.as_dicts(ft.step(rows, lay, 0.3, trans).copy(), dec, 0, calib, carried)
+        res = PP.generic_post_process(opt, {k: v.copy() for k, v in dec.items()}, [meta['c']], [meta['s']],
+                                      meta['out_height'], meta['out_width'], 3, [calib], 900, 1600)[0]
+        want = pt.step([r for r in res if r['score'] > 0.3])
+        assert [r['tracking_id'] for r in got] == [r['tracking_id'] for r in want], t
+        for a, b in zip(got, want):
+            assert a['age'] == b['age'] and a['active'] == b['active']
+            for k in ('dep', 'dim', 'alpha', 'loc', 'rot_y', 'ct', 'bbox'):
+                np.testing.assert_allclose(np.asarray(a[k], np.float64), np.asarray(b[k], np.float64), rtol=1e-6,
+                                           atol=1e-5, err_msg='frame %d %s' % (t, k))
+            seen_carried += int(a['active'] == 0)
+    assert seen_carried > 0
