@@ -165,7 +165,6 @@ def test_native_tracker_matches_reference_golden_all_modes(golden_dir):
 def test_linear_assignment_equals_scipy_including_ties():
     """ct_linear_assignment == scipy.optimize.linear_sum_assignment pair for pair: random, heavily tied integer,
     and 1e18-gated matrices (the tracker's), tall / wide / empty shapes"""
-    import ctypes
     from scipy.optimize import linear_sum_assignment
     lib = _lib.load()
     rs = np.random.RandomState(0)
