@@ -97,3 +97,28 @@ def test_normalisation_table_matches_the_float64_expression():
     want = ((v / 255. - MEAN) / STD).astype(np.float32)[:, 0, :].T
     np.testing.assert_array_equal(lut, want)
     assert lib.ct_preprocess_lut(mean.ctypes.data, std.ctypes.data, 9, lut.ctypes.data) != 0
+
+
+@pytest.mark.parametrize('mode', ['fix_res', 'fix_short', 'keep_res'])
+@pytest.mark.parametrize('h,w', [(375, 1242), (1080, 1920), (640, 480)])
+def test_meta_of_every_testing_mode_equals_the_oracle(mode, h, w):
+    """detector.py:175-239: fixed resolution / fixed short side / keep resolution padded to 32 -- sizes, centre,
+    scale, both affine maps and the default calibration of image.make_meta == oracle/detector.make_meta, and the host
+    pre-processing of that mode == the numpy restatement"""
+    from oracle import detector as odet
+    kw = dict(fix_res=(mode == 'fix_res'), fix_short=(256 if mode == 'fix_short' else 0), pad=31)
+    got = make_meta(128, 160, h, w, **kw)
+    oopt = odet.default_opt(input_h=128, input_w=160, **kw)
+    want = odet.make_meta(oopt, h, w)
+    assert set(got) == set(want)
+    for k in want:
+        np.testing.assert_array_equal(np.asarray(got[k]), np.asarray(want[k]), err_msg=k)
+    if mode == 'fix_short':
+        assert min(got['inp_height'], got['inp_width']) == 256 and max(got['inp_height'], got['inp_width']) % 64 == 0
+    if mode == 'keep_res':
+        assert got['inp_height'] % 32 == 0 and got['inp_height'] >= h and got['inp_width'] >= w
+    if h * w <= 480 * 640:
+        img = np.random.RandomState(h).randint(0, 256, (h, w, 3)).astype(np.uint8)
+        np.testing.assert_array_equal(
+            _run(img, got['trans_input'], got['inp_width'], got['inp_height']),
+            oimage.pre_process_image(img, got['trans_input'], got['inp_width'], got['inp_height'], MEAN, STD))
