@@ -12,6 +12,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 
+#include <thread>
 #include <vector>
 
 #include "ct_common.h"
@@ -51,10 +52,24 @@ extern "C" int ct_preprocess_image(const uint8_t *img, int h, int w, int stride,
         adelta[x] = cv_round(M[0] * x * AB_SCALE);
         bdelta[x] = cv_round(M[3] * x * AB_SCALE);
     }
+    // ((v / 255. - mean) / std).astype(float32) has 256 possible inputs per channel: float64 arithmetic, one rounding
+    // at the end, evaluated once per (channel, value) instead of once per pixel
+    float lut[4][256];
+    for (int c = 0; c < channels; ++c)
+        for (int v = 0; v < 256; ++v) lut[c][v] = (float)(((double)v / 255.0 - (double)mean[c]) / (double)stdv[c]);
     const size_t plane = (size_t)dst_w * dst_h;
-    for (int y = 0; y < dst_h; ++y) {
+    // rows are independent: CENTERTRACK_HOST_THREADS > 1 lets that many host threads share them (results do not depend
+    // on the split).  Default 1: the function usually runs in DataLoader worker processes that are the parallelism
+    // already (test.py:75), and on a 4-vCPU container 4 threads measured slower than 1.
+    int nthreads = 1;
+    if (const char *e = getenv("CENTERTRACK_HOST_THREADS")) nthreads = atoi(e);
+    if (nthreads > dst_h / 64) nthreads = dst_h / 64;
+    if (nthreads < 1) nthreads = 1;
+    auto do_rows = [&](int y_begin, int y_end) {
+    for (int y = y_begin; y < y_end; ++y) {
         const int X0 = cv_round((M[1] * y + M[2]) * AB_SCALE) + round_delta;
         const int Y0 = cv_round((M[4] * y + M[5]) * AB_SCALE) + round_delta;
+        float *orow = out + (size_t)y * dst_w;
         for (int x = 0; x < dst_w; ++x) {
             const int X = (X0 + adelta[x]) >> (AB_BITS - INTER_BITS);
             const int Y = (Y0 + bdelta[x]) >> (AB_BITS - INTER_BITS);
@@ -64,21 +79,41 @@ extern "C" int ct_preprocess_image(const uint8_t *img, int h, int w, int stride,
             const int fx = X & (INTER_TAB_SIZE - 1), fy = Y & (INTER_TAB_SIZE - 1);
             const int w00 = (32 - fx) * (32 - fy) * 32, w01 = fx * (32 - fy) * 32;
             const int w10 = (32 - fx) * fy * 32, w11 = fx * fy * 32;
-            const bool x0 = sx >= 0 && sx < w, x1 = sx + 1 >= 0 && sx + 1 < w;
-            const bool y0 = sy >= 0 && sy < h, y1 = sy + 1 >= 0 && sy + 1 < h;
+            int vals[4];
+            if ((unsigned)sx < (unsigned)(w - 1) && (unsigned)sy < (unsigned)(h - 1)) {
+                // all four taps inside the image (the common case): no border logic
+                const uint8_t *p0 = img + (size_t)sy * stride + (size_t)sx * channels, *p1 = p0 + stride;
+                for (int c = 0; c < channels; ++c)
+                    vals[c] = (p0[c] * w00 + p0[channels + c] * w01 + p1[c] * w10 + p1[channels + c] * w11 + (1 << 14)) >> 15;
+            } else {
+                const bool x0 = sx >= 0 && sx < w, x1 = sx + 1 >= 0 && sx + 1 < w;
+                const bool y0 = sy >= 0 && sy < h, y1 = sy + 1 >= 0 && sy + 1 < h;
+                for (int c = 0; c < channels; ++c) {
+                    const int p00 = (x0 && y0) ? img[(size_t)sy * stride + sx * channels + c] : 0;
+                    const int p01 = (x1 && y0) ? img[(size_t)sy * stride + (sx + 1) * channels + c] : 0;
+                    const int p10 = (x0 && y1) ? img[(size_t)(sy + 1) * stride + sx * channels + c] : 0;
+                    const int p11 = (x1 && y1) ? img[(size_t)(sy + 1) * stride + (sx + 1) * channels + c] : 0;
+                    vals[c] = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+                }
+            }
             for (int c = 0; c < channels; ++c) {
-                const int p00 = (x0 && y0) ? img[(size_t)sy * stride + sx * channels + c] : 0;
-                const int p01 = (x1 && y0) ? img[(size_t)sy * stride + (sx + 1) * channels + c] : 0;
-                const int p10 = (x0 && y1) ? img[(size_t)(sy + 1) * stride + sx * channels + c] : 0;
-                const int p11 = (x1 && y1) ? img[(size_t)(sy + 1) * stride + (sx + 1) * channels + c] : 0;
-                int v = (p00 * w00 + p01 * w01 + p10 * w10 + p11 * w11 + (1 << 14)) >> 15;
+                int v = vals[c];
                 if (v < 0) v = 0; if (v > 255) v = 255;
-                // ((x / 255. - mean) / std).astype(float32): float64 arithmetic, one rounding at the end
-                const float f = (float)(((double)v / 255.0 - (double)mean[c]) / (double)stdv[c]);
-                out[(size_t)c * plane + (size_t)y * dst_w + x] = f;
-                if (flip_copy) out[(size_t)(channels + c) * plane + (size_t)y * dst_w + (dst_w - 1 - x)] = f;
+                const float f = lut[c][v];
+                orow[(size_t)c * plane + x] = f;
+                if (flip_copy) orow[(size_t)(channels + c) * plane + (dst_w - 1 - x)] = f;
             }
         }
+    }
+    };
+    if (nthreads == 1) {
+        do_rows(0, dst_h);
+    } else {
+        std::vector<std::thread> pool;
+        const int per = (dst_h + nthreads - 1) / nthreads;
+        for (int t = 1; t < nthreads; ++t) pool.emplace_back(do_rows, t * per, (t + 1) * per < dst_h ? (t + 1) * per : dst_h);
+        do_rows(0, per < dst_h ? per : dst_h);
+        for (auto &th : pool) th.join();
     }
     return CT_OK;
 }
