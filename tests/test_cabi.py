@@ -52,3 +52,19 @@ def test_product_never_imports_oracle():
         if fn.endswith('.py'):
             src = open(os.path.join(pkg, fn)).read()
             assert not re.search(r'^\s*(from|import)\s+oracle', src, flags=re.M), fn
+
+
+def test_header_is_plain_c99(tmp_path):
+    """the drop-in boundary is a C ABI: include/centertrack_hip.h must compile as C99 (no C++-isms, no torch types)"""
+    import shutil
+    import subprocess
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    src = tmp_path / 'hdr.c'
+    src.write_text('#include "centertrack_hip.h"\nint main(void) { ct_conv_desc c; ct_dcn_desc d; ct_decode_desc e; '
+                   'ct_pose_desc p; (void)c; (void)d; (void)e; (void)p; return ct_version() > 0 ? 0 : 1; }\n')
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I' + os.path.join(root, 'include'),
+                        '-fsyntax-only', str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
