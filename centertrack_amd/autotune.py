@@ -36,23 +36,46 @@ def _cache_path():
     return os.environ.get('CENTERTRACK_TUNE_CACHE', '')
 
 
+PINNED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune_table.json')
+
+
+def _read_table(path):
+    """{key: (algo, split_k, us)} of a table file; a missing, truncated or otherwise unreadable file is ignored
+    (its keys are simply tuned again) instead of failing the start-up"""
+    try:
+        with open(path) as f:
+            return {k: tuple(v) for k, v in json.load(f).items()}
+    except (OSError, ValueError, TypeError):
+        return {}
+
+
 def _load_file():
+    """Choices are taken, in this order, from (1) the pinned table shipped in the package (``tune_table.json``:
+    the launch shapes of the BASELINE.json configurations, measured once on an MI355X and committed, so that every
+    process -- every rank of a torchrun job -- replays IDENTICAL tile shapes, hence identical fp32 summation orders
+    and identical last bits; ``CENTERTRACK_TUNE_PINNED=0`` ignores it), (2) the file named by
+    ``CENTERTRACK_TUNE_CACHE``, (3) live timing."""
     global _LOADED
     if _LOADED:
         return
     _LOADED = True
+    if os.environ.get('CENTERTRACK_TUNE_PINNED', '1') != '0':
+        _CACHE.update(_read_table(PINNED_TABLE))
     p = _cache_path()
-    if p and os.path.exists(p):
-        with open(p) as f:
-            for k, v in json.load(f).items():
-                _CACHE[k] = tuple(v)
+    if p:
+        _CACHE.update(_read_table(p))
 
 
 def _save_file():
+    """atomic (temp file + rename) and written by rank 0 only: under torchrun every rank tunes the same keys, and
+    concurrent rewrites of one path would interleave"""
     p = _cache_path()
-    if p:
-        with open(p, 'w') as f:
-            json.dump({k: list(v) for k, v in sorted(_CACHE.items())}, f, indent=0)
+    if not p or int(os.environ.get('RANK', '0')) != 0:
+        return
+    tmp = '%s.tmp.%d' % (p, os.getpid())
+    with open(tmp, 'w') as f:
+        json.dump({k: list(v) for k, v in sorted(_CACHE.items())}, f, indent=0)
+    os.replace(tmp, p)
 
 
 def _scratch(nbytes, device):

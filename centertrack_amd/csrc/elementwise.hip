@@ -119,41 +119,46 @@ __global__ __launch_bounds__(256) void render_pre_hm_kernel(const int *params, c
     const int ty = bid % tilesY;
     const int b = bid / tilesY;
     const int x0 = tx * PHM_TW, y0 = ty * PHM_TH;
-    const int n = min(min(counts[b], cap), PHM_CAP);
+    const int n = min(counts[b], cap);
     const int *p = params + (size_t)b * cap * 3;
-    if (threadIdx.x == 0) nblob = 0;
-    __syncthreads();
     const int lane = threadIdx.x & 63;
-    for (int i0 = 0; i0 < n; i0 += 256) {
-        const int i = i0 + threadIdx.x;
-        int cx = 0, cy = 0, r = -1;
-        if (i < n) { cx = p[3 * i]; cy = p[3 * i + 1]; r = p[3 * i + 2]; }
-        const bool hit = i < n && r >= 0 && cx + r >= x0 && cx - r < x0 + PHM_TW && cy + r >= y0 && cy - r < y0 + PHM_TH;
-        const unsigned long long mask = __ballot(hit);
-        int base = 0;
-        if (mask) {
-            const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) base = atomicAdd(&nblob, (int)__popcll(mask));
-            base = __shfl(base, leader);
-        }
-        if (hit) {
-            const int s = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
-            blob[3 * s] = cx; blob[3 * s + 1] = cy; blob[3 * s + 2] = r;
-        }
-    }
-    __syncthreads();
     const int x = x0 + (threadIdx.x & (PHM_TW - 1)), y = y0 + (threadIdx.x / PHM_TW);
-    if (x >= W || y >= H) return;
     float v = 0.0f;
-    const int m = nblob;
-    for (int i = 0; i < m; ++i) {
-        const int cx = blob[3 * i], cy = blob[3 * i + 1], r = blob[3 * i + 2];
-        const int dx = x - cx, dy = y - cy;
-        if (dx < -r || dx > r || dy < -r || dy > r) continue;
-        const double sigma = (double)(2 * r + 1) / 6.0;
-        const double g = exp(-(double)(dx * dx + dy * dy) / (2.0 * sigma * sigma));
-        v = fmaxf(v, (float)g);
+    // blobs are culled against the tile PHM_CAP at a time (any number of blobs per stream: K is not bounded)
+    for (int c0 = 0; c0 == 0 || c0 < n; c0 += PHM_CAP) {
+        const int c1 = min(n, c0 + PHM_CAP);
+        if (threadIdx.x == 0) nblob = 0;
+        __syncthreads();
+        for (int i0 = c0; i0 < c1; i0 += 256) {
+            const int i = i0 + threadIdx.x;
+            int cx = 0, cy = 0, r = -1;
+            if (i < c1) { cx = p[3 * i]; cy = p[3 * i + 1]; r = p[3 * i + 2]; }
+            const bool hit = i < c1 && r >= 0 && cx + r >= x0 && cx - r < x0 + PHM_TW && cy + r >= y0 && cy - r < y0 + PHM_TH;
+            const unsigned long long mask = __ballot(hit);
+            int base = 0;
+            if (mask) {
+                const int leader = __ffsll((long long)mask) - 1;
+                if (lane == leader) base = atomicAdd(&nblob, (int)__popcll(mask));
+                base = __shfl(base, leader);
+            }
+            if (hit) {
+                const int s = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+                blob[3 * s] = cx; blob[3 * s + 1] = cy; blob[3 * s + 2] = r;
+            }
+        }
+        __syncthreads();
+        const int m = nblob;
+        for (int i = 0; i < m; ++i) {
+            const int cx = blob[3 * i], cy = blob[3 * i + 1], r = blob[3 * i + 2];
+            const int dx = x - cx, dy = y - cy;
+            if (dx < -r || dx > r || dy < -r || dy > r) continue;
+            const double sigma = (double)(2 * r + 1) / 6.0;
+            const double g = exp(-(double)(dx * dx + dy * dy) / (2.0 * sigma * sigma));
+            v = fmaxf(v, (float)g);
+        }
+        __syncthreads();
     }
+    if (x >= W || y >= H) return;
     out[((size_t)b * H + y) * W + x] = v;
     if (also_flipped) out[((size_t)(B + b) * H + y) * W + (W - 1 - x)] = v;
 }
@@ -219,7 +224,6 @@ extern "C" int ct_render_pre_hm(const int *params, const int *counts, int cap, i
                                 int also_flipped, void *stream)
 {
     if (!params || !counts || !out || cap <= 0 || B <= 0 || H <= 0 || W <= 0) CT_FAIL_ARG("ct_render_pre_hm: bad arguments");
-    if (cap > PHM_CAP) CT_FAIL_ARG("ct_render_pre_hm: cap=%d > %d blobs per stream unsupported", cap, PHM_CAP);
     const long blocks = (long)B * ((H + PHM_TH - 1) / PHM_TH) * ((W + PHM_TW - 1) / PHM_TW);
     hipLaunchKernelGGL(render_pre_hm_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, params, counts,
                        cap, B, H, W, out, also_flipped);

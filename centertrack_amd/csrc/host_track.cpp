@@ -429,11 +429,10 @@ int associate(Tracker *tr, std::vector<ct_track> &dets, const float *public_cts,
         }
     tr->tracks.swap(ret);
     const int n = (int)tr->tracks.size();
-    if (n > cap) {
-        ct_set_error("ct_tracker_step: %d results exceed the output capacity %d", n, cap);
-        return -1;
-    }
-    if (n > 0) memcpy(out, tr->tracks.data(), sizeof(ct_track) * n);
+    // the reference's track list is unbounded (max_age > 0 keeps unmatched tracks): the step always completes;
+    // when n > cap only the first cap tracks are copied and the caller fetches the rest with ct_tracker_get_tracks
+    const int ncopy = n < cap ? n : cap;
+    if (ncopy > 0 && out) memcpy(out, tr->tracks.data(), sizeof(ct_track) * ncopy);
     return n;
 }
 

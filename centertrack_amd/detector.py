@@ -172,10 +172,11 @@ class StreamDetector(object):
         render = self.native and with_hm
         if render:
             # blob triples of every stream followed by the per-stream counts: ONE pinned buffer, one H2D per frame
-            nprm = self.B * fast_track.MAX_BLOBS * 3
+            nblob = ctx['max_blobs'] = fast_track.max_blobs(opt.K)
+            nprm = self.B * nblob * 3
             ctx['pc_host'] = torch.zeros((nprm + self.B,), dtype=torch.int32).pin_memory()
             ctx['pc_dev'] = torch.zeros((nprm + self.B,), dtype=torch.int32, device=self.device)
-            ctx['prm_host'] = ctx['pc_host'][:nprm].view(self.B, fast_track.MAX_BLOBS, 3)
+            ctx['prm_host'] = ctx['pc_host'][:nprm].view(self.B, nblob, 3)
             ctx['cnt_host'] = ctx['pc_host'][nprm:]
             ctx['prm_dev'] = ctx['pc_dev'][:nprm]
             ctx['cnt_dev'] = ctx['pc_dev'][nprm:]
@@ -200,7 +201,7 @@ class StreamDetector(object):
                                                        ctx['pc_host'].numel() * 4, 1, _lib.stream_ptr()), 'H2D')
             if render:
                 _lib.check(_lib.load().ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
-                                                        fast_track.MAX_BLOBS, self.B, H, W, hm_in.data_ptr(),
+                                                        ctx['max_blobs'], self.B, H, W, hm_in.data_ptr(),
                                                         1 if self.flip else 0, _lib.stream_ptr()), 'ct_render_pre_hm')
             self.model._run_plan(plan, inputs=(cur, prev, hm_in))
             if self.flip:
@@ -389,17 +390,18 @@ class StreamDetector(object):
             ta = time.time()
             for s in range(B):
                 m = metas[s]
-                # float32 inverse output affine (post_process.py:30), cached in the meta dict while its c / s
-                # objects stay the same
+                # float32 inverse output affine (post_process.py:30), cached in the meta dict, keyed on the VALUES
+                # of c / s (an in-place edit or a recycled object id must not resurrect a stale transform)
                 cached = m.get('_trans_inv')
-                ident = (id(m['c']), id(m['s']), m['out_width'], m['out_height'])
+                ident = (tuple(np.ravel(m['c']).tolist()), tuple(np.ravel(m['s']).tolist()), m['out_width'],
+                         m['out_height'])
                 if cached is None or cached[0] != ident:
                     tinv = np.ascontiguousarray(get_affine_transform(
                         m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1).astype(np.float32))
                     m['_trans_inv'] = (ident, tinv)
                 else:
                     tinv = cached[1]
-                pub = m.get('cur_dets') if getattr(opt, 'public_det', False) else None    # detector.py:141-142
+                pub = m['cur_dets'] if getattr(opt, 'public_det', False) else None       # detector.py:141-142
                 all_results.append(self.fast[s].step(rows[s], ctx['row_layout'], opt.out_thresh, tinv, pub).copy())
             t_track = time.time() - ta
         dets = None if self.native else self.last_dets
@@ -412,7 +414,7 @@ class StreamDetector(object):
             res = [r for r in res if r['score'] > opt.out_thresh]          # merge_outputs, detector.py:371-377
             tb = time.time()
             if tracking:
-                public_det = meta.get('cur_dets') if getattr(opt, 'public_det', False) else None
+                public_det = meta['cur_dets'] if getattr(opt, 'public_det', False) else None   # (KeyError like the reference)
                 res = self.trackers[s].step(res, public_det)
             tc = time.time()
             t_post += tb - ta
@@ -425,9 +427,11 @@ class StreamDetector(object):
 
     @property
     def last_dets(self):
-        """the reference's ``dets`` dict (decode.py:99-180) of the last step, as numpy views of the packed rows"""
+        """the reference's ``dets`` dict (decode.py:99-180) of the last step: numpy views of a per-frame COPY of the
+        packed rows -- the pinned D2H buffer is overwritten by the next step, while the reference's
+        ``.cpu().numpy()`` arrays (detector.py:349-350) stay valid for as long as a caller keeps the results"""
         if self._last_dets is None and self._ctx is not None:
-            self._last_dets = self._ctx['decoder'].unpack(self._ctx['host_rows'])
+            self._last_dets = self._ctx['decoder'].unpack(self._ctx['host_rows'].copy())
         return self._last_dets
 
     def reset_tracking(self, stream=None):

@@ -14,7 +14,12 @@ TRACK_DTYPE = np.dtype([('score', np.float32), ('class', np.int32), ('ct', np.fl
                         ('tracking', np.float32, 2), ('bbox', np.float32, 4), ('tracking_id', np.int32),
                         ('age', np.int32), ('active', np.int32), ('row', np.int32)], align=True)
 assert TRACK_DTYPE.itemsize == ctypes.sizeof(_lib.Track)
-MAX_BLOBS = 256
+MAX_BLOBS = 256        # minimum capacity of a stream's prior-heat-map blob table (grown to K when K is larger)
+
+
+def max_blobs(K):
+    """blob-table rows per stream: active tracks with score >= pre_thresh are this frame's detections, <= K"""
+    return max(MAX_BLOBS, int(K))
 
 
 def row_layout(layout):
@@ -65,7 +70,7 @@ class FastTracker(object):
         self.cap = 2 * K + 64
         self.buf = np.zeros(self.cap, TRACK_DTYPE)
         self._buf_ptr = self.buf.ctypes.data
-        self.params = np.zeros((MAX_BLOBS, 3), np.int32)
+        self.params = np.zeros((max_blobs(K), 3), np.int32)
 
     def __del__(self):
         try:
@@ -93,8 +98,19 @@ class FastTracker(object):
         else:
             n = self.lib.ct_tracker_step(self.h, rows.ctypes.data, K, F, ctypes.byref(lay), float(out_thresh),
                                          trans_inv.ctypes.data, self._buf_ptr, self.cap)
+        return self._result(n, 'ct_tracker_step')
+
+    def _result(self, n, what):
+        """the step's tracks; the list is unbounded in the reference (max_age > 0 accumulates unmatched tracks), so a
+        result larger than the buffer grows it and is re-read from the tracker (the step itself always completes)"""
         if n < 0:
-            _lib.check(1, 'ct_tracker_step')
+            _lib.check(1, what)
+        if n > self.cap:
+            self.cap = 2 * n
+            self.buf = np.zeros(self.cap, TRACK_DTYPE)
+            self._buf_ptr = self.buf.ctypes.data
+            got = self.lib.ct_tracker_get_tracks(self.h, self._buf_ptr, self.cap)
+            assert got == n, (got, n)
         return self.buf[:n]
 
     def step_dets(self, results, public_det=None):
@@ -104,9 +120,7 @@ class FastTracker(object):
         pub = _public_centres(public_det) if self.public_det else np.zeros((0, 2), np.float32)
         n = self.lib.ct_tracker_step_dets(self.h, dets.ctypes.data, len(dets), pub.ctypes.data, len(pub),
                                           self._buf_ptr, self.cap)
-        if n < 0:
-            _lib.check(1, 'ct_tracker_step_dets')
-        return self.buf[:n]
+        return self._result(n, 'ct_tracker_step_dets')
 
     def init_tracks(self, results):
         """``Tracker.init_track(results)`` (tracker.py:13-26): detections with score > new_thresh start tracks;
@@ -152,7 +166,7 @@ def as_dicts(arr, dets=None, stream=0, calib=None, carried=None):
             extras = {}
             for k in ('dep', 'dim'):
                 if k in dets:
-                    extras[k] = dets[k][stream][row]
+                    extras[k] = np.array(dets[k][stream][row])     # (own copy: `dets` may view a reused buffer)
             if 'rot' in dets:
                 extras['alpha'] = get_alpha(dets['rot'][stream][row:row + 1])[0]
             if calib is not None and all(k in dets for k in ('rot', 'dep', 'dim')):
@@ -161,7 +175,7 @@ def as_dicts(arr, dets=None, stream=0, calib=None, carried=None):
                 extras['loc'], extras['rot_y'] = ddd2locrot(ct, extras['alpha'], extras['dim'], extras['dep'], calib)
             for k in ('nuscenes_att', 'velocity'):
                 if k in dets:
-                    extras[k] = dets[k][stream][row]
+                    extras[k] = np.array(dets[k][stream][row])
             d.update(extras)
             if carried is not None:
                 carried[d['tracking_id']] = extras

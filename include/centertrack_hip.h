@@ -225,8 +225,9 @@ void ct_tracker_reset(void *tracker);
 int ct_tracker_num_tracks(void *tracker);
 int ct_tracker_id_count(void *tracker);
 int ct_tracker_get_tracks(void *tracker, ct_track *out, int cap);
-/* rows: HOST pointer [K,F]; trans_inv: float32 [2,3] output-grid -> image affine; returns the
- * number of tracks written to out (<= cap) or -1 */
+/* rows: HOST pointer [K,F]; trans_inv: float32 [2,3] output-grid -> image affine; returns the number of tracks
+ * after the step (the reference's list is unbounded: with max_age > 0 unmatched tracks accumulate) or -1; at most
+ * cap of them are written to out -- a caller that gets n > cap grows its buffer and reads ct_tracker_get_tracks */
 int ct_tracker_step(void *tracker, const float *rows, int K, int F, const ct_row_layout *lay, float out_thresh,
                     const float *trans_inv, ct_track *out, int cap);
 /* Remaining branches of the reference's Tracker (src/lib/utils/tracker.py): hungarian != 0 = optimal assignment

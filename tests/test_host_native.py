@@ -288,3 +288,83 @@ def test_native_results_as_dicts_carry_the_3d_fields_like_the_reference():
                                            atol=1e-5, err_msg='frame %d %s' % (t, k))
             seen_carried += int(a['active'] == 0)
     assert seen_carried > 0
+
+
+def test_result_dicts_do_not_alias_the_reused_rows_buffer():
+    """the packed rows live in ONE pinned buffer that every step overwrites; dicts handed out for
+    frame t (dep / dim / nuscenes_att / velocity and the tracks carried by max_age) must not change when the buffer
+    is rewritten for frame t+1 -- the reference's per-frame ``.cpu().numpy()`` arrays never do."""
+    rs = np.random.RandomState(2)
+    names = ['reg', 'wh', 'tracking', 'dep', 'rot', 'dim', 'amodel_offset', 'nuscenes_att', 'velocity']
+    lay_list, F = ops.decode_layout(names)
+    lay = FT.row_layout(lay_list)
+    off = {n: s for n, s, _ in lay_list}
+    K = 8
+    meta = IM.make_meta(448, 800, 900, 1600)
+    trans = np.ascontiguousarray(IM.get_affine_transform(
+        meta['c'], meta['s'], 0, (meta['out_width'], meta['out_height']), inv=1).astype(np.float32))
+    rows = np.zeros((1, K, F), np.float32)                # the "pinned buffer"
+    ft = FT.FastTracker(0.3, 2, K)
+    carried = {}
+
+    def fill(seed):
+        r = np.random.RandomState(seed)
+        rows[0] = r.uniform(0.5, 4, (K, F)).astype(np.float32)
+        rows[0, :, 0] = np.linspace(0.9, 0.4, K)
+        rows[0, :, 1] = 0
+        for j in range(K):
+            c = np.array([20.0 + 20 * j, 50.0])
+            rows[0, j, 2:4] = c
+            rows[0, j, off['bboxes']:off['bboxes'] + 4] = [c[0] - 6, c[1] - 6, c[0] + 6, c[1] + 6]
+            rows[0, j, off['tracking']:off['tracking'] + 2] = 0
+
+    def unpack(buf):
+        d = {n: (buf[..., s] if n in ('scores', 'clses', 'xs', 'ys') else buf[..., s:s + w]) for n, s, w in lay_list}
+        d['cts'] = buf[..., 2:4]
+        return d
+
+    fill(1)
+    frame0 = FT.as_dicts(ft.step(rows[0], lay, 0.3, trans).copy(), unpack(rows), 0, meta['calib'], carried)
+    snap = [{k: np.array(v, copy=True) for k, v in d.items()} for d in frame0]
+    fill(2)                                               # the next step's D2H lands in the same memory
+    rows[0, :, 0] = 0.01                                  # ... and detects nothing: every track is carried over
+    frame1 = FT.as_dicts(ft.step(rows[0], lay, 0.3, trans).copy(), unpack(rows), 0, meta['calib'], carried)
+    for d, s in zip(frame0, snap):
+        for k in s:
+            np.testing.assert_array_equal(np.asarray(d[k]), s[k], err_msg=k)
+    assert len(frame1) == len(frame0) and all(r['active'] == 0 for r in frame1)
+    for d, s in zip(frame1, snap):                        # carried tracks show the fields of their last detection
+        for k in ('dep', 'dim', 'nuscenes_att', 'velocity'):
+            np.testing.assert_array_equal(np.asarray(d[k]), s[k], err_msg=k)
+
+
+def test_native_tracker_grows_past_its_initial_capacity():
+    """with max_age > 0 unmatched tracks accumulate beyond 2K+64; the step completes, the result buffer
+    grows, and ids / order stay those of the Python tracker."""
+    K = 6
+    lay_list, F = ops.decode_layout(['reg', 'wh', 'tracking'])
+    lay = FT.row_layout(lay_list)
+    meta = IM.make_meta(512, 512, 512, 512)
+    trans = np.ascontiguousarray(IM.get_affine_transform(
+        meta['c'], meta['s'], 0, (meta['out_width'], meta['out_height']), inv=1).astype(np.float32))
+    opt = types.SimpleNamespace(out_thresh=0.3, new_thresh=0.3, max_age=40, hungarian=False, public_det=False)
+    ft, pt = FT.FastTracker(0.3, 40, K), TR.Tracker(opt)
+    cap0 = ft.cap
+    for t in range(30):                                   # K brand-new far-apart objects per frame, none re-detected
+        rows = np.zeros((K, F), np.float32)
+        rows[:, 0] = np.linspace(0.9, 0.5, K)
+        for j in range(K):
+            c = np.array([3.0 + 7 * ((t * K + j) % 17), 3.0 + 7 * ((t * K + j) // 17)], np.float32)
+            rows[j, 2:4] = c
+            rows[j, 4:8] = [c[0] - 1, c[1] - 1, c[0] + 1, c[1] + 1]
+        dec = {n: (rows[None, :, s] if n in ('scores', 'clses', 'xs', 'ys') else rows[None, :, s:s + w])
+               for n, s, w in lay_list}
+        dec['cts'] = rows[None, :, 2:4]
+        got = ft.step(rows, lay, 0.3, trans).copy()
+        res = PP.generic_post_process(opt, dec, [meta['c']], [meta['s']], meta['out_height'], meta['out_width'])[0]
+        want = pt.step([r for r in res if r['score'] > 0.3])
+        assert [int(x['tracking_id']) for x in got] == [int(x['tracking_id']) for x in want], t
+        assert [int(x['age']) for x in got] == [int(x['age']) for x in want], t
+    assert len(got) > cap0 and ft.cap > cap0
+    n, prm = ft.prehm_params(0.3, meta['trans_input'], 512, 512)
+    assert n == K                                         # only this frame's detections are active
