@@ -5,22 +5,32 @@
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
         --master-port P bench.py --gpus N --steps K --warmup W
 
-A "step" is one frame of every stream the rank owns through the whole hot path
-(BASELINE.json north_star / SURVEY.md section 8d): frame already resident in HBM -> three
-stems + DLA-34 + 16 DCNv2 nodes + heads (fp32, sigmoid fused) -> NMS/top-K/gather decode
--> one packed D2H -> host post-process -> track association (and, for N > 1, the RCCL
-all-gather of the packed detections).  Workload at N=1: BASELINE.json configs[1] =
-MOT17-half heads, DLA-34, 512x512, batch 1 (one stream), synthetic frames, seeded
-random-init weights.  Weak scaling: every rank runs the same number of streams.
+The metric is SURVEY.md section 8(d)'s: the end-to-end ``Detector.run`` equivalent --
+**H2D of a ready fp32 frame (pinned host memory, src/lib/detector.py:93-94)** -> three stems +
+DLA-34 + 16 DCNv2 nodes + heads (fp32, sigmoid fused) -> NMS / top-K / gather decode -> one
+packed D2H -> host post-process -> track association (and, for N > 1, the RCCL all-gather of
+the packed detections).  The H2D is INSIDE the timed step; the rate with frames already
+resident in HBM is reported next to it (``resident_frames_fps``), never as ``value``.
+
+A "step" is one clip: ``frames_per_step`` consecutive frames of every stream the rank owns
+(frames of one stream are sequential -- each needs the previous frame and the tracker state --
+so a clip is the natural batch of synthetic input; the default of 64 / streams frames makes the
+driver's 20 steps a > 1 s timed region).  ``value`` = streams x frames / time.  Workload at
+N=1: BASELINE.json configs[1] = MOT17-half heads, DLA-34, 512x512, batch 1 (one stream),
+synthetic frames, seeded random-init weights.  Weak scaling: every rank runs the same number
+of streams.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the DCNv2 kernel (dcn_mfma_kernel): algorithmic flops (2*9*Cin*Cout*h*w per
-                layer) and algorithmic bytes (4*(Cin*h*w + 27*h*w + Cout*h*w + 9*Cin*Cout
-                + Cout)) of the 16 DCN layers / their summed launch time, measured with HIP
-                events on the launch stream (graph replay of exactly these launches) in this process;
-                traffic = HBM bytes per launch from the committed rocprofv3 PMC passes (profiles/)
-  cpu_baseline  the CPU oracle (oracle/, a port of the reference's CPU path) timed on the
-                host cores for a bounded sample of the same workload (reported baseline only)
+                layer, + the fused offset/mask conv's) and algorithmic bytes (4*(Cin*h*w + 27*h*w
+                + Cout*h*w + 9*Cin*Cout + Cout)) of the 16 DCN layers / their summed launch time,
+                measured with HIP events on the launch stream (graph replay of exactly these
+                launches) in this process; ``frac_main`` = the same with section 8(d)'s formula
+                (main contraction only); traffic = HBM bytes per launch from the committed
+                rocprofv3 PMC passes (profiles/)
+  cpu_baseline  the CPU oracle (oracle/, a port of the reference's CPU path) timed on the host
+                cores: thread sweep, then >= 20 frames after 3 warm-ups at the best thread count
+                (reported baseline only)
 """
 import argparse
 import json
@@ -41,8 +51,10 @@ PEAK_HBM_GBS = 8000.0
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=20)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--frames-per-step', type=int, default=0,
+                    help='consecutive frames of every stream in one step; 0 = max(4, 64 // streams)')
     ap.add_argument('--config', default='mot17_512', help='workload name (centertrack_amd.scenarios.CONFIGS)')
     ap.add_argument('--streams', type=int, default=0, help='streams (batch) per GPU; 0 = 1 (the headline config)')
     ap.add_argument('--height', type=int, default=0)
@@ -50,11 +62,13 @@ def parse():
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-roofline', action='store_true')
-    ap.add_argument('--cpu-frames', type=int, default=3)
+    ap.add_argument('--no-resident', action='store_true', help='skip the extra resident-frames loop')
+    ap.add_argument('--cpu-frames', type=int, default=20)
+    ap.add_argument('--cpu-threads', default='8,16,32,64', help='thread counts of the CPU-baseline sweep')
     ap.add_argument('--hm-gain', type=float, default=11.0)
-    ap.add_argument('--pcie', action='store_true',
-                    help='also report the PCIe-inclusive rates (pinned host fp32 frames; raw u8 1080p frames with the '
-                         'device-side pre-processing) under "pcie_inclusive" -- never the headline value')
+    ap.add_argument('--raw-u8', action='store_true',
+                    help='also report the rate with raw u8 1080p frames handed to step() (u8 H2D + device-side '
+                         'pre-processing) under "raw_u8_1080p_fps" -- never the headline value')
     return ap.parse_args()
 
 
@@ -96,11 +110,12 @@ def kernel_pass(model, plan, reps=10):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        flops = bytes_ = 0.0
+        flops = flops_main = bytes_ = 0.0
         for l in launches:
             d = l.args
             if kind == 'dcn':
                 hw = d.N * d.H * d.W
+                flops_main += 2.0 * 9 * d.Cin * d.Cout * hw
                 flops += 2.0 * 9 * d.Cin * d.Cout * hw
                 bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout)
                 if d.fuse_offset:          # offset/mask conv computed in the same launch: its flops and weights
@@ -114,7 +129,7 @@ def kernel_pass(model, plan, reps=10):
                 wo = (d.W + 2 * pad - d.ks) // d.stride + 1
                 flops += 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)
-        stats[kind] = dict(launches=len(launches), flops=flops, bytes=bytes_, ms=ms)
+        stats[kind] = dict(launches=len(launches), flops=flops, flops_main=flops_main, bytes=bytes_, ms=ms)
     return stats
 
 
@@ -130,21 +145,54 @@ def pmc_traffic():
         return None, None
 
 
-def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes):
-    """CPU oracle (port of the reference CPU path) on the same workload, bounded sample."""
+def cpu_model():
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
+    """CPU oracle (port of the reference CPU path) on the same workload, bounded sample: a thread sweep (1 warm-up + 2
+    timed frames per thread count), then ``nframes`` frames after 3 warm-ups at the best count."""
     from oracle import detector as odet
     oopt = odet.default_opt(input_h=cfg['H'], input_w=cfg['W'], num_classes=heads['hm'], **opt_kw)
     det = odet.Detector(oopt, sd, heads)
     if oopt.flip_test:
         frames_cpu = [torch.cat((f, torch.flip(f, [3])), 0) for f in frames_cpu]
-    det.run(frames_cpu[0], dict(metas[0]))                   # warm-up frame (thread pools, first-touch)
-    t0 = time.time()
-    for i in range(nframes):
-        det.run(frames_cpu[(i + 1) % len(frames_cpu)], dict(metas[0]))
-    dt = time.time() - t0
-    return dict(value=round(nframes / dt, 4), unit='frames/s', cores=torch.get_num_threads(), kind='port',
-                sample='%d frames of the N=1 workload (1 stream, %dx%d) through oracle/detector.py after 1 warm-up '
-                       'frame; pure-PyTorch CPU restatement of the reference path incl. DCNv2' % (nframes, cfg['H'], cfg['W']))
+    ncpu = os.cpu_count() or 1
+    counts = sorted({min(max(1, t), ncpu) for t in sweep})
+    saved = torch.get_num_threads()
+    per_thread = {}
+
+    def run(n, first):
+        t0 = time.time()
+        for i in range(n):
+            det.run(frames_cpu[(first + i) % len(frames_cpu)], dict(metas[0]))
+        return time.time() - t0
+
+    try:
+        for t in counts:
+            torch.set_num_threads(t)
+            det.reset_tracking()
+            run(1, 0)
+            per_thread[t] = round(2 / run(2, 1), 3)
+        best = max(per_thread, key=per_thread.get)
+        torch.set_num_threads(best)
+        det.reset_tracking()
+        run(3, 0)
+        fps = nframes / run(nframes, 3)
+    finally:
+        torch.set_num_threads(saved)
+    return dict(value=round(fps, 4), unit='frames/s', cores=best, kind='port', cpu=cpu_model(), host_cpus=ncpu,
+                thread_sweep_fps=per_thread,
+                sample='%d frames of the N=1 workload (1 stream, %dx%d) through oracle/detector.py after 3 warm-up '
+                       'frames at the best thread count of the sweep (1 warm-up + 2 timed frames per count); '
+                       'pure-PyTorch CPU restatement of the reference path incl. DCNv2' % (nframes, cfg['H'], cfg['W']))
 
 
 def main():
@@ -173,6 +221,7 @@ def main():
     if args.width:
         cfg['W'] = args.width
     B = args.streams if args.streams > 0 else 1
+    fps_step = args.frames_per_step if args.frames_per_step > 0 else max(4, 64 // B)
     heads = S.HEAD_SETS[cfg['heads']]
     sd = W.make_synthetic_state_dict(heads, seed=317, hm_gain=args.hm_gain)
     if 'ltrb_amodal' in heads:
@@ -183,48 +232,68 @@ def main():
     model.load_state_dict(sd)
     det = StreamDetector(opt, model=model, num_streams=B, use_graph=not args.no_graph)
 
-    # synthetic stream: a fixed N(0,1) image scrolled by 4 px / frame, T distinct frames resident in HBM
+    # synthetic stream: a fixed N(0,1) image scrolled by 4 px / frame, T distinct frames in PINNED host memory (what
+    # the reference's PrefetchDataset / DataLoader(pin_memory=True) hands to Detector.run, test.py:74-76)
     T = 8
     g = torch.Generator().manual_seed(317 + 7 + rank)
     base = torch.randn((B, 3, cfg['H'], cfg['W'] + 4 * T), generator=g, dtype=torch.float32)
     frames_cpu = [base[:, :, :, 4 * t:4 * t + cfg['W']].contiguous() for t in range(T)]
-    frames = [f.to(device) for f in frames_cpu]
+    pinned = [f.pin_memory() for f in frames_cpu]
     meta = make_meta(cfg['H'], cfg['W'], cfg['H'] * 2, cfg['W'] * 2)
     metas = [meta] * B
 
     total_streams = B * world
-    gathered = {}
+    gatherer = None
+    last = {}
     if world > 1:
+        K, F = det_rows_shape(det, cfg)
+        gatherer = parallel.DetectionGatherer(total_streams, world, rank, K, F, device)
+
         def gather(rows):
-            gathered['rows'] = parallel.gather_detections(rows, total_streams, world, rank)
+            last['rows'] = rows
+            last['all'] = gatherer(rows)
         det.gather_fn = gather
-    ndet = 0
-    for i in range(args.warmup):
-        res = det.step(frames[i % T], metas)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        res = det.step(frames[i % T], metas)
-        ndet += sum(len(r) for r in res)
-    torch.cuda.synchronize()
-    parallel.barrier()
-    torch.cuda.synchronize()
-    dt = parallel.max_over_ranks(time.perf_counter() - t0)
-    fps = total_streams * args.steps / dt
+
+    def timed(frame_of, steps, first=0):
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        nfr, ndet = parallel.run_steps(det, frame_of, metas, steps, fps_step, first)
+        torch.cuda.synchronize()
+        parallel.barrier()
+        torch.cuda.synchronize()
+        return parallel.max_over_ranks(time.perf_counter() - t0), nfr, ndet
+
+    host_frame = lambda t: pinned[t % T]
+    parallel.run_steps(det, host_frame, metas, args.warmup, fps_step)
+    dt, nfr, ndet = timed(host_frame, args.steps, args.warmup * fps_step)
+    fps = total_streams * nfr / dt
+    rccl_ranks = 1
+    if gatherer is not None:                         # outside the timed region: prove what the collective moved
+        rccl_ranks = gatherer.verify(last['rows'])
 
     out = {
-        'metric': 'frames/sec (DLA-34 + DCNv2 CenterTrack hot path: forward + decode + track association)',
+        'metric': 'frames/sec (DLA-34 + DCNv2 CenterTrack hot path: H2D of the frame + forward + decode + D2H + '
+                  'track association)',
         'value': round(fps, 2), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
         'ms_per_step': round(1000.0 * dt / args.steps, 4), 'higher_is_better': True, 'scaling': 'weak',
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s heads, DLA-34, %dx%d, %d stream(s)/GPU, K=%d, flip_test=%s, seeded random-init '
-                               'weights' % (args.config, cfg['heads'], cfg['H'], cfg['W'], B, opt.K, cfg['flip']),
-                   'global_batch': total_streams, 'parallelism': 'streams sharded dp%d, all-gather of packed detections' % world,
-                   'hip_graph': det._ctx['graph'] is not None, 'mean_detections_per_frame': round(ndet / max(1, args.steps * B), 1)},
-        'fps_per_gpu': round(fps / world, 2),
+                               'weights; one step = %d consecutive frames of every stream, each frame uploaded from '
+                               'pinned host memory inside the step' % (args.config, cfg['heads'], cfg['H'], cfg['W'], B,
+                                                                      opt.K, cfg['flip'], fps_step),
+                   'global_batch': total_streams, 'frames_per_step': fps_step,
+                   'parallelism': 'streams sharded dp%d, all-gather of packed detections' % world,
+                   'hip_graph': det._ctx['graph'] is not None,
+                   'mean_detections_per_frame': round(ndet / max(1, nfr * B), 1)},
+        'fps_per_gpu': round(fps / world, 2), 'ms_per_frame_batch': round(1000.0 * dt / max(1, nfr), 4),
+        'timed_region_s': round(dt, 3), 'h2d_in_timed_region': True, 'rccl_ranks': rccl_ranks,
     }
+    if not args.no_resident:
+        frames = [f.to(device) for f in frames_cpu]
+        dt2, nfr2, _ = timed(lambda t: frames[t % T], args.steps)
+        out['resident_frames_fps'] = round(total_streams * nfr2 / dt2, 2)
     if rank == 0:
         ctx = det._ctx
         # device-only time of one frame (graph replay or eager launches), HIP events on the launch stream
@@ -241,14 +310,19 @@ def main():
         torch.cuda.synchronize()
         dev_ms = e0.elapsed_time(e1) / reps
         out['device_ms_per_frame_batch'] = round(dev_ms, 4)
+        out['launches_per_frame'] = len(ctx['plan']['launches'])
         if not args.no_roofline:
             st = kernel_pass(det.model, ctx['plan'])
             d = st['dcn']
             tf = d['flops'] / (d['ms'] * 1e-3) / 1e12
+            tf_main = d['flops_main'] / (d['ms'] * 1e-3) / 1e12
             gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-            out['roofline'] = {'kernel': 'dcn_mfma_kernel (16 DCNv2 layers of one frame batch, incl. split-K reduce)',
+            out['roofline'] = {'kernel': 'dcn_mfma_kernel (16 DCNv2 layers of one frame batch incl. their fused offset/mask '
+                                         'convs and split-K reduce / up-sample launches)',
                                'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                               'frac': round(tf / PEAK_FP32_TFLOPS, 4), 'traffic': None, 'traffic_source': None,
+                               'frac': round(tf / PEAK_FP32_TFLOPS, 4),
+                               'frac_main': round(tf_main / PEAK_FP32_TFLOPS, 4),      # main contraction only
+                               'traffic': None, 'traffic_source': None,
                                'avg_launch_us': round(1000.0 * d['ms'] / d['launches'], 2),
                                'hbm': {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': round(gbs / PEAK_HBM_GBS, 4),
@@ -264,32 +338,25 @@ def main():
                 if tb is not None:
                     out['roofline']['traffic'] = round(tb)
                     out['roofline']['traffic_source'] = src
-        if args.pcie and world == 1:
-            # the boundary of the reference hands over HOST frames (PrefetchDataset, test.py:22-51): same loop with the
-            # H2D copy inside the step, and with raw u8 1080p frames warped / normalised on the device
+        if args.raw_u8 and world == 1:
+            # raw u8 1080p frames handed to step(): u8 H2D + warp / normalise on the device
             det2 = StreamDetector(opt, model=model, num_streams=B, use_graph=not args.no_graph)
-            pinned = [f.pin_memory() for f in frames_cpu]
             raw = [np.random.RandomState(t).randint(0, 256, (1080, 1920 + 8, 3)).astype(np.uint8) for t in range(2)]
             rmeta = make_meta(cfg['H'], cfg['W'], 1080, 1920)
-            modes = {'host_fp32_pinned_frames': lambda i: det2.step(pinned[i % T], metas),
-                     'raw_u8_1080p_frames_device_preprocess':
-                         lambda i: det2.step([raw[i & 1][:, 4 * (i % 3):4 * (i % 3) + 1920]] * B, [rmeta] * B)}
-            out['pcie_inclusive'] = {}
-            for name, fn in modes.items():
-                det2.reset_tracking()
-                for i in range(args.warmup):
-                    fn(i)
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for i in range(args.steps):
-                    fn(i)
-                torch.cuda.synchronize()
-                out['pcie_inclusive'][name] = round(B * args.steps / (time.perf_counter() - t1), 2)
-            out['pcie_inclusive']['unit'] = 'frames/s'
+            fn = lambda i: det2.step([raw[i & 1][:, 4 * (i % 3):4 * (i % 3) + 1920]] * B, [rmeta] * B)
+            n = args.steps * fps_step
+            for i in range(args.warmup * fps_step):
+                fn(i)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for i in range(n):
+                fn(i)
+            torch.cuda.synchronize()
+            out['raw_u8_1080p_fps'] = round(B * n / (time.perf_counter() - t1), 2)
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out['cpu_baseline'] = cpu_baseline(cfg, heads, sd, [f[0:1] for f in frames_cpu], metas, opt_kw,
-                                                   args.cpu_frames)
+                                                   args.cpu_frames, [int(t) for t in args.cpu_threads.split(',')])
             except Exception as e:  # the baseline is informational; never lose the GPU line
                 out['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
                                        'kind': 'port', 'sample': 'failed: %r' % (e,)}
@@ -297,6 +364,12 @@ def main():
         sys.stdout.flush()
     parallel.barrier()
     parallel.shutdown()
+
+
+def det_rows_shape(det, cfg):
+    """(K, F) of the packed decode rows of this detector (known once its context exists)"""
+    ctx = det._context(cfg['H'], cfg['W'])
+    return int(ctx['decoder'].out.shape[1]), int(ctx['decoder'].out.shape[2])
 
 
 if __name__ == '__main__':

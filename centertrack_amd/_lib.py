@@ -76,6 +76,14 @@ class PoseDesc(ctypes.Structure):
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
 
 
+class FlipHead(ctypes.Structure):
+    _fields_ = [('src', ctypes.c_void_p), ('dst', ctypes.c_void_p), ('src_batch_stride', ctypes.c_size_t),
+                ('C', ctypes.c_int), ('mode', ctypes.c_int)]
+
+
+CT_FLIP_AVG, CT_FLIP_NEG_EVEN, CT_FLIP_JOINTS, CT_FLIP_JOINT_OFFSETS = range(4)
+
+
 class RowLayout(ctypes.Structure):
     _fields_ = [(n, ctypes.c_int) for n in ('score', 'cls', 'cts', 'tracking', 'bbox', 'amodel_offset')]
 
@@ -97,7 +105,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
            'ct_tracker_step_public', 'ct_tracker_step_dets',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
-           'ct_memcpy_async', 'ct_stream_synchronize']
+           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_flip_merge', 'ct_flip_images']
 
 _lib = None
 
@@ -172,6 +180,9 @@ def load():
     lib.ct_graph_destroy.argtypes = [p]
     lib.ct_memcpy_async.argtypes = [p, p, sz, i, p]
     lib.ct_stream_synchronize.argtypes = [p]
+    lib.ct_memset_async.argtypes = [p, i, sz, p]
+    lib.ct_flip_merge.argtypes = [ctypes.POINTER(FlipHead), i, p, i, i, i, i, p]
+    lib.ct_flip_images.argtypes = [p, p, sz, i, p]
     # CENTERTRACK_TUNE="key=value,key=value": launch-heuristic knobs of ct_set_tuning (A/B runs)
     for kv in filter(None, os.environ.get('CENTERTRACK_TUNE', '').split(',')):
         k, _, v = kv.partition('=')

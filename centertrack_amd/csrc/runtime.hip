@@ -60,6 +60,16 @@ extern "C" int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kin
     return CT_OK;
 }
 
+extern "C" int ct_memset_async(void *dst, int value, size_t bytes, void *stream)
+{
+    hipError_t e = hipMemsetAsync(dst, value, bytes, (hipStream_t)stream);
+    if (e != hipSuccess) {
+        ct_set_error("ct_memset_async: %s", hipGetErrorString(e));
+        return CT_ERR_LAUNCH;
+    }
+    return CT_OK;
+}
+
 extern "C" int ct_stream_synchronize(void *stream)
 {
     hipError_t e = hipStreamSynchronize((hipStream_t)stream);

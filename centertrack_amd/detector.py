@@ -158,12 +158,29 @@ class StreamDetector(object):
         outs = plan['outputs']
         ctx = {'hw': (H, W), 'plan': plan, 'NB': NB}
         if self.flip:
-            merged = {k: torch.empty((self.B,) + tuple(v.shape[1:]), device=self.device) for k, v in outs.items()}
+            # detector.py:311-332: averaged heads get a merged [B,c,h,w] map (ct_flip_merge, one launch for all of
+            # them); the heads the reference takes from the un-flipped image alone are read in place (first B images)
+            modes = {'hps': _lib.CT_FLIP_JOINT_OFFSETS, 'hm_hp': _lib.CT_FLIP_JOINTS}
+            modes.update({k: _lib.CT_FLIP_AVG for k in AVERAGE_FLIPS})
+            modes.update({k: _lib.CT_FLIP_NEG_EVEN for k in NEG_AVERAGE_FLIPS})
+            merged, fl = {}, []
+            for k, v in outs.items():
+                if k in modes:
+                    merged[k] = torch.empty((self.B,) + tuple(v.shape[1:]), device=self.device)
+                    fl.append((v, merged[k], modes[k]))
+                else:
+                    merged[k] = v[:self.B]
+            heads_arr = (_lib.FlipHead * len(fl))()
+            for i, (v, m, mode) in enumerate(fl):
+                assert v.stride(3) == 1 and v.stride(2) == v.shape[3] and v.stride(1) == v.shape[2] * v.shape[3]
+                heads_arr[i].src, heads_arr[i].dst = v.data_ptr(), m.data_ptr()
+                heads_arr[i].src_batch_stride, heads_arr[i].C, heads_arr[i].mode = v.stride(0), v.shape[1], mode
+            pairs = np.ascontiguousarray(getattr(opt, 'flip_idx', COCO_FLIP_IDX), np.int32).reshape(-1, 2)
+            hm0 = outs['hm']
+            ctx['flip_call'] = (heads_arr, len(fl), pairs, int(hm0.shape[2]), int(hm0.shape[3]))
         else:
             merged = outs
         ctx['merged'] = merged
-        if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:
-            pass
         dec_heads = {k: v for k, v in merged.items() if k != 'hm'}
         ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
         ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
@@ -199,15 +216,24 @@ class StreamDetector(object):
             if with_copies and render:
                 _lib.check(_lib.load().ct_memcpy_async(ctx['pc_dev'].data_ptr(), ctx['pc_host'].data_ptr(),
                                                        ctx['pc_host'].numel() * 4, 1, _lib.stream_ptr()), 'H2D')
+            lib = _lib.load()
             if render:
-                _lib.check(_lib.load().ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
-                                                        ctx['max_blobs'], self.B, H, W, hm_in.data_ptr(),
-                                                        1 if self.flip else 0, _lib.stream_ptr()), 'ct_render_pre_hm')
+                _lib.check(lib.ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
+                                                ctx['max_blobs'], self.B, H, W, hm_in.data_ptr(),
+                                                1 if self.flip else 0, _lib.stream_ptr()), 'ct_render_pre_hm')
+            if self.flip:
+                # the mirrored half of the batch (detector.py:224-226), built from the frames already in HBM
+                _lib.check(lib.ct_flip_images(cur.data_ptr(), cur[self.B:].data_ptr(), self.B * 3 * H, W,
+                                              _lib.stream_ptr()), 'ct_flip_images')
             self.model._run_plan(plan, inputs=(cur, prev, hm_in))
             if self.flip:
-                self._flip_merge(outs, merged)
-            if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:
-                merged['tracking'].zero_()
+                arr, n, pairs, h, w = ctx['flip_call']
+                _lib.check(lib.ct_flip_merge(arr, n, pairs.ctypes.data, len(pairs), self.B, h, w, _lib.stream_ptr()),
+                           'ct_flip_merge')
+            if getattr(opt, 'zero_tracking', False) and 'tracking' in merged:      # decode.py:142-143 `*= 0`
+                t = merged['tracking']
+                for b in range(t.shape[0]):
+                    _lib.check(lib.ct_memset_async(t[b].data_ptr(), 0, t[b].numel() * 4, _lib.stream_ptr()), 'memset')
             ctx['decoder'].run()
             if with_copies:
                 _lib.check(_lib.load().ct_memcpy_async(ctx['host_out'].data_ptr(), ctx['decoder'].out.data_ptr(),
@@ -223,9 +249,9 @@ class StreamDetector(object):
                     device_frame(0)           # warm-up (lazy module loads must not happen in capture)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
-                # only C-ABI launches inside device_frame (no torch op): capture / replay straight through HIP
-                raw = (not self.flip and not getattr(opt, 'zero_tracking', False)
-                       and os.environ.get('CENTERTRACK_RAW_GRAPH', '1') != '0')
+                # only C-ABI launches inside device_frame (no torch op, flip_test included): capture / replay
+                # straight through HIP
+                raw = os.environ.get('CENTERTRACK_RAW_GRAPH', '1') != '0'
                 for par in ((0, 1) if img_in is not None else (0,)):
                     if raw:
                         g = _HipGraph(lambda: device_frame(par, True))
@@ -235,8 +261,13 @@ class StreamDetector(object):
                             device_frame(par)
                     ctx['graphs'][par] = g
                 ctx['raw'] = raw
-            except Exception as e:             # capture is an optimisation; eager launches are the same kernels
-                print('centertrack_amd: HIP graph capture failed (%s); using eager launches' % e)
+            except Exception as e:
+                # never degrade silently: the eager launches are the same kernels at a fraction of the frame rate
+                if os.environ.get('CENTERTRACK_GRAPH_FALLBACK', '0') != '1':
+                    raise _lib.CTError('HIP graph capture of the frame failed (%s); pass use_graph=False or set '
+                                       'CENTERTRACK_GRAPH_FALLBACK=1 to run eager launches' % (e,))
+                import warnings
+                warnings.warn('centertrack_amd: HIP graph capture failed (%s); using eager launches' % (e,))
                 ctx['graphs'] = [None, None]
                 torch.cuda.synchronize()
         ctx['graph'] = ctx['graphs'][0]
@@ -268,34 +299,6 @@ class StreamDetector(object):
                                             frames[self.B + s].data_ptr() if self.flip else None, st),
                    'ct_preprocess_device')
 
-    def _flip_merge(self, outs, merged):
-        """detector.py:311-332 (non-pose heads), for [B originals ; B flipped]."""
-        B = self.B
-        for head, v in outs.items():
-            if head in AVERAGE_FLIPS:
-                torch.add(v[:B], torch.flip(v[B:], [3]), out=merged[head])
-                merged[head].div_(2)
-            elif head in NEG_AVERAGE_FLIPS:
-                f = torch.flip(v[B:], [3])
-                f[:, 0::2] *= -1
-                torch.add(v[:B], f, out=merged[head])
-                merged[head].div_(2)
-            elif head in ('hps', 'hm_hp'):                     # flip_lr_off / flip_lr, model/utils.py:33-50
-                f = torch.flip(v[B:], [3])
-                perm = list(range(f.shape[1] // (2 if head == 'hps' else 1)))
-                for a, b in getattr(self.opt, 'flip_idx', COCO_FLIP_IDX):
-                    perm[a], perm[b] = perm[b], perm[a]
-                if head == 'hps':
-                    f = f.reshape(f.shape[0], -1, 2, f.shape[2], f.shape[3])[:, perm]
-                    f[:, :, 0] *= -1
-                    f = f.reshape(v[B:].shape)
-                else:
-                    f = f[:, perm]
-                torch.add(v[:B], f, out=merged[head])
-                merged[head].div_(2)
-            else:
-                merged[head].copy_(v[:B])
-
     # ---- one frame for every stream -------------------------------------------------------
     def step(self, images, metas, timers=None):
         """images: float32 [B,3,H,W] (already normalised, like PrefetchDataset hands over), or a list of B raw
@@ -313,14 +316,27 @@ class StreamDetector(object):
             H, W = int(images.shape[2]), int(images.shape[3])
         ctx = self._context(H, W)
         x_in, img_in, hm_in = ctx['plan']['inputs']
+        lib = _lib.load()
+        par = ctx['parity'] if img_in is not None else 0
+        fr = ctx['frames'][par]
+        # ---- the frame goes straight into the graph's frame buffer (images [0, B); the mirrored images [B, 2B) of
+        #      flip_test are built on the device by the frame's first launch, detector.py:224-226) ----
         if raw_frames:
-            x_dev = ctx['frames'][ctx['parity'] if img_in is not None else 0]
             for s in range(B):
-                self._warp_frame(s, images[s], metas[s], x_dev, H, W)
+                self._warp_frame(s, images[s], metas[s], fr, H, W)
         else:
-            if self.flip:
-                images = torch.cat((images, torch.flip(images, [3])), 0)
-            x_dev = images if images.device == self.device else images.to(self.device, non_blocking=True)
+            if images.shape[0] == 2 * B and self.flip:
+                images = images[:B]                            # (a pre-flipped batch: the copy is rebuilt on device)
+            if tuple(images.shape) != (B, 3, H, W):
+                raise _lib.CTError('step() expects [%d,3,%d,%d] frames, got %s' % (B, H, W, tuple(images.shape)))
+            if images.dtype == torch.float32 and images.is_contiguous():
+                # one DMA from wherever the caller keeps the frame: H2D for a host tensor (detector.py:93-94 -- pinned
+                # memory makes it asynchronous), D2D for a resident one
+                kind = 0 if images.device.type == 'cuda' else 1
+                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), images.data_ptr(), images.numel() * 4, kind,
+                                               _lib.stream_ptr()), 'frame copy')
+            else:
+                fr[:B].copy_(images)
         tracking = bool(getattr(opt, 'tracking', False))
         if tracking:
             for s in range(B):
@@ -332,15 +348,18 @@ class StreamDetector(object):
                         self.trackers[s].init_track(pre_dets)
             if img_in is not None:
                 # first frame of a stream: pre_images = images (detector.py:99-103)
-                prev = ctx['frames'][ctx['parity'] ^ 1]
+                prev = ctx['frames'][par ^ 1]
                 fresh = [s for s in range(B) if not self.started[s]]
+                if fresh and self.flip:
+                    _lib.check(lib.ct_flip_images(fr.data_ptr(), fr[B:].data_ptr(), B * 3 * H, W, _lib.stream_ptr()),
+                               'ct_flip_images')
                 if len(fresh) == B:
-                    prev.copy_(x_dev)
+                    prev.copy_(fr)
                 else:
                     for s in fresh:
-                        prev[s].copy_(x_dev[s])
+                        prev[s].copy_(fr[s])
                         if self.flip:
-                            prev[B + s].copy_(x_dev[B + s])
+                            prev[B + s].copy_(fr[B + s])
             if hm_in is not None and self.native:
                 ph, ch = ctx['prm_host'].numpy(), ctx['cnt_host'].numpy()
                 for s in range(B):
@@ -359,14 +378,6 @@ class StreamDetector(object):
                 hm_in.copy_(hh, non_blocking=True)
             for s in range(B):
                 self.started[s] = True
-        par = ctx['parity'] if img_in is not None else 0
-        fr = ctx['frames'][par]
-        if x_dev is fr:
-            pass                                               # (raw frames were warped straight into it)
-        elif ctx['raw'] and x_dev.is_contiguous() and x_dev.dtype == torch.float32 and x_dev.shape == fr.shape:
-            _lib.load().ct_memcpy_async(fr.data_ptr(), x_dev.data_ptr(), fr.numel() * 4, 0, _lib.stream_ptr())
-        else:
-            fr.copy_(x_dev)
         t1 = time.time()
         if ctx['graphs'][par] is not None:
             ctx['graphs'][par].replay()
@@ -535,8 +546,6 @@ class Detector(object):
         else:
             raise _lib.CTError('run() takes a uint8 image array, a normalised tensor + meta, or a pre-processed '
                                'dict; reading image files (cv2.imread) is left to the caller')
-        if torch.is_tensor(images) and images.shape[0] == 2 and self.impl.flip:
-            images = images[0:1]                               # the flipped copy is rebuilt on device
         loaded = time.time()
         timers = {}
         results = self.impl.results_as_dicts(self.impl.step(images, [meta], timers)[0], 0, meta)

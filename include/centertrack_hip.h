@@ -205,6 +205,30 @@ int ct_decode_pose(const ct_pose_desc *d, void *stream);
 int ct_render_pre_hm(const int *params, const int *counts, int cap, int B, int H, int W, float *out,
                      int also_flipped, void *stream);
 
+/* ---- flip_test on the device ------------------------------------------------------------
+ * Replaces Detector._flip_output (src/lib/detector.py:311-332) with flip_tensor / flip_lr / flip_lr_off
+ * (src/lib/model/utils.py:28-50) and the `np.concatenate((images, images[:, :, :, ::-1]))` of
+ * Detector.pre_process (detector.py:224-226) for B streams: the network runs on [B originals ; B mirrored images].
+ * ct_flip_merge: for every listed head  dst[b,c,y,x] = (src[b,c,y,x] + sgn(c) * src[B+b, perm(c), y, w-1-x]) / 2
+ * (bit-identical to the reference's fp32 add + divide).  Heads the reference takes from image 0 alone (reg,
+ * tracking, ltrb, ltrb_amodal, rot, nuscenes_att, velocity, hp_offset) are not listed: read the first B images.
+ * src: NCHW maps of the 2B images, each image's [C,h,w] block dense, src_batch_stride floats between images;
+ * dst: dense [B,C,h,w].  flip_idx: HOST int32 [npairs][2] left/right joint pairs (dataset.flip_idx; NULL / 0 when
+ * no pose head is listed).  At most 8 heads per call. */
+enum { CT_FLIP_AVG = 0,            /* hm, wh, dep, dim */
+       CT_FLIP_NEG_EVEN = 1,       /* amodel_offset: mirrored x offsets change sign */
+       CT_FLIP_JOINTS = 2,         /* hm_hp [J]: partner joint's map (flip_lr) */
+       CT_FLIP_JOINT_OFFSETS = 3   /* hps [2J]: partner joint's (x, y), x negated (flip_lr_off) */ };
+typedef struct ct_flip_head {
+    const float *src; float *dst;
+    size_t src_batch_stride;
+    int C, mode;
+} ct_flip_head;
+int ct_flip_merge(const ct_flip_head *heads, int nheads, const int *flip_idx, int npairs, int B, int h, int w,
+                  void *stream);
+/* dst[r, x] = src[r, W-1-x] for `rows` rows of W floats (the mirrored input batch: rows = B*3*H) */
+int ct_flip_images(const float *src, float *dst, size_t rows, int W, void *stream);
+
 /* ---- host side of a frame (CPU, no device work) ----------------------------------------
  * Replaces generic_post_process (src/lib/utils/post_process.py:21-91), Detector.merge_outputs
  * (src/lib/detector.py:371-377) and Tracker.step with greedy_assignment
@@ -260,6 +284,7 @@ void *ct_graph_end(void *stream);               /* executable graph handle, NULL
 int ct_graph_launch(void *graph_exec, void *stream);
 void ct_graph_destroy(void *graph_exec);
 int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kind /*0 D2D, 1 H2D, 2 D2H*/, void *stream);
+int ct_memset_async(void *dst, int value, size_t bytes, void *stream);      /* DEVICE memory (zero_tracking) */
 int ct_stream_synchronize(void *stream);
 
 /* ---- image pre-processing (CPU, like the reference's: it runs in DataLoader worker processes) -----

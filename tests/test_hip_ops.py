@@ -601,3 +601,74 @@ def test_preprocess_device_known_answers(device):
     want2 = np.full((4, 6, 3), 12, np.uint8)
     want2[:, 0] = 5
     np.testing.assert_array_equal(_preprocess_device(img2, half, 6, 4, False, device), norm(want2))
+
+
+# ---------------------------------------------------------------------------- flip_test kernels
+def _flip_merge(device, heads, B, h, w, flip_idx=None):
+    """heads: list of (src [2B,C,h,w] device tensor (may be a channel slice), mode) -> list of merged [B,C,h,w]"""
+    import ctypes
+    from centertrack_amd import _lib
+    arr = (_lib.FlipHead * len(heads))()
+    outs = []
+    for i, (src, mode) in enumerate(heads):
+        dst = torch.full((B, src.shape[1], h, w), float('nan'), device=device)
+        arr[i].src, arr[i].dst, arr[i].src_batch_stride = src.data_ptr(), dst.data_ptr(), src.stride(0)
+        arr[i].C, arr[i].mode = src.shape[1], mode
+        outs.append(dst)
+    pairs = np.ascontiguousarray(flip_idx if flip_idx is not None else np.zeros((0, 2)), np.int32).reshape(-1, 2)
+    _lib.check(_lib.load().ct_flip_merge(arr, len(heads), pairs.ctypes.data if len(pairs) else None, len(pairs),
+                                         B, h, w, _lib.stream_ptr()), 'ct_flip_merge')
+    torch.cuda.synchronize()
+    return [o.cpu() for o in outs]
+
+
+@pytest.mark.parametrize('B,h,w', [(1, 6, 10), (3, 24, 80), (2, 7, 13)])
+def test_flip_merge_equals_the_reference_formulas_bitwise(device, B, h, w, golden_dir):
+    """ct_flip_merge == Detector._flip_output (detector.py:311-332) per stream, bit for bit: averaged heads,
+    sign-flipped amodel_offset, joint-swapped hm_hp / hps (flip_lr / flip_lr_off through the oracle's
+    mirror_joints, itself pinned to the reference by golden pose_flip.npz); w % 4 != 0 takes the scalar kernel;
+    a channel-slice source (batch stride > C*h*w) like the heads' combined tensor."""
+    from centertrack_amd import _lib
+    from oracle import detector as odet
+    comb = _rand(2 * B, 1 + 2 + 2 + 17 + 34 + 3, h, w, seed=B * 100 + w)
+    names = [('hm', 1, _lib.CT_FLIP_AVG), ('wh', 2, _lib.CT_FLIP_AVG), ('amodel_offset', 2, _lib.CT_FLIP_NEG_EVEN),
+             ('hm_hp', 17, _lib.CT_FLIP_JOINTS), ('hps', 34, _lib.CT_FLIP_JOINT_OFFSETS), ('dim', 3, _lib.CT_FLIP_AVG)]
+    cd = comb.to(device)
+    heads, want, c0 = [], [], 0
+    for name, c, mode in names:
+        v = comb[:, c0:c0 + c]
+        heads.append((cd[:, c0:c0 + c], mode))
+        per = []
+        for b in range(B):                                 # the reference merges one image with its mirror
+            a, f = v[b:b + 1], v[B + b:B + b + 1]
+            if name == 'amodel_offset':
+                ft = torch.flip(f, [3]).clone()
+                ft[:, 0::2] *= -1
+            elif name in ('hm_hp', 'hps'):
+                ft = odet.mirror_joints(f, odet.COCO_FLIP_IDX, name == 'hps')
+            else:
+                ft = torch.flip(f, [3])
+            per.append((a + ft) / 2)
+        want.append(torch.cat(per, 0))
+        c0 += c
+    got = _flip_merge(device, heads, B, h, w, odet.COCO_FLIP_IDX)
+    for (name, _, _), g_, w_ in zip(names, got, want):
+        assert torch.equal(g_, w_), name
+    if (B, h, w) == (1, 6, 10):                            # the reference's own flip_lr / flip_lr_off output
+        gold = np.load(os.path.join(golden_dir, 'pose_flip.npz'))
+        from centertrack_amd import scenarios as S
+        x = S.pose_flip_inputs()
+        for name, mode in (('hm_hp', _lib.CT_FLIP_JOINTS), ('hps', _lib.CT_FLIP_JOINT_OFFSETS)):
+            src = torch.cat((torch.zeros_like(x[name]), x[name]), 0).to(device)      # (0 + mirrored) / 2
+            out = _flip_merge(device, [(src, mode)], 1, 6, 10, odet.COCO_FLIP_IDX)[0]
+            np.testing.assert_array_equal(out.numpy() * 2, gold[name])
+
+
+@pytest.mark.parametrize('W', [160, 13])
+def test_flip_images_mirrors_rows(device, W):
+    from centertrack_amd import _lib
+    x = _rand(2, 3, 9, W, seed=W).to(device)
+    y = torch.full_like(x, float('nan'))
+    _lib.check(_lib.load().ct_flip_images(x.data_ptr(), y.data_ptr(), 2 * 3 * 9, W, _lib.stream_ptr()))
+    torch.cuda.synchronize()
+    assert torch.equal(y.cpu(), torch.flip(x.cpu(), [3]))

@@ -75,3 +75,97 @@ def test_single_process_is_identity():
     x = _rows(3, 5, 10)
     assert parallel.gather_detections(x, 3, 1, 0) is x
     assert parallel.max_over_ranks(3.5) == 3.5
+
+
+# --------------------------------------------------------------------------------------------------
+# the detector-side hook + bench.py's loop body (parallel.run_steps) over a 2-rank gloo group
+class _FakeDetector(object):
+    """Stands in for StreamDetector on a GPU-less host: ``step`` produces this rank's packed decode rows for frame
+    t (a deterministic function of (global stream id, t, frame content)) and, like StreamDetector.step, hands the
+    device rows to ``gather_fn`` before returning per-stream results."""
+
+    def __init__(self, stream_ids, K, F):
+        self.ids, self.K, self.F = stream_ids, K, F
+        self.gather_fn = None
+        self.t = 0
+
+    @staticmethod
+    def rows_of(sid, t, K, F, scale):
+        g = torch.Generator().manual_seed(1000 * sid + t)
+        return torch.rand((K, F), generator=g) * scale
+
+    def step(self, frame, metas):
+        scale = float(frame.mean())
+        rows = torch.stack([self.rows_of(s, self.t, self.K, self.F, scale) for s in self.ids]) if self.ids \
+            else torch.zeros((0, self.K, self.F))
+        if self.gather_fn is not None:
+            self.gather_fn(rows)
+        self.t += 1
+        return [[0] * (s + 1) for s in self.ids]           # "detections": s+1 per stream
+
+
+def _bench_loop_worker(rank, world, port, num_streams, K, F, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from centertrack_amd import parallel
+    parallel.init_from_env(backend='gloo')
+    ids = parallel.shard_streams(num_streams, rank, world)
+    det = _FakeDetector(ids, K, F)
+    gatherer = parallel.DetectionGatherer(num_streams, world, rank, K, F, torch.device('cpu'))
+    last = {}
+
+    def gather(rows):                                      # exactly bench.py's hook
+        last['rows'] = rows
+        last['all'] = gatherer(rows)
+    det.gather_fn = gather
+    frames = [torch.full((len(ids), 3, 4, 4), 1.0 + t) for t in range(3)]
+    bufs = (gatherer.send.data_ptr(), gatherer.recv.data_ptr(), gatherer.out.data_ptr())
+    nfr, ndet = parallel.run_steps(det, lambda t: frames[t % 3], [None] * len(ids), steps=2, frames_per_step=3)
+    ranks = gatherer.verify(last['rows'])
+    assert bufs == (gatherer.send.data_ptr(), gatherer.recv.data_ptr(), gatherer.out.data_ptr())   # no re-allocation
+    tampered = False
+    if world > 1:
+        gatherer.recv[0, 0, 0] += 1.0                      # a corrupted block must be caught
+        try:
+            gatherer.verify(last['rows'])
+        except RuntimeError:
+            tampered = True
+    parallel.barrier()
+    q.put((rank, nfr, ndet, ranks, gatherer.steps, last['all'].clone().numpy(), tampered))
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('num_streams', [4, 5])
+def test_bench_loop_body_gathers_every_frame_through_the_detector_hook(num_streams):
+    world, K, F = 2, 5, 14
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_loop_worker, args=(r, world, port, num_streams, K, F, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    t_last = 5                                             # 2 steps x 3 frames: the last frame is t = 5, content 1 + 5 % 3
+    want = torch.stack([_FakeDetector.rows_of(s, t_last, K, F, 1.0 + t_last % 3) for s in range(num_streams)]).numpy()
+    for rank, nfr, ndet, ranks, steps, allrows, tampered in got:
+        assert nfr == 6 and steps == 6 and ranks == world and tampered
+        mine = [s for s in range(num_streams) if s % world == rank]
+        assert ndet == 6 * sum(s + 1 for s in mine)
+        np.testing.assert_array_equal(allrows, want)       # global stream order, every rank
+
+
+def test_gatherer_single_rank_verifies_and_reuses_buffers():
+    from centertrack_amd import parallel
+    g = parallel.DetectionGatherer(3, 1, 0, 5, 10, torch.device('cpu'))
+    x = _rows(3, 5, 10)
+    out = g(x)
+    assert torch.equal(out, x) and g.verify(x) == 1
+    p = out.data_ptr()
+    assert g(x * 2).data_ptr() == p
+    with pytest.raises(RuntimeError):
+        g.verify(x)                                        # the block now holds 2x: checksum mismatch
+    with pytest.raises(ValueError):
+        g(x[:2])
