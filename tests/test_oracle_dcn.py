@@ -82,3 +82,44 @@ def test_dcn_module_matches_functional():
         om = F.conv2d(x, m.conv_offset_mask.weight, m.conv_offset_mask.bias, padding=1)
         y2 = odcn.dcn_v2_conv(x, om[:, :18], torch.sigmoid(om[:, 18:]), m.weight, m.bias)
     np.testing.assert_allclose(y.numpy(), y2.numpy(), atol=1e-6)
+
+
+# ---- third formulation: F.grid_sample (PyTorch-maintained bilinear sampler) + F.conv2d ---------------------------
+@pytest.mark.parametrize('scale,H,W,Ci,Co,seed', [(0.3, 9, 11, 5, 7, 0), (3.0, 12, 10, 4, 6, 1), (8.0, 7, 16, 3, 5, 2),
+                                                  (0.0, 6, 6, 2, 3, 3), (1.5, 2, 9, 3, 4, 4), (20.0, 16, 16, 8, 8, 5)])
+def test_gridsample_formulation_agrees_with_both_restatements(scale, H, W, Ci, Co, seed):
+    """random offsets from sub-pixel to far outside the image (scale 20 on a 16x16 map: most taps are out of range,
+    many straddle the (-1, 0) and (H-1, H) border strips): the gather-based torch oracle, the scalar-C im2col oracle
+    and the grid_sample formulation give the same numbers (fp64: 1e-9; the C oracle is fp32: 2e-5)."""
+    from oracle import dcn_v2_gridsample as gs
+    g = torch.Generator().manual_seed(100 + seed)
+    x = torch.randn((2, Ci, H, W), generator=g, dtype=torch.float64)
+    w = torch.randn((Co, Ci, 3, 3), generator=g, dtype=torch.float64)
+    b = torch.randn((Co,), generator=g, dtype=torch.float64)
+    off = torch.randn((2, 18, H, W), generator=g, dtype=torch.float64) * scale
+    mask = torch.rand((2, 9, H, W), generator=g, dtype=torch.float64)
+    if seed == 2:                                  # exact border hits: -1, 0, H-1, H and half-integers
+        off[:, :, 0, :] = torch.round(off[:, :, 0, :] * 2) / 2
+    y1 = odcn.dcn_v2_conv(x, off, mask, w, b)
+    y3 = gs.dcn_v2_conv(x, off, mask, w, b)
+    np.testing.assert_allclose(y3.numpy(), y1.numpy(), rtol=0, atol=1e-9)
+    yc = dcn_v2_c.dcn_v2_conv(x.float().numpy(), off.float().numpy(), mask.float().numpy(), w.float().numpy(),
+                              b.float().numpy())
+    np.testing.assert_allclose(yc, y3.numpy(), rtol=0, atol=2e-5 * max(1.0, float(y3.abs().max())))
+
+
+def test_gridsample_formulation_passes_the_kats_and_the_module_forward():
+    from oracle import dcn_v2_gridsample as gs
+    x = _rand(1, 4, 8, 10, seed=7).double()
+    w, b = _rand(5, 4, 3, 3, seed=8).double(), _rand(5, seed=9).double()
+    zero, one = torch.zeros(1, 18, 8, 10, dtype=torch.float64), torch.ones(1, 9, 8, 10, dtype=torch.float64)
+    np.testing.assert_allclose(gs.dcn_v2_conv(x, zero, one, w, b).numpy(), F.conv2d(x, w, b, padding=1).numpy(),
+                               atol=1e-12)                                            # KAT-1
+    np.testing.assert_allclose(gs.dcn_v2_conv(x, zero, 0 * one, w, b).numpy(),
+                               b.view(1, 5, 1, 1).expand(1, 5, 8, 10).numpy(), atol=1e-12)   # KAT-3
+    far = zero.clone()
+    far[:, 0::2] = -9.0                                                                 # every tap at y <= -1
+    np.testing.assert_allclose(gs.dcn_v2_conv(x, far, one, w, None).numpy(), 0.0, atol=1e-12)  # KAT-4
+    w_off, b_off = _rand(27, 4, 3, 3, seed=10).double() * 0.3, _rand(27, seed=11).double()
+    np.testing.assert_allclose(gs.dcn_forward(x, w, b, w_off, b_off).numpy(),
+                               odcn.dcn_forward(x, w, b, w_off, b_off).numpy(), atol=1e-9)

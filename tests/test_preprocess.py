@@ -122,3 +122,41 @@ def test_meta_of_every_testing_mode_equals_the_oracle(mode, h, w):
         np.testing.assert_array_equal(
             _run(img, got['trans_input'], got['inp_width'], got['inp_height']),
             oimage.pre_process_image(img, got['trans_input'], got['inp_width'], got['inp_height'], MEAN, STD))
+
+
+@pytest.mark.parametrize('h,w,inp_h,inp_w', [(360, 480, 128, 160), (375, 1242, 96, 320), (64, 64, 96, 96)])
+def test_warp_stays_within_the_fixed_point_bound_of_an_independent_bilinear_sampler(h, w, inp_h, inp_w):
+    """cv2 is absent, so the fixed-point warp is PARITY UNPINNED against OpenCV itself; this bounds it with an
+    independently maintained sampler instead: ``F.grid_sample`` (float64, zeros padding) evaluated at the exact
+    inverse-affine coordinates is the ideal bilinear warp, and OpenCV's published scheme differs from it only by
+    its quantisation -- coordinates rounded to 1/32 px (<= 1/64 px error per axis, i.e. <= 255/64 grey levels each on
+    a unit-step edge), 15-bit weights, round-to-nearest: |ours - ideal| <= 2*255/64 + 1 everywhere, and the mean
+    difference on a smooth image stays below half a grey level.  Catches a wrong inverse, a half-pixel shift, a
+    transposed matrix or a border slip -- none of which the bit-for-bit host == numpy == device checks can see
+    if all three shared the misreading."""
+    import torch
+    import torch.nn.functional as F
+    from centertrack_amd import image as IM
+    from oracle import image as oimage
+    rs = np.random.RandomState(h + w)
+    yy, xx = np.mgrid[0:h, 0:w]
+    smooth = 127 + 100 * np.sin(xx / 9.0 + rs.uniform(0, 3)) * np.cos(yy / 7.0)
+    img = np.clip(np.stack([smooth, smooth[::-1], smooth[:, ::-1]], -1) + rs.normal(0, 3, (h, w, 3)), 0, 255).astype(np.uint8)
+    meta = IM.make_meta(inp_h, inp_w, h, w)
+    for trans in (meta['trans_input'],
+                  IM.get_affine_transform(np.array([w / 3.0, h / 2.0], np.float32), max(h, w) * 0.6, 0, [inp_w, inp_h])):
+        got = oimage.warp_affine_u8(img, trans, inp_w, inp_h).astype(np.float64)
+        Minv = np.linalg.inv(np.vstack([np.asarray(trans, np.float64), [0, 0, 1]]))[:2]    # dst pixel -> src coordinate
+        dy, dx = np.mgrid[0:inp_h, 0:inp_w].astype(np.float64)
+        sx = Minv[0, 0] * dx + Minv[0, 1] * dy + Minv[0, 2]
+        sy = Minv[1, 0] * dx + Minv[1, 1] * dy + Minv[1, 2]
+        grid = torch.from_numpy(np.stack([2 * sx / (w - 1) - 1, 2 * sy / (h - 1) - 1], -1))[None]
+        src = torch.from_numpy(img.astype(np.float64)).permute(2, 0, 1)[None]
+        ideal = F.grid_sample(src, grid, mode='bilinear', padding_mode='zeros', align_corners=True)[0].permute(1, 2, 0).numpy()
+        err = np.abs(got - ideal)
+        # the local slope bounds the effect of the 1/64 px coordinate rounding: allow (slope_x + slope_y)/64 + 1
+        padded = np.pad(img.astype(np.float64), ((1, 1), (1, 1), (0, 0)))          # (the step into the zero border counts)
+        gx = np.abs(np.diff(padded, axis=1)).max()
+        gy = np.abs(np.diff(padded, axis=0)).max()
+        assert err.max() <= (gx + gy) / 64.0 + 1.0, err.max()
+        assert err.mean() < 0.5, err.mean()
