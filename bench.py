@@ -83,13 +83,16 @@ def kernel_pass(model, plan, reps=10):
     model._run_plan(plan)
     torch.cuda.synchronize()
     for kind in ('dcn', 'conv'):
-        launches = [l for l in plan['launches'] if l.fn == kind]
+        if kind == 'dcn':       # the grouped DCN launches (MAIN + FINISH) and the offset/mask convs of the un-fused layers
+            launches = [l for l in plan['launches'] if l.fn == 'dcn_group' or l.name.endswith('.offset')]
+        else:
+            launches = [l for l in plan['launches'] if l.fn == 'conv' and not l.name.endswith('.offset')]
 
         def run():
             st = _lib.stream_ptr()
             for l in launches:
-                if kind == 'dcn':
-                    lib.ct_dcn_v2(ctypes.byref(l.args), st)
+                if l.fn == 'dcn_group':
+                    lib.ct_dcn_v2_group(l.args[0], l.args[1], l.args[2], st)
                 else:
                     lib.ct_conv2d(ctypes.byref(l.args), st)
         side = torch.cuda.Stream()
@@ -111,36 +114,40 @@ def kernel_pass(model, plan, reps=10):
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         flops = flops_main = bytes_ = 0.0
+        nlayers = 0
         for l in launches:
-            d = l.args
-            if kind == 'dcn':
-                hw = d.N * d.H * d.W
-                flops_main += 2.0 * 9 * d.Cin * d.Cout * hw
-                flops += 2.0 * 9 * d.Cin * d.Cout * hw
-                bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout)
-                if d.fuse_offset:          # offset/mask conv computed in the same launch: its flops and weights
-                    flops += 2.0 * 9 * d.Cin * 27 * hw
-                    bytes_ += 4.0 * (9 * d.Cin * 27 + 27)
-                else:                      # the 27-channel offset/mask map is read from HBM
-                    bytes_ += 4.0 * 27 * hw
-            else:
+            if l.fn == 'dcn_group':
+                if not (l.args[2] & _lib.CT_DCN_MAIN):
+                    continue
+                for j in range(l.args[1]):
+                    d = l.args[0][j]
+                    nlayers += 1
+                    hw = d.N * d.H * d.W
+                    flops_main += 2.0 * 9 * d.Cin * d.Cout * hw
+                    flops += 2.0 * 9 * d.Cin * d.Cout * hw + 2.0 * 9 * d.Cin * 27 * hw      # main + offset/mask conv
+                    bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout + 9 * d.Cin * 27 + 27)
+            elif kind == 'conv':
+                d = l.args
                 pad = d.ks // 2
                 ho = (d.H + 2 * pad - d.ks) // d.stride + 1
                 wo = (d.W + 2 * pad - d.ks) // d.stride + 1
                 flops += 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)
+        if kind == 'dcn':
+            stats[kind] = dict(launches=len(launches), layers=nlayers, flops=flops, flops_main=flops_main, bytes=bytes_, ms=ms)
+            continue
         stats[kind] = dict(launches=len(launches), flops=flops, flops_main=flops_main, bytes=bytes_, ms=ms)
     return stats
 
 
 def pmc_traffic():
-    """HBM bytes per DCN launch from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, made by
+    """HBM bytes per DCN layer (all dcn_* kernels of a frame / 16) from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json, made by
     tools/collect_profiles.sh from FETCH_SIZE / WRITE_SIZE with the gfx950 corrections); None if absent."""
     p = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     try:
         with open(p) as f:
             j = json.load(f)
-        return j['dcn_mfma_kernel']['hbm_bytes_per_launch'], j.get('source', p)
+        return j['dcn_mfma_kernel']['hbm_bytes_per_layer'], j.get('source', p)
     except Exception:
         return None, None
 
@@ -317,16 +324,18 @@ def main():
             tf = d['flops'] / (d['ms'] * 1e-3) / 1e12
             tf_main = d['flops_main'] / (d['ms'] * 1e-3) / 1e12
             gbs = d['bytes'] / (d['ms'] * 1e-3) / 1e9
-            out['roofline'] = {'kernel': 'dcn_mfma_kernel (16 DCNv2 layers of one frame batch incl. their fused offset/mask '
-                                         'convs and split-K reduce / up-sample launches)',
+            nl = max(1, d['layers'])
+            out['roofline'] = {'kernel': 'dcn_mfma_kernel: the %d DCNv2 layers of one frame batch (grouped gather + contraction '
+                                         'launches, their offset/mask convs, the finishing reduce / BN / ReLU / IDAUp launches: '
+                                         '%d launches); unit of the per-launch figures = one layer' % (nl, d['launches']),
                                'bound': 'mfma', 'achieved': round(tf, 3), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                                'frac': round(tf / PEAK_FP32_TFLOPS, 4),
                                'frac_main': round(tf_main / PEAK_FP32_TFLOPS, 4),      # main contraction only
                                'traffic': None, 'traffic_source': None,
-                               'avg_launch_us': round(1000.0 * d['ms'] / d['launches'], 2),
+                               'avg_launch_us': round(1000.0 * d['ms'] / nl, 2),
                                'hbm': {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': round(gbs / PEAK_HBM_GBS, 4),
-                                       'algorithmic_bytes_per_launch': round(d['bytes'] / d['launches'])}}
+                                       'algorithmic_bytes_per_launch': round(d['bytes'] / nl)}}
             c = st['conv']
             ctf = c['flops'] / (c['ms'] * 1e-3) / 1e12
             out['roofline_conv'] = {'kernel': 'conv_mfma_kernel (%d dense conv launches)' % c['launches'], 'bound': 'mfma',

@@ -7,7 +7,7 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, 'libcentertrack_hip.so')
+LIB_PATH = os.environ.get('CENTERTRACK_LIB') or os.path.join(_PKG, 'libcentertrack_hip.so')   # (override: debugging builds)
 
 c_float_p = ctypes.c_void_p      # device pointers are opaque to the host
 NUM_HEADS = 11
@@ -22,6 +22,7 @@ HEAD_CH = {'reg': 2, 'wh': 2, 'tracking': 2, 'ltrb': 4, 'ltrb_amodal': 4, 'dep':
 
 CT_RELU = 1
 CT_OUT_NCHW = 2
+CT_DCN_MAIN, CT_DCN_FINISH = 1, 2
 
 
 class ConvDesc(ctypes.Structure):
@@ -97,7 +98,7 @@ class Track(ctypes.Structure):
 
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
-           'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_stem_forward',
+           'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_decode_pose_workspace_bytes',
            'ct_decode_pose', 'ct_render_pre_hm',
@@ -140,6 +141,9 @@ def load():
     lib.ct_dcn_v2.argtypes = [ctypes.POINTER(DcnDesc), p]
     lib.ct_dcn_v2_workspace_bytes.restype = sz
     lib.ct_dcn_v2_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
+    lib.ct_dcn_v2_group.argtypes = [ctypes.POINTER(DcnDesc), i, i, p]
+    lib.ct_dcn_v2_group_workspace_bytes.restype = sz
+    lib.ct_dcn_v2_group_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
     lib.ct_stem_forward.argtypes = [p, p, p, i, i, i, p, p, p, p, p, p, i, p]
     lib.ct_maxpool2x2.argtypes = [p, i, i, i, i, i, p, i, p]
     lib.ct_upsample_add.argtypes = [p, i, i, i, i, i, p, i, p, i, p, i, p]

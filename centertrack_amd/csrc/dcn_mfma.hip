@@ -32,69 +32,106 @@ struct DcnArgs {
     int tilesX, tilesY, coutBlocks;
     int NT;
     int nchunks, chunksPerSplit;     // chunks of 32 channels
+    int tiles;                       // N * tilesY * tilesX * coutBlocks: workgroups per split
     float *ws;
     int wsCout;
-    const float *w_off;              // fused offset/mask conv (FUSE kernels): packed 3x3 Cin -> 27 weights, bias
-    const float *b_off;
+    const float *w_off;              // fused offset/mask conv (FUSE kernels; per layer: nullptr = read `om`):
+    const float *b_off;              //   packed 3x3 Cin -> 27 weights, bias
     EpiArgs epi;
 };
 
-// fused offset/mask conv stage: the K-split conv tile of ksplit_core.h on the workgroup's own 2 x 16 pixels
-using OffCfg = KsCfg<3, 1, 2, 2, 4>;
+// Several independent layers in ONE launch (ct_dcn_v2_group): workgroup ids [first[i], first[i+1]) belong to layer
+// i.  At one stream most DCN layers of the network are 128 .. 512-workgroup problems on a 256-CU chip; the IDAUp
+// tree has up to three of them ready at the same time (dla.py:539-574: every `proj` only needs a finished level).
+constexpr int DCN_MAX_GROUP = 4;
+struct DcnGroup {
+    DcnArgs p[DCN_MAX_GROUP];
+    int first[DCN_MAX_GROUP + 1];
+    int n;
+};
 
-// BM = pixels per workgroup (64 = 4 rows x 16, 32 = 2 rows x 16); wave grid is (BM/32) pixel-row
-// pairs x (128/BM) cout groups; wave tile = 2 m-tiles x WN n-tiles => BN = 16 * WN * 128 / BM couts.
-// FUSE: the offset/mask conv of upstream's DCN.forward (conv_offset_mask + sigmoid of the mask channels) is
-// computed by the workgroup itself for its own pixels (ksplit_conv_tile, result kept in LDS) instead of being
-// read from a map another launch wrote: one launch and one HBM round trip of the 27-channel map less per layer.
-template <int BM, int WN, bool FUSE>
-__global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
+// BM = pixels per workgroup (64 = 4 rows x 16, 32 = 2 rows x 16); a K group of 4 waves is a (BM/32) x (128/BM)
+// grid of (pixel-row pairs) x (cout groups); wave tile = 2 m-tiles x WN n-tiles => BN = 16 * WN * 128 / BM couts.
+// KW = K groups per workgroup (256 * KW threads): group g contracts the (chunk, tap) steps g, g + KW, ... into its
+// own accumulators (own A double buffer) and the KW partial tiles are summed through LDS in group order at the
+// end -- at one stream a 512-workgroup layer leaves each CU two workgroups for the whole launch, so the launch
+// lasts as long as ONE workgroup's dependent chain (offset conv -> table -> 18 gather/MFMA steps); twice the waves
+// on half the steps each shorten that chain instead of adding workgroups nobody is waiting for.
+// FUSE: the offset/mask conv of upstream's DCN.forward (conv_offset_mask + sigmoid of the mask channels) may be
+// computed by the workgroup itself for its own pixels (per layer, when a.w_off is set: ksplit_conv_tile, result
+// kept in LDS) instead of being read from a map another launch wrote: one launch and one HBM round trip of the
+// 27-channel map less per layer.
+template <int BM, int WN, bool FUSE, int KW>
+__global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
 {
     constexpr int NKK = 2, WM = 2;
     constexpr int WGM = BM / 32, WGN = 4 / WGM;
     constexpr int ROWS = BM / 16;
     constexpr int SLAB = BM * 16;            // floats
     constexpr int BUF = NKK * SLAB;
+    constexpr int NTHR = 256 * KW;
     static_assert(!FUSE || BM == 32, "the fused offset conv works on 32-pixel tiles");
-    // dynamic LDS: [ om tile float[BM*32] (FUSE) ] | A tile double buffer | table offsets int4[BM*9] | table
-    // weights float4[BM*9]; the offset-conv stage's scratch aliases everything after the om tile
+    static_assert(KW == 1 || KW == 2, "1 or 2 K groups");
+    // dynamic LDS: [ om tile float[BM*32] (FUSE) ] | A tile double buffer x KW | table offsets int4[BM*9] | table
+    // weights float4[BM*9]; the offset-conv stage's scratch and the final cross-group sum alias everything after
+    // the om tile
     extern __shared__ __attribute__((aligned(16))) float dlds[];
     float *om_lds = dlds;
     float *lds_a = dlds + (FUSE ? BM * 32 : 0);
-    int *tab_off = reinterpret_cast<int *>(lds_a + 2 * BUF);
-    float *tab_w = lds_a + 2 * BUF + BM * 9 * 4;
+    int *tab_off = reinterpret_cast<int *>(lds_a + KW * 2 * BUF);
+    float *tab_w = lds_a + KW * 2 * BUF + BM * 9 * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: kept in an SGPR
-    const int wm = wave / WGN, wn = wave % WGN;
+    const int kg = (KW == 1) ? 0 : (wave >> 2);                  // K group
+    const int w4 = wave & 3;
+    const int tl = tid & 255;                                    // thread index inside the K group
+    const int wm = w4 / WGN, wn = w4 % WGN;
 
+    // ---- which layer of the group, which tile, which K split --------------------------------------
     int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DCN_MAX_GROUP; ++i)
+        if (i < g.n && bid >= g.first[i]) pi = i;
+#if defined(CT_DBG_STATIC0)
+    const DcnArgs &a = g.p[0];
+    pi = 0;
+#elif defined(CT_DBG_BRANCH)
+    const DcnArgs &a = (pi == 0) ? g.p[0] : ((pi == 1) ? g.p[1] : ((pi == 2) ? g.p[2] : g.p[3]));
+#else
+    const DcnArgs &a = g.p[pi];
+#endif
+    bid -= g.first[pi];
+    const int split = bid / a.tiles;
+    bid -= split * a.tiles;
     const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
     const int oy0 = ty * ROWS, ox0 = tx * 16;
-    const int split = blockIdx.y;
     const int c_begin = split * a.chunksPerSplit;
     const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
 
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
-    const float *omn = FUSE ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
+    const bool fuse = FUSE && a.w_off != nullptr;                // (uniform)
+    const float *omn = fuse ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
 
-    if (FUSE) {
+    if (fuse) {
         // ---- offset / mask conv of this tile (all input channels, whatever K range this split owns) ----
-        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a,
-                                        [&](int mt, int nt, f32x4 sum) {
-                                            const int co = nt * 16 + (lane & 15);
-                                            const float b = (co < 27) ? a.b_off[co] : 0.0f;
+        auto fin = [&](int mt, int nt, f32x4 sum) {
+            const int co = nt * 16 + (lane & 15);
+            const float b = (co < 27) ? a.b_off[co] : 0.0f;
 #pragma unroll
-                                            for (int e = 0; e < 4; ++e) {
-                                                float v = sum[e] + b;
-                                                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
-                                                om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
-                                            }
-                                        });
+            for (int e = 0; e < 4; ++e) {
+                float v = sum[e] + b;
+                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
+                om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
+            }
+        };
+        // (8 waves: the taps of every 64-channel chunk are split over the two wave groups as well)
+        ksplit_conv_tile<3, 1, 2, 2, 4, KW>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
         __syncthreads();
     }
     // ---- B fragment addressing (set up first so that the weights of step 0 are in flight while
@@ -116,35 +153,43 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
                 b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
         }
     };
+    // this K group's steps: linear (chunk, tap) index u = kg, kg + KW, ...  (chunk-outer / tap-inner order, so the
+    // groups work on the same chunk and share its footprint in L1); clamped past the end (never used)
+    const int nall = (c_end - c_begin) * 9;
+    const int nsteps = (nall - kg + KW - 1) / KW;                // steps of this group
+    const int nmax = (nall + KW - 1) / KW;                       // barrier rounds of the workgroup
+    auto step_ct = [&](int s, int &chunk, int &tap) {
+        const int u = min(max(min(s, nsteps - 1), 0) * KW + kg, max(nall - 1, 0));
+        const int c = u / 9;
+        chunk = min(c_begin + c, a.nchunks - 1);
+        tap = u - c * 9;
+    };
     f32x4 bq[2][NKK][WN];
-    load_b(bq[0], min(c_begin, a.nchunks - 1), 0);
+    {
+        int ch, tp;
+        step_ct(0, ch, tp);
+        load_b(bq[0], ch, tp);
+    }
 
     // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
     // (all offset/mask loads of a thread are issued before any of them is used: one round trip)
     {
-        constexpr int TI = (BM * 9 + 255) / 256;
+        constexpr int TI = (BM * 9 + NTHR - 1) / NTHR;
         float tdy[TI], tdx[TI], tmk[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int it = tid + 256 * i;
+            const int it = tid + NTHR * i;
             const int m = it / 9, k = it - m * 9;
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             const bool in = it < BM * 9 && oy < a.H && ox < a.W;
-            if (FUSE) {
-                const float *omp = om_lds + (in ? m * 32 : 0);
-                tdy[i] = omp[in ? 2 * k : 0];
-                tdx[i] = omp[in ? 2 * k + 1 : 0];
-                tmk[i] = omp[in ? 18 + k : 0];
-            } else {
-                const float *omp = omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
-                tdy[i] = omp[in ? 2 * k : 0];
-                tdx[i] = omp[in ? 2 * k + 1 : 0];
-                tmk[i] = omp[in ? 18 + k : 0];
-            }
+            const float *omp = fuse ? om_lds + (in ? m * 32 : 0) : omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
+            tdy[i] = omp[in ? 2 * k : 0];
+            tdx[i] = omp[in ? 2 * k + 1 : 0];
+            tmk[i] = omp[in ? 18 + k : 0];
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            const int it = tid + 256 * i;
+            const int it = tid + NTHR * i;
             if (it >= BM * 9) continue;
             const int m = it / 9, k = it - m * 9;
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);   // m < BM
@@ -171,12 +216,13 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
     }
     __syncthreads();
 
-    // ---- gather assignment: thread -> pixel m = tid>>2, channel quad q = tid&3, both slabs ----
-    // BM = 64: thread -> (pixel tid>>2, quad tid&3) for both slabs; BM = 32: (pixel tid>>3, slab (tid>>2)&1, quad tid&3)
+    // ---- gather assignment inside a K group: thread -> pixel, channel quad, slab(s) ----
+    // BM = 64: thread -> (pixel tl>>2, quad tl&3) for both slabs; BM = 32: (pixel tl>>3, slab (tl>>2)&1, quad tl&3)
     constexpr int GK = (BM == 64) ? NKK : 1;            // slabs gathered per thread
-    const int gm = (BM == 64) ? (tid >> 2) : (tid >> 3), gq = tid & 3;
-    const int gk0 = (BM == 64) ? 0 : ((tid >> 2) & 1);
+    const int gm = (BM == 64) ? (tl >> 2) : (tl >> 3), gq = tl & 3;
+    const int gk0 = (BM == 64) ? 0 : ((tl >> 2) & 1);
     const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);   // float offset inside a slab
+    float *lds_g = lds_a + kg * (2 * BUF);                       // this K group's A double buffer
     // two gather stages in flight (register slots 0/1): the corner loads of step s+2 are issued
     // before the MFMAs of step s and consumed (blend + LDS store) after the MFMAs of step s+1
     f32x4 cv[2][GK][4];
@@ -198,7 +244,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
         for (int kk = 0; kk < GK; ++kk) {
             const f32x4 v = gw[slot][0] * cv[slot][kk][0] + gw[slot][1] * cv[slot][kk][1] +
                             gw[slot][2] * cv[slot][kk][2] + gw[slot][3] * cv[slot][kk][3];
-            *reinterpret_cast<f32x4 *>(lds_a + buf * BUF + (gk0 + kk) * SLAB + lslot) = v;
+            *reinterpret_cast<f32x4 *>(lds_g + buf * BUF + (gk0 + kk) * SLAB + lslot) = v;
         }
     };
 
@@ -215,15 +261,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    const int nsteps = (c_end - c_begin) * 9;
-    if (nsteps > 0) {
-        // (chunk, tap) of a step index, clamped to the last valid step (extra fetches are never used)
-        auto step_ct = [&](int s, int &chunk, int &tap) {
-            s = min(s, nsteps - 1);
-            const int c = s / 9;
-            chunk = c_begin + c;
-            tap = s - c * 9;
-        };
+    if (nmax > 0) {
         int ch, tp;
         step_ct(0, ch, tp);
         gather_load(0, ch, tp);
@@ -243,29 +281,50 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
             // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
             // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
-            const float *buf = lds_a + P * BUF;
+            if (KW == 1 || s < nsteps) {                          // (uniform per wave: the other K group may own the last step)
+                const float *buf = lds_g + P * BUF;
 #pragma unroll
-            for (int kk = 0; kk < NKK; ++kk) {
-                f32x4 af[WM];
+                for (int kk = 0; kk < NKK; ++kk) {
+                    f32x4 af[WM];
 #pragma unroll
-                for (int mt = 0; mt < WM; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(buf + kk * SLAB + aoff[mt]);
+                    for (int mt = 0; mt < WM; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(buf + kk * SLAB + aoff[mt]);
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
+                    for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int mt = 0; mt < WM; ++mt)
+                        for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < WN; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bq[P][kk][nt][e],
-                                                                              acc[mt][nt], 0, 0, 0);
+                            for (int nt = 0; nt < WN; ++nt)
+                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bq[P][kk][nt][e],
+                                                                                  acc[mt][nt], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0x386);
-            if (s + 1 < nsteps) gather_store(P ^ 1, P ^ 1);      // step s+1's A tile (loaded one step ago)
+            if (s + 1 < nmax) gather_store(P ^ 1, P ^ 1);        // step s+1's A tile (loaded one step ago)
             __syncthreads();
         };
-        for (int s = 0; s < nsteps; s += 2) {
+        for (int s = 0; s < nmax; s += 2) {
             step(std::integral_constant<int, 0>{}, s);
-            if (s + 1 < nsteps) step(std::integral_constant<int, 1>{}, s + 1);
+            if (s + 1 < nmax) step(std::integral_constant<int, 1>{}, s + 1);
         }
+    }
+
+    if (KW > 1) {
+        // ---- sum of the K groups (group order, deterministic): group 1 parks its tiles in LDS ------------
+        float *red = lds_a;                                      // (the A buffers are dead: every wave passed the last barrier)
+        if (kg == 1) {
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    *reinterpret_cast<f32x4 *>(red + (((mt * WN + nt) * 4 + w4) * 64 + lane) * 4) = acc[mt][nt];
+        }
+        __syncthreads();
+        if (kg != 0) return;
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt)
+                acc[mt][nt] += *reinterpret_cast<const f32x4 *>(red + (((mt * WN + nt) * 4 + w4) * 64 + lane) * 4);
     }
 
     if (a.ws) {
@@ -297,10 +356,13 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnArgs a)
 
 struct DcnPlan {
     int fuse;
-    int BM, BN, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
+    int BM, BN, KW, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
+    int use_ws;                      // partial / raw tiles go through the workspace (split-K, or a fused IDAUp step of a group)
 };
 
-int make_plan(const ct_dcn_desc *d, DcnPlan *p)
+// `grouped`: the layer is one of several in a ct_dcn_v2_group launch (32-pixel x 64-cout tiles for all of them; a
+// fused IDAUp step always goes through the workspace so that ONE reduce launch finishes every layer of the group)
+int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
 {
     if (!d || !d->x || !d->w_packed || !d->y) CT_FAIL_ARG("ct_dcn_v2: null pointer");
     p->fuse = d->fuse_offset ? 1 : 0;
@@ -322,18 +384,27 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     p->tilesX = ct_cdiv(d->W, 16);
     p->BM = 64;
     p->BN = 64;
-    // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile
-    if (d->algo != 0 && d->algo != 64 && d->algo != 128 && d->algo != 3264 && d->algo != 32128)
+    p->KW = 1;
+    // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile; 23264 /
+    // 232128 = 32-pixel tile, 8 waves (two K groups)
+    int algo = d->algo;
+    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 23264 && algo != 232128)
         CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
-    if (d->algo == 3264) { p->BM = 32; p->BN = 64; }
-    else if (d->algo == 32128) { p->BM = 32; p->BN = 128; }
-    else if (d->algo == 128) p->BN = 128;
-    else if (d->algo == 64) p->BN = 64;
+    if (algo == 23264) { p->KW = 2; algo = 3264; }
+    else if (algo == 232128) { p->KW = 2; algo = 32128; }
+    if (grouped) {
+        if (algo != 0 && algo != 3264) CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel x 64-cout tiles (algo 3264 / 23264)");
+        algo = 3264;
+    }
+    if (algo == 3264) { p->BM = 32; p->BN = 64; }
+    else if (algo == 32128) { p->BM = 32; p->BN = 128; }
+    else if (algo == 128) p->BN = 128;
+    else if (algo == 64) p->BN = 64;
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 128 && d->Cout >= 128) p->BN = 128;
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 64) p->BN = 64;
     else if (d->Cout >= 128 && (long)d->N * p->tilesX * ct_cdiv(d->H, 4) * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
     if (p->fuse) {
-        if (d->algo == 64 || d->algo == 128) CT_FAIL_ARG("ct_dcn_v2: fuse_offset runs on the 32-pixel tiles (algo 3264 / 32128)");
+        if (algo == 64 || algo == 128) CT_FAIL_ARG("ct_dcn_v2: fuse_offset runs on the 32-pixel tiles (algo 3264 / 32128)");
         if (p->BM != 32) { p->BM = 32; p->BN = 64; }
     }
     p->tilesY = ct_cdiv(d->H, p->BM / 16);
@@ -343,9 +414,10 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     int splits = d->split_k;
     if (splits <= 0) {
         splits = 1;
-        if (d->workspace && tiles < 256) {
+        if (grouped) {
+            splits = p->nchunks / 2;              // 18 (chunk, tap) steps per workgroup: the layers of a group finish together
+        } else if (d->workspace && tiles < 256) {
             splits = (int)((512 + tiles - 1) / tiles);
-            if (splits > p->nchunks) splits = p->nchunks;
             if (splits > 16) splits = 16;
         }
     }
@@ -353,54 +425,76 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p)
     if (splits < 1) splits = 1;
     p->chunksPerSplit = ct_cdiv(p->nchunks, splits);
     p->splits = ct_cdiv(p->nchunks, p->chunksPerSplit);
+    p->use_ws = (p->splits > 1 || (grouped && d->up_w)) ? 1 : 0;
     return CT_OK;
 }
 
 size_t ws_bytes(const ct_dcn_desc *d, const DcnPlan &p)
 {
-    if (p.splits <= 1) return 0;
+    if (!p.use_ws) return 0;
     return (size_t)p.splits * d->N * d->H * d->W * (size_t)(p.NT * 16) * sizeof(float);
 }
 
-// defined in conv_mfma.hip's anonymous namespace -> re-declare a local copy of the reducer launch
-__global__ __launch_bounds__(256) void dcn_splitk_reduce_kernel(const float *ws, int splits, size_t Mtot, int wsCout,
-                                                                EpiArgs e)
-{
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    const int quads = wsCout >> 2;
-    if (idx >= Mtot * quads) return;
-    const size_t m = idx / quads;
-    const int c4 = (int)(idx - m * quads) << 2;
-    f32x4 s = *reinterpret_cast<const f32x4 *>(ws + m * wsCout + c4);
-    for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(ws + ((size_t)k * Mtot + m) * wsCout + c4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int co = c4 + i;
-        if (co >= e.Cout) break;
-        const float sc = e.scale ? e.scale[co] : 1.0f;
-        const float sh = e.shift ? e.shift[co] : 0.0f;
-        e.y[m * e.ldy + co] = ct_epilogue_value(e, s[i], co, sc, sh, 0.0f);
-    }
-}
-
-// Split-K reduction fused with the IDAUp step that consumes a `proj` DCN (dla.py:543-545): one thread per
-// output pixel and 4 channels reduces the partials of the (at most four) input pixels it needs, applies
-// BN + ReLU and accumulates the depth-wise transposed conv on top of the skip tensor -- the same operation
-// order as dcn_splitk_reduce_kernel followed by upsample_add_kernel (bit-identical result), in one launch
-// and without materialising the DCN output.
+// Split-K reduction (+ BN + ReLU), optionally fused with the IDAUp step that consumes a `proj` DCN (dla.py:543-545):
+// one thread per output pixel and 4 channels reduces the partials of the (at most four) input pixels it needs, applies
+// BN + ReLU and accumulates the depth-wise transposed conv on top of the skip tensor -- the same operation order as
+// the plain reduction followed by upsample_add_kernel (bit-identical result), in one launch and without
+// materialising the DCN output.  One launch finishes every layer of a group.
 struct UpArgs {
     const float *w;      // [2f*2f][C]
     const float *skip;
     float *y;
-    int f, lds, ldy;
+    int f, lds, ldy;     // f == 0: plain reduction into e.y
 };
-__global__ __launch_bounds__(256) void dcn_reduce_upsample_kernel(const float *ws, int splits, size_t Mtot, int wsCout,
-                                                                  EpiArgs e, int N, int H, int W, UpArgs u)
+struct RedArgs {
+    const float *ws;
+    int splits, wsCout;
+    size_t Mtot;
+    int N, H, W;
+    EpiArgs e;
+    UpArgs u;
+};
+struct RedGroup {
+    RedArgs p[DCN_MAX_GROUP];
+    int first[DCN_MAX_GROUP + 1];
+    int n;
+};
+
+__global__ __launch_bounds__(256) void dcn_reduce_kernel(RedGroup g)
 {
+    int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DCN_MAX_GROUP; ++i)
+        if (i < g.n && bid >= g.first[i]) pi = i;
+    const RedArgs &r = g.p[pi];
+    const EpiArgs &e = r.e;
+    const size_t idx = (size_t)(bid - g.first[pi]) * 256 + threadIdx.x;
+    const float *ws = r.ws;
+    const int splits = r.splits, wsCout = r.wsCout;
+    const size_t Mtot = r.Mtot;
+    if (r.u.f == 0) {
+        const int quads = wsCout >> 2;
+        if (idx >= Mtot * quads) return;
+        const size_t m = idx / quads;
+        const int c4 = (int)(idx - m * quads) << 2;
+        f32x4 s = *reinterpret_cast<const f32x4 *>(ws + m * wsCout + c4);
+        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(ws + ((size_t)k * Mtot + m) * wsCout + c4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int co = c4 + i;
+            if (co >= e.Cout) break;
+            const float sc = e.scale ? e.scale[co] : 1.0f;
+            const float sh = e.shift ? e.shift[co] : 0.0f;
+            e.y[m * e.ldy + co] = ct_epilogue_value(e, s[i], co, sc, sh, 0.0f);
+        }
+        return;
+    }
+    const UpArgs &u = r.u;
+    const int H = r.H, W = r.W;
     const int C = e.Cout, C4 = C >> 2, f = u.f, kw = 2 * f, p = f >> 1;
     const int Ho = H * f, Wo = W * f;
-    const size_t total = (size_t)N * Ho * Wo * C4;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t total = (size_t)r.N * Ho * Wo * C4;
     if (idx >= total) return;
     const int c = (int)(idx % C4) * 4;
     size_t q = idx / C4;
@@ -433,6 +527,132 @@ __global__ __launch_bounds__(256) void dcn_reduce_upsample_kernel(const float *w
     *reinterpret_cast<f32x4 *>(u.y + opix * u.ldy + c) = acc;
 }
 
+void fill_args(const ct_dcn_desc *d, const DcnPlan &p, DcnArgs *a)
+{
+    a->x = d->x; a->om = d->om; a->wp = d->w_packed;
+    a->N = d->N; a->H = d->H; a->W = d->W; a->Cin = d->Cin; a->ldx = d->ldx; a->ldom = d->ldom;
+    a->tilesX = p.tilesX; a->tilesY = p.tilesY; a->coutBlocks = p.coutBlocks; a->NT = p.NT;
+    a->nchunks = p.nchunks; a->chunksPerSplit = p.chunksPerSplit;
+    a->tiles = d->N * p.tilesX * p.tilesY * p.coutBlocks;
+    a->ws = p.use_ws ? d->workspace : nullptr;
+    a->wsCout = p.NT * 16;
+    a->epi.scale = d->scale; a->epi.shift = d->shift; a->epi.res = nullptr; a->epi.y = d->y;
+    a->epi.ldr = 0; a->epi.ldy = d->ldy; a->epi.Cout = d->Cout; a->epi.Ho = d->H; a->epi.Wo = d->W;
+    a->epi.flags = d->flags & CT_RELU; a->epi.sig_lo = a->epi.sig_hi = 0; a->epi.dep_lo = a->epi.dep_hi = 0;
+    a->epi.depth_scale = 1.0f;
+    a->w_off = p.fuse ? d->w_off_packed : nullptr;
+    a->b_off = p.fuse ? d->b_off : nullptr;
+}
+
+// dynamic LDS of one workgroup: A double buffers + the two tables (+ om tile and the offset-conv scratch when fused)
+template <int KW>
+size_t lds_bytes(int BM, bool fuse_any, bool single_chunk)
+{
+    using OffCfg = KsCfg<3, 1, 2, 2, 4, KW>;
+    size_t regionA = sizeof(float) * (size_t)(KW * 2 * 2 * BM * 16 + 2 * BM * 9 * 4);
+    if (!fuse_any) return regionA;
+    // (every fused layer has Cin == 64: the offset conv holds a single chunk and needs no double buffer)
+    const size_t scratch = single_chunk ? sizeof(float) * (size_t)OffCfg::LDS1_FLOATS : OffCfg::LDS_BYTES;
+    return sizeof(float) * (size_t)(BM * 32) + (scratch > regionA ? scratch : regionA);
+}
+
+int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void *stream)
+{
+    if (!descs || n < 1 || n > DCN_MAX_GROUP) CT_FAIL_ARG("ct_dcn_v2_group: 1..%d layers per launch", DCN_MAX_GROUP);
+    DcnPlan plans[DCN_MAX_GROUP];
+    DcnGroup g;
+    RedGroup rg;
+    g.n = n;
+    rg.n = 0;
+    long blocks = 0, rblocks = 0;
+    bool fuse_any = false, single_chunk = true;
+    const ct_dcn_desc *legacy_up = nullptr;
+    for (int i = 0; i < n; ++i) {
+        const ct_dcn_desc *d = descs + i;
+        DcnPlan &p = plans[i];
+        int rc = make_plan(d, &p, grouped);
+        if (rc != CT_OK) return rc;
+        if (p.BM != plans[0].BM || p.BN != plans[0].BN || p.KW != plans[0].KW)
+            CT_FAIL_ARG("ct_dcn_v2_group: layer %d resolves to another tile shape than layer 0", i);
+        const size_t need = ws_bytes(d, p);
+        if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
+            ct_set_error("ct_dcn_v2: layer %d: split_k=%d needs %zu workspace bytes, got %zu", i, p.splits, need, d->workspace_bytes);
+            return CT_ERR_WORKSPACE;
+        }
+        fill_args(d, p, &g.p[i]);
+        fuse_any = fuse_any || p.fuse;
+        if (p.fuse && d->Cin != 64) single_chunk = false;
+        g.first[i] = (int)blocks;
+        blocks += (long)g.p[i].tiles * p.splits;
+        if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
+        if (p.use_ws) {
+            RedArgs &r = rg.p[rg.n];
+            r.ws = d->workspace; r.splits = p.splits; r.wsCout = g.p[i].wsCout;
+            r.Mtot = (size_t)d->N * d->H * d->W;
+            r.N = d->N; r.H = d->H; r.W = d->W;
+            r.e = g.p[i].epi;
+            size_t nq;
+            if (d->up_w) {
+                r.u.w = d->up_w; r.u.skip = d->up_skip; r.u.y = d->up_y; r.u.f = d->up_f; r.u.lds = d->up_lds; r.u.ldy = d->up_ldy;
+                nq = r.Mtot * (size_t)(d->up_f * d->up_f) * (size_t)(d->Cout / 4);
+            } else {
+                r.u.w = nullptr; r.u.skip = nullptr; r.u.y = nullptr; r.u.f = 0; r.u.lds = r.u.ldy = 0;
+                nq = r.Mtot * (size_t)(r.wsCout / 4);
+            }
+            rg.first[rg.n] = (int)rblocks;
+            rblocks += (long)((nq + 255) / 256);
+            ++rg.n;
+        } else if (d->up_w) {
+            legacy_up = d;      // (single launch without split-K: the plain IDAUp step on the finished DCN output)
+        }
+    }
+    g.first[n] = (int)blocks;
+    for (int i = n + 1; i <= DCN_MAX_GROUP; ++i) g.first[i] = (int)blocks;
+    for (int i = n; i < DCN_MAX_GROUP; ++i) g.p[i] = g.p[0];
+    const DcnPlan &p0 = plans[0];
+    hipStream_t s = (hipStream_t)stream;
+    const dim3 grid((unsigned)blocks);
+    if (!(phases & CT_DCN_MAIN)) {
+        // finish only: the partials were written by an earlier CT_DCN_MAIN call on the same descriptors
+    } else if (p0.KW == 2) {
+        if (p0.BM != 32) CT_FAIL_ARG("ct_dcn_v2: the 8-wave shapes run on 32-pixel tiles");
+        const size_t lds = lds_bytes<2>(32, fuse_any, single_chunk);
+        if (fuse_any) {
+            if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true, 2>), grid, dim3(512), lds, s, g);
+            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true, 2>), grid, dim3(512), lds, s, g);
+        } else {
+            if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false, 2>), grid, dim3(512), lds, s, g);
+            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false, 2>), grid, dim3(512), lds, s, g);
+        }
+    } else if (fuse_any) {
+        const size_t lds = lds_bytes<1>(32, true, single_chunk);
+        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true, 1>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true, 1>), grid, dim3(256), lds, s, g);
+    } else if (p0.BM == 32) {
+        const size_t lds = lds_bytes<1>(32, false, false);
+        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false, 1>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false, 1>), grid, dim3(256), lds, s, g);
+    } else {
+        const size_t lds = lds_bytes<1>(64, false, false);
+        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4, false, 1>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2, false, 1>), grid, dim3(256), lds, s, g);
+    }
+    CT_CHECK_LAUNCH("ct_dcn_v2");
+    if (!(phases & CT_DCN_FINISH)) return CT_OK;
+    if (rg.n > 0) {
+        rg.first[rg.n] = (int)rblocks;
+        for (int i = rg.n + 1; i <= DCN_MAX_GROUP; ++i) rg.first[i] = (int)rblocks;
+        for (int i = rg.n; i < DCN_MAX_GROUP; ++i) rg.p[i] = rg.p[0];
+        hipLaunchKernelGGL(dcn_reduce_kernel, dim3((unsigned)rblocks), dim3(256), 0, s, rg);
+        CT_CHECK_LAUNCH("ct_dcn_v2(split-K reduce / IDAUp step)");
+    }
+    if (legacy_up)
+        return ct_upsample_add(legacy_up->y, legacy_up->N, legacy_up->H, legacy_up->W, legacy_up->Cout, legacy_up->ldy,
+                               legacy_up->up_w, legacy_up->up_f, legacy_up->up_skip, legacy_up->up_lds, legacy_up->up_y,
+                               legacy_up->up_ldy, stream);
+    return CT_OK;
+}
+
 }  // namespace
 
 extern "C" size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d)
@@ -442,71 +662,25 @@ extern "C" size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d)
     float dummy;
     if (!t.workspace) t.workspace = &dummy;
     if (!t.y) t.y = &dummy;
-    if (make_plan(&t, &p) != CT_OK) return 0;
+    if (make_plan(&t, &p, false) != CT_OK) return 0;
     return ws_bytes(&t, p);
 }
 
-extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
+extern "C" size_t ct_dcn_v2_group_workspace_bytes(const ct_dcn_desc *d)
 {
     DcnPlan p;
-    int rc = make_plan(d, &p);
-    if (rc != CT_OK) return rc;
-    const size_t need = ws_bytes(d, p);
-    if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
-        ct_set_error("ct_dcn_v2: split_k=%d needs %zu workspace bytes, got %zu", p.splits, need, d->workspace_bytes);
-        return CT_ERR_WORKSPACE;
-    }
-    DcnArgs a;
-    a.x = d->x; a.om = d->om; a.wp = d->w_packed;
-    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx; a.ldom = d->ldom;
-    a.tilesX = p.tilesX; a.tilesY = p.tilesY; a.coutBlocks = p.coutBlocks; a.NT = p.NT;
-    a.nchunks = p.nchunks; a.chunksPerSplit = p.chunksPerSplit;
-    a.ws = p.splits > 1 ? d->workspace : nullptr;
-    a.wsCout = p.NT * 16;
-    a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = nullptr; a.epi.y = d->y;
-    a.epi.ldr = 0; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;
-    a.epi.flags = d->flags & CT_RELU; a.epi.sig_lo = a.epi.sig_hi = 0; a.epi.dep_lo = a.epi.dep_hi = 0;
-    a.epi.depth_scale = 1.0f;
-    const long blocks = (long)d->N * p.tilesX * p.tilesY * p.coutBlocks;
-    if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
-    dim3 grid((unsigned)blocks, (unsigned)p.splits);
-    hipStream_t s = (hipStream_t)stream;
-    a.w_off = d->w_off_packed; a.b_off = d->b_off;
-    // dynamic LDS: A double buffer + the two tables (+ om tile and the offset-conv scratch when fused)
-    auto lds_bytes = [&](int BM) {
-        size_t regionA = sizeof(float) * (size_t)(2 * 2 * BM * 16 + 2 * BM * 9 * 4);
-        if (!p.fuse) return regionA;
-        const size_t scratch = (d->Cin == 64) ? sizeof(float) * (size_t)OffCfg::LDS1_FLOATS : OffCfg::LDS_BYTES;
-        return sizeof(float) * (size_t)(BM * 32) + (scratch > regionA ? scratch : regionA);
-    };
-    if (p.fuse) {
-        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true>), grid, dim3(256), lds_bytes(32), s, a);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), grid, dim3(256), lds_bytes(32), s, a);
-    } else if (p.BM == 32) {
-        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false>), grid, dim3(256), lds_bytes(32), s, a);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false>), grid, dim3(256), lds_bytes(32), s, a);
-    } else {
-        if (p.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4, false>), grid, dim3(256), lds_bytes(64), s, a);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2, false>), grid, dim3(256), lds_bytes(64), s, a);
-    }
-    CT_CHECK_LAUNCH("ct_dcn_v2");
-    if (p.splits > 1 && d->up_w) {
-        const size_t Mtot = (size_t)d->N * d->H * d->W;
-        UpArgs u;
-        u.w = d->up_w; u.skip = d->up_skip; u.y = d->up_y; u.f = d->up_f; u.lds = d->up_lds; u.ldy = d->up_ldy;
-        const size_t nq = Mtot * (size_t)(d->up_f * d->up_f) * (size_t)(d->Cout / 4);
-        hipLaunchKernelGGL(dcn_reduce_upsample_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
-                           d->workspace, p.splits, Mtot, a.wsCout, a.epi, d->N, d->H, d->W, u);
-        CT_CHECK_LAUNCH("ct_dcn_v2(split-K reduce + upsample)");
-    } else if (p.splits > 1) {
-        const size_t Mtot = (size_t)d->N * d->H * d->W;
-        const size_t nq = Mtot * (size_t)(a.wsCout / 4);
-        hipLaunchKernelGGL(dcn_splitk_reduce_kernel, dim3((unsigned)((nq + 255) / 256)), dim3(256), 0, s,
-                           d->workspace, p.splits, Mtot, a.wsCout, a.epi);
-        CT_CHECK_LAUNCH("ct_dcn_v2(split-K reduce)");
-    }
-    if (d->up_w && p.splits <= 1)      // no partials to fuse with: the plain IDAUp step on the DCN output
-        return ct_upsample_add(d->y, d->N, d->H, d->W, d->Cout, d->ldy, d->up_w, d->up_f, d->up_skip, d->up_lds, d->up_y,
-                               d->up_ldy, stream);
-    return CT_OK;
+    ct_dcn_desc t = *d;
+    float dummy;
+    if (!t.workspace) t.workspace = &dummy;
+    if (!t.y) t.y = &dummy;
+    if (make_plan(&t, &p, true) != CT_OK) return 0;
+    return ws_bytes(&t, p);
+}
+
+extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream) { return launch_group(d, 1, false, CT_DCN_MAIN | CT_DCN_FINISH, stream); }
+
+extern "C" int ct_dcn_v2_group(const ct_dcn_desc *descs, int n, int phases, void *stream)
+{
+    if (!(phases & (CT_DCN_MAIN | CT_DCN_FINISH))) CT_FAIL_ARG("ct_dcn_v2_group: phases must name CT_DCN_MAIN and / or CT_DCN_FINISH");
+    return launch_group(descs, n, true, phases, stream);
 }

@@ -6,7 +6,7 @@ head_conv, opt)`` / ``load_model`` (src/lib/model/model.py:24-90) and
 dla.py:593-640), with the reference's state-dict keys, so its ``.pth`` files load
 unchanged.  Internally nothing of torch.nn runs: weights are BN-folded and packed
 once into MFMA fragment order, activations are NHWC views, concatenations are
-channel slices of shared buffers, and each frame is ~140 launches of
+channel slices of shared buffers, and each frame is ~70 launches of
 libcentertrack_hip kernels on the current stream (capturable in one HIP graph).
 """
 import ctypes
@@ -15,13 +15,12 @@ from collections import OrderedDict
 
 import torch
 
-from . import _lib, autotune, ops, schedule
+from . import _lib, autotune, ops
 from .ops import View
 from .weights import CHANNELS, LEVELS, dla34_param_shapes
 
 BN_EPS = 1e-5
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
-FUSE_UP = os.environ.get('CENTERTRACK_FUSE_UP', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 
 
@@ -33,15 +32,21 @@ def _fold_bn(sd, p):
 
 
 class _Launch(object):
-    """One pre-built C-ABI call + what it reads / writes (for the multi-stream schedule)."""
-    __slots__ = ('fn', 'args', 'name', 'keep', 'reads', 'writes', 'us', 'stream', 'waits', 'record', 'ws_need')
+    """One pre-built C-ABI call of the frame (`keep` pins the tensors its raw pointers refer to)."""
+    __slots__ = ('fn', 'args', 'name', 'keep', 'us', 'ws_need')
 
     def __init__(self, name, fn, args, keep=(), reads=(), writes=(), us=5.0, ws_need=0):
         self.name, self.fn, self.args, self.keep = name, fn, args, keep
-        self.reads = [schedule.region(r) for r in reads if r is not None]
-        self.writes = [schedule.region(w) for w in writes if w is not None]
         self.us, self.ws_need = us, ws_need
-        self.stream, self.waits, self.record = 0, [], False
+
+
+class _DcnLayer(object):
+    """One DeformConv node of the IDAUp tree (dla.py:506-518) waiting to be scheduled: input view, output view, the
+    fused IDAUp step ``up`` = (weight, f, skip view, output view) of a `proj` node."""
+    __slots__ = ('name', 'x', 'cout', 'out', 'up', 'main', 'finish', 'desc', 'fused', 'splits', 'use_ws')
+
+    def __init__(self, name, x, cout, out, up):
+        self.name, self.x, self.cout, self.out, self.up = name, x, cout, out, up
 
 
 class DLASegHIP(torch.nn.Module):
@@ -257,31 +262,13 @@ class DLASegHIP(torch.nn.Module):
             feats.append(out)
             x = out
 
+        dcn_layers = []
+
         def deform(name, x, cout, out, up=None):
             """DeformConv.forward (dla.py:515-518): offset/mask conv -> DCNv2 -> BN -> ReLU; with ``up`` =
-            (weight, f, skip view, output view) the IDAUp step `up(.) + skip` (dla.py:543-545) that consumes a
-            `proj` node runs in the same C-ABI call (fused into the split-K reduction when there is one)."""
-            wr = (out,) if up is None else (out, up[3])
-            rd_up = () if up is None else (up[2],)
-            pk = P[name]
-            om = ops.new_view(N, x.H, x.W, 32, dev)       # one per DCN: independent branches may overlap
-            d = ops.make_conv_desc(x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
-            us_off = autotune.tune_conv(d, dev)[2] if tune else 10.0
-            dd = ops.make_dcn_desc(x, om, pk['w'], cout, pk['scale'], pk['shift'], True, out, up=up)
-            us = autotune.tune_dcn(dd, dev)[2] if tune else 20.0
-            if tune and x.C % 64 == 0 and FUSE_OFFSET:
-                # one launch computing the offset/mask conv itself vs offset conv + DCN (+ a kernel boundary)
-                df = ops.make_dcn_desc(x, None, pk['w'], cout, pk['scale'], pk['shift'], True, out,
-                                       w_off=pk['w_off'], b_off=pk['b_off'], up=up)
-                us_f = autotune.tune_dcn(df, dev)[2]
-                if 0.0 < us_f < us_off + us + 1.0:
-                    L.append(_Launch(name + '.dcn', 'dcn', df, (x, None, out, pk, up), reads=(x,) + rd_up, writes=wr,
-                                     us=us_f, ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(df))))
-                    return out
-            L.append(_Launch(name + '.offset', 'conv', d, (x, om, pk), reads=(x,), writes=(om,), us=us_off,
-                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-            L.append(_Launch(name + '.dcn', 'dcn', dd, (x, om, out, pk, up), reads=(x, om) + rd_up, writes=wr, us=us,
-                             ws_need=lib.ct_dcn_v2_workspace_bytes(ctypes.byref(dd))))
+            (weight, f, skip view, output view) also the IDAUp step `up(.) + skip` (dla.py:543-545) that consumes a
+            `proj` node.  Only recorded here: the 16 nodes are scheduled together below (_schedule_dcn)."""
+            dcn_layers.append(_DcnLayer(name, x, cout, out, up))
             return out
 
         def ida(p, layers, startp, endp, o, up_f):
@@ -291,13 +278,8 @@ class DLASegHIP(torch.nn.Module):
                 f = up_f[k]
                 xi = layers[i]
                 up = alloc(xi.H * f, xi.W * f, o)
-                if FUSE_UP:
-                    deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o),
-                           up=(P['%s.up_%d' % (p, k)], f, layers[i - 1], up))
-                else:
-                    pr = deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o))
-                    L.append(_Launch('%s.up_%d' % (p, k), 'up', (pr, P['%s.up_%d' % (p, k)], f, layers[i - 1], up),
-                                     reads=(pr, layers[i - 1]), writes=(up,)))
+                deform('%s.proj_%d' % (p, k), xi, o, alloc(xi.H, xi.W, o),
+                       up=(P['%s.up_%d' % (p, k)], f, layers[i - 1], up))
                 layers[i] = deform('%s.node_%d' % (p, k), up, o, alloc(up.H, up.W, o))
 
         layers = list(feats)                                   # DLAUp.forward, dla.py:568-574
@@ -309,6 +291,11 @@ class DLASegHIP(torch.nn.Module):
         ida('ida_up', y, 0, 3, 64, [1, 2, 4])
         feat = y[-1]
         plan['feat'] = feat
+        produced0 = {id(f_.buf): 0 for f_ in feats}
+        knobs, dcn_launches = self._tune_dcn_schedule(dcn_layers, produced0, N, H, W, dev, tune)
+        plan['dcn_knobs'] = knobs
+        plan['dcn_layers'] = {ly.name: (ly.up[3] if ly.up is not None else ly.out) for ly in dcn_layers}   # name -> result view
+        L.extend(dcn_launches)
 
         nh = len(self.heads)
         hc = self.head_conv
@@ -352,52 +339,33 @@ class DLASegHIP(torch.nn.Module):
                                  us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
                 outputs[hname] = o
         plan['outputs'] = outputs
-        # ---- streams: independent branches (IDAUp projections, residual projections, pools) overlap ----
-        S = int(os.environ.get('CENTERTRACK_STREAMS', '1'))   # > 1: experimental
-        if S > 1:
-            plan['makespan_us'] = schedule.schedule(L, S)
-        else:
-            schedule.serialize(L)
-        nstreams = 1 + max(l.stream for l in L)
-        plan['side_streams'] = [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
-        plan['ws'] = []
-        for sidx in range(nstreams):                      # split-K partials: one workspace per stream
-            need = max([l.ws_need for l in L if l.stream == sidx] + [16])
-            ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
-            plan['ws'].append(ws)
-            for l in L:
-                if l.stream == sidx and l.fn in ('conv', 'dcn'):
-                    l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
-        plan['ws_need'] = sum(w.numel() * 4 for w in plan['ws'])
+        # split-K partials of the dense convs: one workspace shared by all of them (the launches of a frame are
+        # sequential); every DCN layer owns its workspace (the layers of a group run concurrently)
+        need = max([l.ws_need for l in L if l.fn == 'conv'] + [16])
+        ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
+        plan['ws'] = [ws]
+        for l in L:
+            if l.fn == 'conv':
+                l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        plan['ws_need'] = ws.numel() * 4
         return plan
 
     def _run_plan(self, plan, inputs=None):
-        """Enqueue every launch of the plan.  ``inputs`` = (x, pre_img, pre_hm) tensors to read instead
-        of the plan's own static input buffers (a detector ping-pongs two frame buffers so that the
+        """Enqueue every launch of the plan on the current stream.  ``inputs`` = (x, pre_img, pre_hm) tensors to read
+        instead of the plan's own static input buffers (a detector ping-pongs two frame buffers so that the
         previous frame never has to be copied)."""
         P = self._prepared
         lib = _lib.load()
-        main = torch.cuda.current_stream()
-        streams = [main] + plan['side_streams']
-        for sd_ in plan['side_streams']:                   # fork (also what makes the side streams part of a capture)
-            sd_.wait_stream(main)
-        sptr = [ctypes.c_void_p(s_.cuda_stream) for s_ in streams]
-        events = {}
-        for idx, l in enumerate(plan['launches']):
-            for i in l.waits:
-                streams[l.stream].wait_event(events[i])
-            st = sptr[l.stream]
+        st = _lib.stream_ptr()
+        for l in plan['launches']:
             if l.fn == 'conv':
                 rc = lib.ct_conv2d(ctypes.byref(l.args), st)
-            elif l.fn == 'dcn':
-                rc = lib.ct_dcn_v2(ctypes.byref(l.args), st)
+            elif l.fn == 'dcn_group':
+                arr, n, phases = l.args
+                rc = lib.ct_dcn_v2_group(arr, n, phases, st)
             elif l.fn == 'pool':
                 x, y = l.args
                 rc = lib.ct_maxpool2x2(x.ptr, x.N, x.H, x.W, x.C, x.ld, y.ptr, y.ld, st)
-            elif l.fn == 'up':
-                x, w, f, skip, y = l.args
-                rc = lib.ct_upsample_add(x.ptr, x.N, x.H, x.W, x.C, x.ld, w.data_ptr(), f, skip.ptr, skip.ld,
-                                         y.ptr, y.ld, st)
             elif l.fn == 'stem':
                 x, img, hm, y = l.args
                 if inputs is not None:
@@ -411,12 +379,156 @@ class DLASegHIP(torch.nn.Module):
                 raise AssertionError(l.fn)
             if rc != 0:
                 _lib.check(rc, l.name)
-            if l.record:
-                ev = torch.cuda.Event()
-                ev.record(streams[l.stream])
-                events[idx] = ev
-        for sd_ in plan['side_streams']:                   # join
-            main.wait_stream(sd_)
+
+    # --- the 16 DeformConv nodes of DLAUp / IDAUp as grouped launches -------------------------------------
+    def _schedule_dcn(self, layers, produced0, N, dev, knobs):
+        """Launch list of the 16 DCN nodes for one choice of ``knobs``.
+
+        Dataflow (dla.py:539-574): a `proj` node only reads a finished level; the IDAUp step behind it needs the
+        previous node's output as its skip tensor; a `node` reads that step's result.  Every layer is split in two
+        launches' worth of work -- MAIN (gather + contraction, results or split-K partials) and FINISH (reduction +
+        BN + ReLU + IDAUp step) -- and placed in the earliest slot t (M_t at time 2t, F_t at time 2t+1) whose
+        inputs exist: main(L) = first t with 2t > time(x); finish(L) = first t' >= main(L) with 2t'+1 > time(skip).
+        The layers sharing a slot go out as ONE ct_dcn_v2_group launch each for M_t and F_t: 8 + 7 launches for the
+        16 nodes instead of 16 + (offset convs) + 8 reductions, and at one stream 768 .. 1536 workgroups per launch
+        instead of 128 .. 512.  knobs = (fuse_max_cin, chunks_per_split, kw_below): the offset/mask conv is computed
+        inside the DCN launch for Cin <= fuse_max_cin (else by its own conv launch just before the slot), every
+        workgroup contracts chunks_per_split 32-channel chunks, and slots with fewer than kw_below workgroups run
+        the 8-wave shape (two K groups per workgroup)."""
+        lib = _lib.load()
+        P = self._prepared
+        fuse_max_cin, cps, kw_below = knobs
+        time_of = dict(produced0)                    # buffer id -> time after which it is readable
+
+        def t_of(view):
+            return time_of.get(id(view.buf), 0)
+
+        slots = {}
+        convs = {}
+        for ly in layers:                            # (reference order: producers come first)
+            pk = P[ly.name]
+            ly.fused = ly.x.C % 64 == 0 and ly.x.C <= fuse_max_cin and FUSE_OFFSET
+            nchunks = ly.x.C // 32
+            ly.splits = max(1, nchunks // cps)
+            ly.main = t_of(ly.x) // 2 + 1
+            om = None
+            if not ly.fused:
+                om = ops.new_view(N, ly.x.H, ly.x.W, 32, dev)
+                d = ops.make_conv_desc(ly.x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
+                if autotune.enabled():
+                    autotune.tune_conv(d, dev)
+                convs.setdefault(ly.main, []).append(
+                    _Launch(ly.name + '.offset', 'conv', d, (ly.x, om, pk),
+                            ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            dd = ops.make_dcn_desc(ly.x, om, pk['w'], ly.cout, pk['scale'], pk['shift'], True, ly.out, up=ly.up,
+                                   split_k=ly.splits, algo=3264,
+                                   w_off=pk['w_off'] if ly.fused else None, b_off=pk['b_off'] if ly.fused else None)
+            need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(dd))
+            ly.use_ws = need > 0
+            keep = [ly.x, om, ly.out, pk, ly.up]
+            if need:
+                ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
+                dd.workspace, dd.workspace_bytes = ws.data_ptr(), need
+                keep.append(ws)
+            ly.desc = (dd, keep)
+            if ly.use_ws:
+                ly.finish = max(ly.main, (t_of(ly.up[2]) + 1) // 2) if ly.up is not None else ly.main
+                done = 2 * ly.finish + 1
+            else:
+                ly.finish = None
+                done = 2 * ly.main
+            time_of[id((ly.up[3] if ly.up is not None else ly.out).buf)] = done
+            slots.setdefault(ly.main, {'main': [], 'finish': []})['main'].append(ly)
+            if ly.finish is not None:
+                slots.setdefault(ly.finish, {'main': [], 'finish': []})['finish'].append(ly)
+        out = []
+
+        def group(lys, phases, tag, kw):
+            for i in range(0, len(lys), 4):
+                part = lys[i:i + 4]
+                arr = (_lib.DcnDesc * len(part))()
+                keep = []
+                for j, ly in enumerate(part):
+                    ctypes.memmove(ctypes.byref(arr[j]), ctypes.byref(ly.desc[0]), ctypes.sizeof(_lib.DcnDesc))
+                    arr[j].algo = 23264 if kw == 2 else 3264
+                    keep.append(ly.desc[1])
+                name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
+                out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
+
+        for t in sorted(slots):
+            out.extend(convs.get(t, []))
+            lys = slots[t]['main']
+            if lys:
+                wgs = sum(N * ((ly.x.H + 1) // 2) * ((ly.x.W + 15) // 16) * ((ly.cout + 63) // 64) * ly.splits for ly in lys)
+                group(lys, _lib.CT_DCN_MAIN, 'dcn', 2 if wgs < kw_below else 1)
+            if slots[t]['finish']:
+                group(slots[t]['finish'], _lib.CT_DCN_FINISH, 'dcn.finish', 1)
+        return out
+
+    def _time_launches(self, launches, reps=10):
+        """device time (us) of a launch list, by graph replay on a side stream"""
+        plan = {'launches': launches}
+        need = max([l.ws_need for l in launches if l.fn == 'conv'] + [16])
+        dev = next(self.buffers()).device
+        ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
+        for l in launches:
+            if l.fn == 'conv':
+                l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            self._run_plan(plan)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for _ in range(reps):
+                self._run_plan(plan)
+        g.replay()
+        torch.cuda.synchronize()
+        best = None
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(2):
+            e0.record()
+            g.replay()
+            e1.record()
+            torch.cuda.synchronize()
+            t = e0.elapsed_time(e1) * 1e3 / reps
+            best = t if best is None else min(best, t)
+        del g
+        return best
+
+    def _tune_dcn_schedule(self, layers, produced0, N, H, W, dev, tune):
+        """Pick the knobs of _schedule_dcn for this (batch, size) by timing the whole 16-node sequence (a HIP graph of
+        exactly its launches) for every candidate; the choice is cached like the per-layer ones (pinned table /
+        CENTERTRACK_TUNE_CACHE) because it fixes the fp32 summation order.  CENTERTRACK_DCN_KNOBS="a,b,c" forces one."""
+        env = os.environ.get('CENTERTRACK_DCN_KNOBS', '')
+        if env:
+            knobs = tuple(int(v) for v in env.split(','))
+            return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
+        default = (128, 2, 768)
+        if not tune:
+            return default, self._schedule_dcn(layers, produced0, N, dev, default)
+        key = 'dcnplan:%d,%d,%d' % (N, H, W)
+        autotune._load_file()
+        if key in autotune._CACHE:
+            knobs = tuple(int(v) for v in autotune._CACHE[key][:3])
+            return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
+        best = None
+        for fuse_max in (64, 128, 256):
+            for cps in (2, 4):
+                for kw_below in (0, 768, 1 << 30):
+                    knobs = (fuse_max, cps, kw_below)
+                    launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
+                    us = self._time_launches(launches)
+                    if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
+                        print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us' % (N, H, W, knobs, len(launches), us))
+                    if best is None or us < best[0]:
+                        best = (us, knobs)
+                    del launches
+        autotune._CACHE[key] = (best[1][0], best[1][1], best[1][2], round(best[0], 1))
+        autotune._save_file()
+        return best[1], self._schedule_dcn(layers, produced0, N, dev, best[1])
 
     def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False):
         key = (N, H, W, with_img, with_hm, fuse_sigmoid)

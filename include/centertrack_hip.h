@@ -109,7 +109,11 @@ typedef struct ct_dcn_desc {
     float *workspace; size_t workspace_bytes;
     int split_k;
     int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
-                                                   workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts */
+                                                   workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts;
+                                                   23264 / 232128 = the same with 8 waves per workgroup (two wave
+                                                   groups split the (chunk, tap) steps and are summed through LDS:
+                                                   half the dependent chain of a workgroup, for launches that leave
+                                                   a CU only one or two workgroups) */
     int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
                                                    unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile */
@@ -121,6 +125,21 @@ typedef struct ct_dcn_desc {
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
+/* Up to 4 INDEPENDENT DeformConv layers in one launch (+ one reduce launch that finishes all of them): the IDAUp /
+ * DLAUp tree (dla.py:539-574) has several layers ready at the same time -- every `proj_i` only needs a finished
+ * level, `node_i` of different IDAUp stages do not depend on each other -- and at one stream each of them alone
+ * cannot fill 256 CUs.  All layers run on 32-pixel x 64-cout tiles (algo 0 / 3264, or 23264 for all of them);
+ * split_k == 0 gives every workgroup two 32-channel chunks (18 (chunk, tap) steps), so the layers of a group finish
+ * together whatever their Cin; fuse_offset is per layer; a fused IDAUp step (up_w) always goes through the
+ * workspace (y is then not written).  Each layer needs its OWN workspace of ct_dcn_v2_group_workspace_bytes(d)
+ * bytes (the layers run concurrently).  `phases`: CT_DCN_MAIN | CT_DCN_FINISH runs both launches back to back;
+ * the two may also be issued separately, with different groupings -- the IDAUp step of a `proj` needs its skip
+ * tensor (the previous node's output) only in the finishing launch, so the contraction can start before that
+ * tensor exists.  Results are bit-identical to ct_dcn_v2 with the same split_k. */
+enum { CT_DCN_MAIN = 1,      /* the gather + contraction launch (results or split-K partials) */
+       CT_DCN_FINISH = 2     /* the launch that finishes the layers holding partials: reduction + BN + ReLU (+ IDAUp step) */ };
+int ct_dcn_v2_group(const ct_dcn_desc *descs, int n, int phases, void *stream);
+size_t ct_dcn_v2_group_workspace_bytes(const ct_dcn_desc *d);
 
 /* ---- the three 7x7 stems, fused --------------------------------------------------
  * Replaces DLA.forward's base_layer / pre_img_layer / pre_hm_layer and their sum

@@ -116,7 +116,7 @@ def test_two_launch_shape_choices_give_identical_ids(device, monkeypatch):
             out.append((res, d))
         runs.append(out)
         algos.append([(l.name, int(l.args.algo), int(l.args.split_k)) for l in det._ctx['plan']['launches']
-                      if l.fn in ('conv', 'dcn')])
+                      if l.fn == 'conv'] + [tuple(det._ctx['plan']['dcn_knobs'])])
     assert algos[0] != algos[1], 'the two runs must use different launch shapes'
     swaps = 0
     for t, ((ra, da), (rb, db)) in enumerate(zip(*runs)):

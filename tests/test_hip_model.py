@@ -76,8 +76,7 @@ def test_backbone_levels_match_oracle(device):
     for l in plan['launches']:
         if l.fn == 'conv' and len(l.keep) > 2 and hasattr(l.keep[2], 'to_nchw'):
             outs[l.name] = l.keep[2]
-        if l.fn == 'dcn':
-            outs[l.name] = l.keep[2]
+    outs.update({k + '.dcn': v for k, v in plan['dcn_layers'].items()})
     names = ['level0', 'level1', 'base.level2.root', 'base.level3.tree2.root', 'base.level4.tree2.root',
              'base.level5.root']
     refs = list(base) + [ups[2], ups[1], ups[0]]

@@ -216,6 +216,10 @@ DCN_CASES = [
     (1, 16, 16, 128, 128, 1.0, 1),
     (6, 32, 32, 64, 128, 1.0, 1),     # BN=128 config (>= 512 tiles)
     (1, 8, 8, 256, 64, 1.0, 4),
+    (1, 8, 16, 64, 64, 0.5, 1, 23264),    # 8 waves per workgroup: two K groups (18 steps -> 9 + 9)
+    (2, 7, 19, 96, 96, 3.0, 1, 23264),    # ... odd step count (27 = 14 + 13), ragged, out-of-range taps
+    (1, 6, 16, 128, 256, 1.0, 2, 232128), # ... 128-cout tiles + split-K
+    (1, 5, 9, 32, 64, 1.0, 1, 23264),     # ... one chunk: 9 steps = 5 + 4
 ]
 
 
@@ -271,7 +275,9 @@ def test_offset_conv_plus_dcn_is_DCN_module(device):
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k', [(1, 12, 20, 64, 64, 3264, 1), (2, 9, 21, 128, 64, 0, 2),
-                                                       (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8)])
+                                                       (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8),
+                                                       (1, 12, 20, 64, 64, 23264, 1), (2, 9, 21, 128, 64, 23264, 2),
+                                                       (1, 8, 8, 256, 256, 232128, 4)])
 def test_dcn_with_fused_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, algo, split_k):
     """one launch: conv_offset_mask + sigmoid(mask) + deformable conv == upstream DCN.forward (oracle)"""
     from centertrack_amd import ops
@@ -311,6 +317,80 @@ def test_dcn_with_fused_idaup_step(device, f, split_k):
                     w_off=wop, b_off=bo.to(device))
     two = ops.upsample_add(pr, wt, f, sv)
     assert torch.equal(two.to_nchw(), up_out.to_nchw())
+
+
+@pytest.mark.parametrize('kw', [1, 2])
+def test_dcn_group_launch_equals_single_launches(device, kw):
+    """ct_dcn_v2_group: three independent layers of different shapes -- fused offset conv + IDAUp step with split-K,
+    offset/mask map read from HBM, fused offset conv without split -- in ONE gather/contraction launch and ONE
+    finishing launch == the same layers launched one by one (bit for bit at kw = 1: same tiles, same split-K, same
+    reduction order), also when the two phases are issued separately, and == the oracle."""
+    import ctypes
+    from centertrack_amd import _lib, ops
+    from oracle import dcn_v2 as odcn
+    lib = _lib.load()
+    specs = [dict(N=1, H=6, W=10, Cin=128, Cout=64, split=2, fuse=True, f=2),
+             dict(N=2, H=5, W=17, Cin=256, Cout=128, split=4, fuse=False, f=0),
+             dict(N=1, H=12, W=20, Cin=64, Cout=64, split=1, fuse=True, f=0)]
+    descs, keep, want, single = [], [], [], []
+    for i, sp in enumerate(specs):
+        N, H, W, Cin, Cout = sp['N'], sp['H'], sp['W'], sp['Cin'], sp['Cout']
+        x = F.relu(_rand(N, Cin, H, W, seed=60 + i))
+        w, b = _rand(Cout, Cin, 3, 3, seed=70 + i, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=80 + i)
+        wo, bo = _rand(27, Cin, 3, 3, seed=90 + i, scale=0.5 * (Cin * 9) ** -0.5), _rand(27, seed=100 + i, scale=0.3)
+        scale = torch.rand(Cout, generator=torch.Generator().manual_seed(110 + i)) + 0.5
+        y = F.relu(odcn.dcn_forward(x, w, None, wo, bo) * scale.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+        xv = ops.view_from_nchw(x.to(device))
+        wp, wop = ops.pack_weight(w.to(device)), ops.pack_weight(wo.to(device))
+        sc_d, b_d, bo_d = scale.to(device), b.to(device), bo.to(device)
+        om = None
+        if not sp['fuse']:
+            om = ops.conv2d(xv, wop, 27, 3, 1, shift=bo_d, sig=(18, 27), out=ops.new_view(N, H, W, 32, device))
+        up = up1 = None
+        out = ops.new_view(N, H, W, Cout, device)
+        if sp['f']:
+            f = sp['f']
+            wup, skip = _rand(Cout, 1, 2 * f, 2 * f, seed=120 + i), _rand(N, Cout, H * f, W * f, seed=130 + i)
+            y = F.conv_transpose2d(y, wup, None, stride=f, padding=f // 2, groups=Cout) + skip
+            wt, sv = ops.upsample_weight(wup.to(device)), ops.view_from_nchw(skip.to(device))
+            up = (wt, f, sv, ops.new_view(N, H * f, W * f, Cout, device))
+            up1 = (wt, f, sv, ops.new_view(N, H * f, W * f, Cout, device))
+        want.append(y)
+        fuse_kw = dict(w_off=wop, b_off=bo_d) if sp['fuse'] else {}
+        d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sp['split'], algo=23264 if kw == 2 else 3264,
+                              up=up, **fuse_kw)
+        need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d))
+        assert (need > 0) == (sp['split'] > 1 or sp['f'] > 0)
+        ws = torch.empty(max(need, 4) // 4, device=device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+        descs.append(d)
+        keep += [xv, wp, wop, sc_d, b_d, bo_d, om, up, ws, out]
+        # the same layer alone (legacy entry point, same tile shape and split)
+        one = ops.dcn_v2(xv, om, wp, Cout, sc_d, b_d, relu=True, split_k=sp['split'], algo=23264 if kw == 2 else 3264,
+                         up=up1, **fuse_kw)
+        single.append(up1[3] if up1 is not None else one)
+    arr = (_lib.DcnDesc * 3)(*descs)
+
+    def results():
+        torch.cuda.synchronize()
+        return [(specs[i]['f'] and keep[10 * i + 7][3] or keep[10 * i + 9]).to_nchw().clone() for i in range(3)]
+
+    _lib.check(lib.ct_dcn_v2_group(arr, 3, _lib.CT_DCN_MAIN | _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'group')
+    got = results()
+    for i in range(3):
+        _close(got[i], want[i], msg='group layer %d vs oracle' % i)
+        assert torch.equal(got[i], single[i].to_nchw()), 'group layer %d vs single launch' % i
+    for r in got:
+        r.zero_()
+    for i in range(3):
+        (keep[10 * i + 7][3] if specs[i]['f'] else keep[10 * i + 9]).buf.zero_()
+    # phases issued separately, the finishing launch with another grouping (layer 1 then layers 0 + 2)
+    _lib.check(lib.ct_dcn_v2_group(arr, 3, _lib.CT_DCN_MAIN, _lib.stream_ptr()), 'main')
+    _lib.check(lib.ct_dcn_v2_group((_lib.DcnDesc * 1)(descs[1]), 1, _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'finish 1')
+    _lib.check(lib.ct_dcn_v2_group((_lib.DcnDesc * 2)(descs[0], descs[2]), 2, _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'finish 0,2')
+    again = results()
+    for i in range(3):
+        assert torch.equal(again[i], single[i].to_nchw()), 'separate phases, layer %d' % i
 
 
 @pytest.mark.parametrize('with_img,with_hm,shape', [(True, True, (2, 24, 40)), (True, False, (1, 16, 32)),

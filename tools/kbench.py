@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--layers', default='', help='substring filter on the layer name')
     ap.add_argument('--xcd', action='store_true', help='A/B of the XCD-aware workgroup order only')
     ap.add_argument('--no-dcn', action='store_true')
+    ap.add_argument('--no-conv', action='store_true')
     ap.add_argument('--variant', default='', help='run only this conv variant (e.g. w64x32)')
     args = ap.parse_args()
     lib = _lib.load()
@@ -88,7 +89,7 @@ def main():
                     ('old/cfg0', dict(conv_ks=-2, conv_cfg=0)), ('cfg0/x0', dict(conv_ks=-2, conv_cfg=0, xcd_remap=0)),
                     ('w64x32', dict(algo=202)), ('w64x32/x0', dict(algo=202, xcd_remap=0)),
                     ('w32/k2', dict(algo=205)), ('w32/k2/x0', dict(algo=205, xcd_remap=0))]
-    convs = [c for c in convs if args.layers in c[0]]
+    convs = [] if args.no_conv else [c for c in convs if args.layers in c[0]]
     if args.variant:
         variants = [v for v in variants if v[0] == args.variant]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in variants))
@@ -133,7 +134,12 @@ def main():
              ('32x64/4', dict(algo=3264, split=4)), ('32x64/8', dict(algo=3264, split=8)),
              ('32x128/1', dict(algo=32128, split=1)), ('32x128/4', dict(algo=32128, split=4)),
              ('F32x64/1', dict(algo=3264, split=1, fuse=1)), ('F32x64/2', dict(algo=3264, split=2, fuse=1)),
-             ('F32x64/4', dict(algo=3264, split=4, fuse=1)), ('F32x64/8', dict(algo=3264, split=8, fuse=1))]
+             ('F32x64/4', dict(algo=3264, split=4, fuse=1)), ('F32x64/8', dict(algo=3264, split=8, fuse=1)),
+             ('2F32x64/1', dict(algo=23264, split=1, fuse=1)), ('2F32x64/2', dict(algo=23264, split=2, fuse=1)),
+             ('2F32x64/4', dict(algo=23264, split=4, fuse=1)), ('2x32x64/1', dict(algo=23264, split=1)),
+             ('2x32x64/4', dict(algo=23264, split=4)), ('2x32x128/1', dict(algo=232128, split=1))]
+    if args.no_conv:       # (the DCN study of round 2: 4- vs 8-wave workgroups)
+        dvars = [v for v in dvars if v[0] in ('auto', '32x64/1', '32x64/4', 'F32x64/1', 'F32x64/2', 'F32x64/4', '32x128/1') or v[0].startswith('2')]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in dvars))
     dtot = {v[0]: 0.0 for v in dvars}
     for name, cnt, H, Cin, Cout in dcns:
@@ -149,7 +155,7 @@ def main():
         gf = 2.0 * 9 * Cin * Cout * N * H * H / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in dvars:
-            if kw.get('algo', 0) == 32128 and Cout < 128:
+            if kw.get('algo', 0) in (32128, 232128) and Cout < 128:
                 line += ' %12s' % '-'
                 continue
             fz = dict(w_off=w_off, b_off=b_off) if kw.get('fuse') else {}

@@ -1,6 +1,6 @@
 #!/usr/bin/env python
-"""FETCH_SIZE / WRITE_SIZE summaries (tools/pmc_stats.py output) -> profiles/pmc_traffic.json: HBM bytes per launch
-of the DCNv2 kernel, corrected as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB; on gfx950
+"""FETCH_SIZE / WRITE_SIZE summaries (tools/pmc_stats.py output) -> profiles/pmc_traffic.json: HBM bytes per layer
+of the DCNv2 kernels, corrected as MI355X_MICROARCH.md (HBM section) prescribes: both counters are in KiB; on gfx950
 FETCH_SIZE reports half of the bytes of wide (16 B/lane) coalesced reads -> doubled; WRITE_SIZE taken as is
 (checked against kernels whose output size is known: heads conv 81920 KiB = its 83.9 MB output, stem 16384 KiB)."""
 import json
@@ -29,15 +29,19 @@ def main(fetch_path, write_path, tag):
            'correction': 'KiB -> bytes; FETCH_SIZE x2 (gfx950 wide-read under-count, MI355X_MICROARCH.md); WRITE_SIZE as is',
            'kernels': {}}
     for name in fr:
-        if name in wr and ('dcn_mfma_kernel' in name or 'conv_' in name or 'stem' in name):
+        if name in wr and ('dcn_' in name or 'conv_' in name or 'stem' in name):
             calls, us, fkib = fr[name]
             wkib = wr[name][2]
             out['kernels'][name] = {'calls': calls, 'avg_us': us, 'fetch_bytes': 2 * 1024 * fkib, 'write_bytes': 1024 * wkib,
                                     'hbm_bytes_per_launch': 2 * 1024 * fkib + 1024 * wkib}
-    dcn = [v for k, v in out['kernels'].items() if 'dcn_mfma_kernel' in k]
-    if dcn:
-        n = sum(v['calls'] for v in dcn)
-        out['dcn_mfma_kernel'] = {'launches': n, 'hbm_bytes_per_launch': sum(v['hbm_bytes_per_launch'] * v['calls'] for v in dcn) / n}
+    # every DCN kernel of a frame (grouped gather + contraction launches, the finishing reduce / IDAUp launches), per
+    # LAYER: 16 DCNv2 layers per frame; frames = launches of the stem kernel (one per frame)
+    dcn = [v for k, v in out['kernels'].items() if 'dcn_' in k]
+    frames = [v['calls'] for k, v in out['kernels'].items() if 'stem' in k]
+    if dcn and frames:
+        total = sum(v['hbm_bytes_per_launch'] * v['calls'] for v in dcn)
+        out['dcn_mfma_kernel'] = {'frames': frames[0], 'launches_per_frame': sum(v['calls'] for v in dcn) / frames[0],
+                                  'hbm_bytes_per_frame': total / frames[0], 'hbm_bytes_per_layer': total / frames[0] / 16}
     print(json.dumps(out, indent=1))
 
 
