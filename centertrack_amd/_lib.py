@@ -104,7 +104,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_decode_pose', 'ct_render_pre_hm',
            'ct_tracker_create', 'ct_tracker_destroy', 'ct_tracker_reset', 'ct_tracker_num_tracks',
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
-           'ct_tracker_step_public', 'ct_tracker_step_dets',
+           'ct_tracker_step_public', 'ct_tracker_step_dets', 'ct_transform_points',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
            'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_flip_merge', 'ct_flip_images']
 
@@ -173,6 +173,7 @@ def load():
     lib.ct_tracker_init_tracks.argtypes = [p, p, i]
     lib.ct_tracker_step_public.argtypes = [p, p, i, i, ctypes.POINTER(RowLayout), ctypes.c_float, p, p, i, p, i]
     lib.ct_tracker_step_dets.argtypes = [p, p, i, p, i, p, i]
+    lib.ct_transform_points.argtypes = [p, p, i, p]
     lib.ct_preprocess_image.argtypes = [p, i, i, i, i, p, i, i, p, p, p, i]
     lib.ct_preprocess_lut.argtypes = [p, p, i, p]
     lib.ct_preprocess_device.argtypes = [p, i, i, i, i, p, i, i, p, p, p, p]

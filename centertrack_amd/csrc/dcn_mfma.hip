@@ -50,44 +50,40 @@ struct DcnGroup {
     int n;
 };
 
-// BM = pixels per workgroup (64 = 4 rows x 16, 32 = 2 rows x 16); a K group of 4 waves is a (BM/32) x (128/BM)
-// grid of (pixel-row pairs) x (cout groups); wave tile = 2 m-tiles x WN n-tiles => BN = 16 * WN * 128 / BM couts.
-// KW = K groups per workgroup (256 * KW threads): group g contracts the (chunk, tap) steps g, g + KW, ... into its
-// own accumulators (own A double buffer) and the KW partial tiles are summed through LDS in group order at the
-// end -- at one stream a 512-workgroup layer leaves each CU two workgroups for the whole launch, so the launch
-// lasts as long as ONE workgroup's dependent chain (offset conv -> table -> 18 gather/MFMA steps); twice the waves
-// on half the steps each shorten that chain instead of adding workgroups nobody is waiting for.
+// BM = pixels per workgroup (64 = 4 rows x 16, 32 = 2 rows x 16); the 4 waves are a (BM/32) x (128/BM) grid of
+// (pixel-row pairs) x (cout groups); wave tile = 2 m-tiles x WN n-tiles => BN = 16 * WN * 128 / BM couts.
 // FUSE: the offset/mask conv of upstream's DCN.forward (conv_offset_mask + sigmoid of the mask channels) may be
 // computed by the workgroup itself for its own pixels (per layer, when a.w_off is set: ksplit_conv_tile, result
 // kept in LDS) instead of being read from a map another launch wrote: one launch and one HBM round trip of the
 // 27-channel map less per layer.
-template <int BM, int WN, bool FUSE, int KW>
-__global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
+// NKK = 16-channel slabs per step: 2 (32 channels x 1 tap, 16 * WN MFMAs per wave between barriers) or 4 (64 channels:
+// 32 * WN MFMAs per barrier -- every step pays the same few hundred cycles of LDS round trips, waits and barrier skew, so
+// the matrix pipe's share of a step grows with the work per barrier: measured 47 % busy at 16, 60 % at 32 MFMAs per step).
+template <int BM, int WN, bool FUSE, int NKK = 2>
+__global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 {
-    constexpr int NKK = 2, WM = 2;
+    constexpr int WM = 2;
     constexpr int WGM = BM / 32, WGN = 4 / WGM;
     constexpr int ROWS = BM / 16;
     constexpr int SLAB = BM * 16;            // floats
     constexpr int BUF = NKK * SLAB;
-    constexpr int NTHR = 256 * KW;
+    constexpr int NTHR = 256;
     static_assert(!FUSE || BM == 32, "the fused offset conv works on 32-pixel tiles");
-    static_assert(KW == 1 || KW == 2, "1 or 2 K groups");
-    // dynamic LDS: [ om tile float[BM*32] (FUSE) ] | A tile double buffer x KW | table offsets int4[BM*9] | table
-    // weights float4[BM*9]; the offset-conv stage's scratch and the final cross-group sum alias everything after
-    // the om tile
+    static_assert(NKK == 2 || NKK == 4, "32- or 64-channel steps");
+    constexpr int UPC2 = NKK / 2;            // 32-channel chunks (the split-K bookkeeping unit) per step unit
+    // dynamic LDS: [ om tile float[BM*32] (FUSE) ] | A tile double buffer | table offsets int4[BM*9] | table
+    // weights float4[BM*9]; the offset-conv stage's scratch aliases everything after the om tile
     extern __shared__ __attribute__((aligned(16))) float dlds[];
     float *om_lds = dlds;
     float *lds_a = dlds + (FUSE ? BM * 32 : 0);
-    int *tab_off = reinterpret_cast<int *>(lds_a + KW * 2 * BUF);
-    float *tab_w = lds_a + KW * 2 * BUF + BM * 9 * 4;
+    int *tab_off = reinterpret_cast<int *>(lds_a + 2 * BUF);
+    float *tab_w = lds_a + 2 * BUF + BM * 9 * 4;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: kept in an SGPR
-    const int kg = (KW == 1) ? 0 : (wave >> 2);                  // K group
-    const int w4 = wave & 3;
-    const int tl = tid & 255;                                    // thread index inside the K group
-    const int wm = w4 / WGN, wn = w4 % WGN;
+    const int tl = tid;
+    const int wm = wave / WGN, wn = wave % WGN;
 
     // ---- which layer of the group, which tile, which K split --------------------------------------
     int bid = blockIdx.x;
@@ -111,8 +107,10 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
     const int oy0 = ty * ROWS, ox0 = tx * 16;
-    const int c_begin = split * a.chunksPerSplit;
-    const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
+    // units of 16 * NKK channels (the host keeps chunksPerSplit a multiple of UPC2)
+    const int nunits = a.nchunks / UPC2;
+    const int c_begin = split * (a.chunksPerSplit / UPC2);
+    const int c_end = min(nunits, c_begin + a.chunksPerSplit / UPC2);
 
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
     const bool fuse = FUSE && a.w_off != nullptr;                // (uniform)
@@ -130,8 +128,7 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
                 om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
             }
         };
-        // (8 waves: the taps of every 64-channel chunk are split over the two wave groups as well)
-        ksplit_conv_tile<3, 1, 2, 2, 4, KW>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
+        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
         __syncthreads();
     }
     // ---- B fragment addressing (set up first so that the weights of step 0 are in flight while
@@ -153,15 +150,14 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
                 b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
         }
     };
-    // this K group's steps: linear (chunk, tap) index u = kg, kg + KW, ...  (chunk-outer / tap-inner order, so the
-    // groups work on the same chunk and share its footprint in L1); clamped past the end (never used)
-    const int nall = (c_end - c_begin) * 9;
-    const int nsteps = (nall - kg + KW - 1) / KW;                // steps of this group
-    const int nmax = (nall + KW - 1) / KW;                       // barrier rounds of the workgroup
-    auto step_ct = [&](int s, int &chunk, int &tap) {
-        const int u = min(max(min(s, nsteps - 1), 0) * KW + kg, max(nall - 1, 0));
+    // (chunk, tap) of a step index (chunk-outer / tap-inner order keeps the 9 taps' footprint of a chunk in L1),
+    // clamped to the last valid step (extra fetches are never used)
+    const int nsteps = (c_end - c_begin) * 9;
+    const int nmax = nsteps;
+    auto step_ct = [&](int st, int &chunk, int &tap) {
+        const int u = min(max(st, 0), max(nsteps - 1, 0));
         const int c = u / 9;
-        chunk = min(c_begin + c, a.nchunks - 1);
+        chunk = min(c_begin + c, nunits - 1);
         tap = u - c * 9;
     };
     f32x4 bq[2][NKK][WN];
@@ -216,13 +212,14 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
     }
     __syncthreads();
 
-    // ---- gather assignment inside a K group: thread -> pixel, channel quad, slab(s) ----
-    // BM = 64: thread -> (pixel tl>>2, quad tl&3) for both slabs; BM = 32: (pixel tl>>3, slab (tl>>2)&1, quad tl&3)
-    constexpr int GK = (BM == 64) ? NKK : 1;            // slabs gathered per thread
+    // ---- gather assignment: thread -> pixel, channel quad, slab(s) ----
+    // BM = 64: thread -> (pixel tl>>2, quad tl&3), every slab; BM = 32: (pixel tl>>3, quad tl&3), slabs (tl>>2)&1, +2, ..
+    constexpr int GK = NKK * BM / 64;                   // slabs gathered per thread
+    constexpr int SSTR = (BM == 64) ? 1 : 2;            // ... and their stride
     const int gm = (BM == 64) ? (tl >> 2) : (tl >> 3), gq = tl & 3;
     const int gk0 = (BM == 64) ? 0 : ((tl >> 2) & 1);
     const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);   // float offset inside a slab
-    float *lds_g = lds_a + kg * (2 * BUF);                       // this K group's A double buffer
+    float *lds_g = lds_a;
     // two gather stages in flight (register slots 0/1): the corner loads of step s+2 are issued
     // before the MFMAs of step s and consumed (blend + LDS store) after the MFMAs of step s+1
     f32x4 cv[2][GK][4];
@@ -230,13 +227,13 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
     auto gather_load = [&](int slot, int chunk, int tap) {
         const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
         gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
-        const float *base = xin + chunk * 32 + gk0 * 16 + gq * 4;
+        const float *base = xin + chunk * (16 * NKK) + gk0 * 16 + gq * 4;
 #pragma unroll
         for (int kk = 0; kk < GK; ++kk) {
-            cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * 16);
-            cv[slot][kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * 16);
-            cv[slot][kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * 16);
-            cv[slot][kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * 16);
+            cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * SSTR * 16);
+            cv[slot][kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * SSTR * 16);
+            cv[slot][kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * SSTR * 16);
+            cv[slot][kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * SSTR * 16);
         }
     };
     auto gather_store = [&](int slot, int buf) {
@@ -244,7 +241,7 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
         for (int kk = 0; kk < GK; ++kk) {
             const f32x4 v = gw[slot][0] * cv[slot][kk][0] + gw[slot][1] * cv[slot][kk][1] +
                             gw[slot][2] * cv[slot][kk][2] + gw[slot][3] * cv[slot][kk][3];
-            *reinterpret_cast<f32x4 *>(lds_g + buf * BUF + (gk0 + kk) * SLAB + lslot) = v;
+            *reinterpret_cast<f32x4 *>(lds_g + buf * BUF + (gk0 + kk * SSTR) * SLAB + lslot) = v;
         }
     };
 
@@ -281,7 +278,7 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
             // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
             // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
-            if (KW == 1 || s < nsteps) {                          // (uniform per wave: the other K group may own the last step)
+            {
                 const float *buf = lds_g + P * BUF;
 #pragma unroll
                 for (int kk = 0; kk < NKK; ++kk) {
@@ -306,25 +303,6 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
             step(std::integral_constant<int, 0>{}, s);
             if (s + 1 < nmax) step(std::integral_constant<int, 1>{}, s + 1);
         }
-    }
-
-    if (KW > 1) {
-        // ---- sum of the K groups (group order, deterministic): group 1 parks its tiles in LDS ------------
-        float *red = lds_a;                                      // (the A buffers are dead: every wave passed the last barrier)
-        if (kg == 1) {
-#pragma unroll
-            for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-                    *reinterpret_cast<f32x4 *>(red + (((mt * WN + nt) * 4 + w4) * 64 + lane) * 4) = acc[mt][nt];
-        }
-        __syncthreads();
-        if (kg != 0) return;
-#pragma unroll
-        for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-                acc[mt][nt] += *reinterpret_cast<const f32x4 *>(red + (((mt * WN + nt) * 4 + w4) * 64 + lane) * 4);
     }
 
     if (a.ws) {
@@ -354,9 +332,20 @@ __global__ __launch_bounds__(256 * KW) void dcn_mfma_kernel(DcnGroup g)
     }
 }
 
+// Measured and dropped in round 2 (tools/kbench.py, profiles/r02_kbench_dcn_*.txt; every variant was parity-green):
+//   * 8 waves per workgroup, two K groups in phase (same steps, summed through LDS) and in ANTI-phase (one group's
+//     MFMAs beside the other's gather / blend / weight loads per barrier interval): 64->64 @128x128 x 8 streams 142-144
+//     us against 129 us for this kernel;
+//   * gathering the bilinear corners from an LDS-staged window of the input (+-2 px halo, zero-filled border, global
+//     fall-back per wave-step) on 32- and 64-pixel tiles: 4x fewer vector-memory instructions (SQ_INSTS_VMEM_RD 0.51 M
+//     against 2.03 M per launch) and the same 132 us.
+// PMC of this kernel on that layer: MFMA busy 0.46, 4 waves per SIMD resident, 58 % of the wave cycles in
+// s_waitcnt, 4.1 VALU + 3.7 SALU instructions per MFMA.  A loop of the same MFMAs with LDS fragment reads and a barrier
+// every 16 MFMAs sustains 137-148 TFLOP/s on the same box (tools/micro/mfma_peak.py), so the matrix side is not what
+// holds these kernels near 75-95 TFLOP/s.
 struct DcnPlan {
     int fuse;
-    int BM, BN, KW, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
+    int BM, BN, NKK, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
     int use_ws;                      // partial / raw tiles go through the workspace (split-K, or a fused IDAUp step of a group)
 };
 
@@ -384,17 +373,17 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     p->tilesX = ct_cdiv(d->W, 16);
     p->BM = 64;
     p->BN = 64;
-    p->KW = 1;
-    // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile; 23264 /
-    // 232128 = 32-pixel tile, 8 waves (two K groups)
+    p->NKK = 2;
+    // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile; 43264 / 432128 =
+    // 32-pixel tile stepping through 64 channels (32 * WN MFMAs per barrier)
     int algo = d->algo;
-    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 23264 && algo != 232128)
+    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128)
         CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
-    if (algo == 23264) { p->KW = 2; algo = 3264; }
-    else if (algo == 232128) { p->KW = 2; algo = 32128; }
+    if (algo == 43264) { p->NKK = 4; algo = 3264; }
+    else if (algo == 432128) { p->NKK = 4; algo = 32128; }
     if (grouped) {
-        if (algo != 0 && algo != 3264) CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel x 64-cout tiles (algo 3264 / 23264)");
-        algo = 3264;
+        if (algo != 0 && algo != 3264 && algo != 32128) CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128)");
+        if (algo == 0) algo = 3264;
     }
     if (algo == 3264) { p->BM = 32; p->BN = 64; }
     else if (algo == 32128) { p->BM = 32; p->BN = 128; }
@@ -404,9 +393,10 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     else if (ct_tune_get(CT_TUNE_DCN_BN) == 64) p->BN = 64;
     else if (d->Cout >= 128 && (long)d->N * p->tilesX * ct_cdiv(d->H, 4) * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
     if (p->fuse) {
-        if (algo == 64 || algo == 128) CT_FAIL_ARG("ct_dcn_v2: fuse_offset runs on the 32-pixel tiles (algo 3264 / 32128)");
+        if (algo == 64 || algo == 128) CT_FAIL_ARG("ct_dcn_v2: fuse_offset runs on the 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128)");
         if (p->BM != 32) { p->BM = 32; p->BN = 64; }
     }
+    if (p->NKK == 4 && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: the 64-channel-step shapes need Cin %% 64 == 0 (got %d)", d->Cin);
     p->tilesY = ct_cdiv(d->H, p->BM / 16);
     p->coutBlocks = ct_cdiv(d->Cout, p->BN);
     p->nchunks = d->Cin / 32;
@@ -421,9 +411,11 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
             if (splits > 16) splits = 16;
         }
     }
-    if (splits > p->nchunks) splits = p->nchunks;
+    const int upc = p->NKK / 2;                       // 32-channel chunks per step unit: a split owns whole units
+    const int nunits = p->nchunks / upc;
+    if (splits > nunits) splits = nunits;
     if (splits < 1) splits = 1;
-    p->chunksPerSplit = ct_cdiv(p->nchunks, splits);
+    p->chunksPerSplit = ct_cdiv(nunits, splits) * upc;
     p->splits = ct_cdiv(p->nchunks, p->chunksPerSplit);
     p->use_ws = (p->splits > 1 || (grouped && d->up_w)) ? 1 : 0;
     return CT_OK;
@@ -545,11 +537,10 @@ void fill_args(const ct_dcn_desc *d, const DcnPlan &p, DcnArgs *a)
 }
 
 // dynamic LDS of one workgroup: A double buffers + the two tables (+ om tile and the offset-conv scratch when fused)
-template <int KW>
-size_t lds_bytes(int BM, bool fuse_any, bool single_chunk)
+size_t lds_bytes(int BM, bool fuse_any, bool single_chunk, int NKK = 2)
 {
-    using OffCfg = KsCfg<3, 1, 2, 2, 4, KW>;
-    size_t regionA = sizeof(float) * (size_t)(KW * 2 * 2 * BM * 16 + 2 * BM * 9 * 4);
+    using OffCfg = KsCfg<3, 1, 2, 2, 4>;
+    size_t regionA = sizeof(float) * (size_t)(2 * NKK * BM * 16 + 2 * BM * 9 * 4);
     if (!fuse_any) return regionA;
     // (every fused layer has Cin == 64: the offset conv holds a single chunk and needs no double buffer)
     const size_t scratch = single_chunk ? sizeof(float) * (size_t)OffCfg::LDS1_FLOATS : OffCfg::LDS_BYTES;
@@ -572,7 +563,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         DcnPlan &p = plans[i];
         int rc = make_plan(d, &p, grouped);
         if (rc != CT_OK) return rc;
-        if (p.BM != plans[0].BM || p.BN != plans[0].BN || p.KW != plans[0].KW)
+        if (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK)
             CT_FAIL_ARG("ct_dcn_v2_group: layer %d resolves to another tile shape than layer 0", i);
         const size_t need = ws_bytes(d, p);
         if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
@@ -614,28 +605,28 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
     const dim3 grid((unsigned)blocks);
     if (!(phases & CT_DCN_MAIN)) {
         // finish only: the partials were written by an earlier CT_DCN_MAIN call on the same descriptors
-    } else if (p0.KW == 2) {
-        if (p0.BM != 32) CT_FAIL_ARG("ct_dcn_v2: the 8-wave shapes run on 32-pixel tiles");
-        const size_t lds = lds_bytes<2>(32, fuse_any, single_chunk);
+    } else if (p0.NKK == 4) {
+        if (p0.BM != 32) CT_FAIL_ARG("ct_dcn_v2: the 64-channel-step shapes run on 32-pixel tiles");
+        const size_t lds = lds_bytes(32, fuse_any, single_chunk, 4);
         if (fuse_any) {
-            if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true, 2>), grid, dim3(512), lds, s, g);
-            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true, 2>), grid, dim3(512), lds, s, g);
+            if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true, 4>), grid, dim3(256), lds, s, g);
+            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true, 4>), grid, dim3(256), lds, s, g);
         } else {
-            if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false, 2>), grid, dim3(512), lds, s, g);
-            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false, 2>), grid, dim3(512), lds, s, g);
+            if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false, 4>), grid, dim3(256), lds, s, g);
+            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false, 4>), grid, dim3(256), lds, s, g);
         }
     } else if (fuse_any) {
-        const size_t lds = lds_bytes<1>(32, true, single_chunk);
-        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true, 1>), grid, dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true, 1>), grid, dim3(256), lds, s, g);
+        const size_t lds = lds_bytes(32, true, single_chunk);
+        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, true>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), grid, dim3(256), lds, s, g);
     } else if (p0.BM == 32) {
-        const size_t lds = lds_bytes<1>(32, false, false);
-        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false, 1>), grid, dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false, 1>), grid, dim3(256), lds, s, g);
+        const size_t lds = lds_bytes(32, false, false);
+        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<32, 2, false>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, false>), grid, dim3(256), lds, s, g);
     } else {
-        const size_t lds = lds_bytes<1>(64, false, false);
-        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4, false, 1>), grid, dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2, false, 1>), grid, dim3(256), lds, s, g);
+        const size_t lds = lds_bytes(64, false, false);
+        if (p0.BN == 128) hipLaunchKernelGGL((dcn_mfma_kernel<64, 4, false>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn_mfma_kernel<64, 2, false>), grid, dim3(256), lds, s, g);
     }
     CT_CHECK_LAUNCH("ct_dcn_v2");
     if (!(phases & CT_DCN_FINISH)) return CT_OK;

@@ -438,6 +438,16 @@ int associate(Tracker *tr, std::vector<ct_track> &dets, const float *public_cts,
 
 }  // namespace
 
+extern "C" int ct_transform_points(const float *trans, const float *xy, int n, float *out)
+{
+    if (!trans || (n > 0 && (!xy || !out)) || n < 0) {
+        ct_set_error("ct_transform_points: bad argument");
+        return -1;
+    }
+    for (int i = 0; i < n; ++i) xform(trans, xy[2 * i], xy[2 * i + 1], &out[2 * i], &out[2 * i + 1]);
+    return n;
+}
+
 extern "C" int ct_tracker_set_mode(void *h, int hungarian, int public_det)
 {
     Tracker *tr = static_cast<Tracker *>(h);

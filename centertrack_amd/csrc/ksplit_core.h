@@ -10,11 +10,9 @@
 #pragma once
 #include "ct_common.h"
 
-// TG > 1 additionally splits the TAPS of every chunk over TG wave groups (wave = tg * WK + slab): the fused
-// offset conv of the 8-wave DCN workgroups has a single 64-channel chunk, so its 9 taps are what is left to split.
-template <int KS, int STRIDE, int WM, int WN, int WK, int TG = 1>
+template <int KS, int STRIDE, int WM, int WN, int WK>
 struct KsCfg {
-    static constexpr int NTHR = 64 * WK * TG;
+    static constexpr int NTHR = 64 * WK;
     static constexpr int BN = 16 * WN;
     static constexpr int PH = (WM - 1) * STRIDE + KS;
     static constexpr int PW = 15 * STRIDE + KS;
@@ -23,7 +21,7 @@ struct KsCfg {
     static constexpr int BUF = WK * SLAB;
     static constexpr int ITEMS = WK * PP * 4;
     static constexpr int NR = (ITEMS + NTHR - 1) / NTHR;
-    static constexpr int RED = WK * TG * WM * WN * 256;
+    static constexpr int RED = WK * WM * WN * 256;
     static constexpr size_t LDS_BYTES = sizeof(float) * (size_t)((2 * BUF > RED) ? 2 * BUF : RED);
     // floats needed when a launch holds a single chunk (no double buffering)
     static constexpr int LDS1_FLOATS = (BUF > RED) ? BUF : RED;
@@ -33,23 +31,20 @@ struct KsCfg {
 // (NT n-tiles of 16 couts); this workgroup's first n-tile is nt0; chunks [c_begin, c_end) of 16*WK
 // channels; lds: >= KsCfg::LDS_BYTES (or LDS1_FLOATS floats for a single chunk), free for reuse on
 // return AFTER a __syncthreads().  fin(mt, nt, sum) is called by exactly one wave per tile.
-template <int KS, int STRIDE, int WM, int WN, int WK, int TG = 1, typename Fin>
+template <int KS, int STRIDE, int WM, int WN, int WK, typename Fin>
 __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W, int ldx, int Cin, const float *wp, int NT,
                                                  int nt0, int oy0, int ox0, int c_begin, int c_end, float *lds, Fin fin)
 {
-    using C = KsCfg<KS, STRIDE, WM, WN, WK, TG>;
+    using C = KsCfg<KS, STRIDE, WM, WN, WK>;
     constexpr int PAD = KS / 2;
-    constexpr int TAPS = KS * KS;
-    constexpr int S = (TAPS + TG - 1) / TG;          // steps (taps) per chunk and wave
+    constexpr int S = KS * KS;                       // steps (taps) per chunk and wave
     constexpr int D = 2;                             // B prefetch distance (steps)
     constexpr int R = D + 1;                         // register ring
     constexpr int U = (S % R == 0) ? 1 : R;          // chunk unroll so that ring slots stay static
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // uniform: SGPR
-    const int slab = (TG == 1) ? wave : wave % WK;                // K slab inside a chunk
-    const int tap0 = (TG == 1) ? 0 : (wave / WK) * S;             // this wave's taps: [tap0, min(tap0 + S, TAPS))
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = K slab inside a chunk (uniform: SGPR)
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
 
     int goff[C::NR], loff[C::NR];
@@ -97,11 +92,10 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
     for (int nt = 0; nt < WN; ++nt) bptr[nt] = wp + ((size_t)min(nt0 + nt, NT - 1) << 8) + (lane << 2);
     const size_t slab_stride = (size_t)NT << 8;
     // B fragment of (chunk, tap) for THIS wave's slab; chunks past the end clamp (loaded, never used)
-    auto load_b = [&](f32x4 (&b)[WN], int chunk, int step) {
-        const int tap = (TG == 1) ? step : min(tap0 + step, TAPS - 1);
-        const size_t sl = (size_t)tap * NCH16 + (size_t)min(chunk, c_end - 1) * WK + slab;
+    auto load_b = [&](f32x4 (&b)[WN], int chunk, int tap) {
+        const size_t slab = (size_t)tap * NCH16 + (size_t)min(chunk, c_end - 1) * WK + wave;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + sl * slab_stride);
+        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
     };
 
     f32x4 acc[WM][WN];
@@ -126,16 +120,14 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                     const int cur = (c - c_begin) & 1;
                     stage_load(min(c + 1, c_end - 1));
                     __builtin_amdgcn_sched_barrier(0x386);
-                    const float *buf = lds + cur * C::BUF + slab * C::SLAB;
+                    const float *buf = lds + cur * C::BUF + wave * C::SLAB;
 #pragma unroll
                     for (int s = 0; s < S; ++s) {
                         const int g = u * S + s;                    // static position in the unrolled body
                         const int sp = s + D;
                         load_b(breg[(g + D) % R], c + sp / S, sp % S);
                         __builtin_amdgcn_sched_barrier(0x386);
-                        const int tap = tap0 + s;
-                        if (TG > 1 && tap >= TAPS) continue;        // (wave-uniform: the last tap group may be short)
-                        const int ky = tap / KS, kx = tap - ky * KS;
+                        const int ky = s / KS, kx = s % KS;
                         f32x4 af[WM];
 #pragma unroll
                         for (int mt = 0; mt < WM; ++mt) {
@@ -167,14 +159,13 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
         for (int nt = 0; nt < WN; ++nt)
             *reinterpret_cast<f32x4 *>(red + ((wave * T + mt * WN + nt) * 64 + lane) * 4) = acc[mt][nt];
     __syncthreads();
-    constexpr int NW = WK * TG;
 #pragma unroll
-    for (int t0 = 0; t0 < T; t0 += NW) {
+    for (int t0 = 0; t0 < T; t0 += WK) {
         const int t = t0 + wave;
         if (t < T) {
             f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (t * 64 + lane) * 4);
 #pragma unroll
-            for (int w = 1; w < NW; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
+            for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
             fin(t / WN, t % WN, sum);
         }
     }

@@ -74,6 +74,26 @@ def render_pre_hm(tracks, meta, pre_thresh, out=None, with_hm=True):
     return hm, inds
 
 
+def imread_bgr(path):
+    """``cv2.imread(path)`` (detector.py:66): the decoded image as uint8 [H,W,3] in BGR channel order.  cv2 is used
+    when it is installed (bit-identical to the reference by construction); otherwise Pillow decodes the file -- lossless
+    formats (PNG, BMP, PPM) give the same pixels, JPEG decoders may differ in the last bit of a pixel."""
+    try:
+        import cv2
+        img = cv2.imread(str(path))
+        if img is None:
+            raise _lib.CTError('cannot read image %r' % (path,))
+        return img
+    except ImportError:
+        pass
+    try:
+        from PIL import Image
+    except ImportError:
+        raise _lib.CTError('reading image files needs cv2 or Pillow; pass the decoded uint8 BGR array instead')
+    with Image.open(path) as im:
+        return np.ascontiguousarray(np.asarray(im.convert('RGB'))[:, :, ::-1])
+
+
 class _HipGraph(object):
     """One captured frame (ct_graph_begin / ct_graph_end); ``replay()`` enqueues it on the current stream."""
 
@@ -125,10 +145,9 @@ class StreamDetector(object):
         self.use_graph = use_graph
         self.trackers = [Tracker(opt) for _ in range(self.B)]
         # native host path (C++ post-process + association incl. the Hungarian / public-detection / pre_dets branches
-        # + device-rendered prior heat-map); the reference-shaped Python path serves zero_pre_hm and the pose task
+        # + device-rendered prior heat-map, key points of the pose task); the reference-shaped Python path serves zero_pre_hm
         self.native = bool(native_host and getattr(opt, 'tracking', False) and 'tracking' in opt.heads
-                           and not getattr(opt, 'zero_pre_hm', False)
-                           and 'hps' not in opt.heads)         # (key points ride on the Python host path)
+                           and not getattr(opt, 'zero_pre_hm', False))
         self.fast = [fast_track.FastTracker(opt.new_thresh, getattr(opt, 'max_age', -1), opt.K,
                                             hungarian=getattr(opt, 'hungarian', False),
                                             public_det=getattr(opt, 'public_det', False))
@@ -458,8 +477,9 @@ class StreamDetector(object):
         ``calib`` yields the 3D location / yaw of the ddd heads)"""
         if isinstance(results, np.ndarray):
             carried = self._carried.setdefault(stream, {})
+            tinv = meta['_trans_inv'][1] if (meta is not None and '_trans_inv' in meta) else None
             return fast_track.as_dicts(results, self.last_dets, stream, None if meta is None else meta.get('calib'),
-                                       carried)
+                                       carried, tinv)
         return results
 
 
@@ -538,14 +558,17 @@ class Detector(object):
             meta = m
         elif torch.is_tensor(x):
             images = x
-        elif isinstance(x, np.ndarray):                        # raw BGR frame (demo.py / README embedding)
+        elif isinstance(x, (str, os.PathLike)) or isinstance(x, np.ndarray):
+            if not isinstance(x, np.ndarray):                  # image file (detector.py:65-66; test.py:163)
+                x = imread_bgr(x)
+            # raw BGR frame (demo.py / README embedding)
             if getattr(self.opt, 'device_pre_process', True) and x.ndim == 3 and x.shape[2] == 3:
                 images, meta = [x], self.frame_meta(x, meta)   # u8 upload + warp on the device
             else:
                 images, meta = self.pre_process(x, 1.0, meta)
         else:
-            raise _lib.CTError('run() takes a uint8 image array, a normalised tensor + meta, or a pre-processed '
-                               'dict; reading image files (cv2.imread) is left to the caller')
+            raise _lib.CTError('run() takes an image path, a uint8 image array, a normalised tensor + meta, or a '
+                               'pre-processed dict (got %s)' % type(x).__name__)
         loaded = time.time()
         timers = {}
         results = self.impl.results_as_dicts(self.impl.step(images, [meta], timers)[0], 0, meta)

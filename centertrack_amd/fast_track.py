@@ -147,12 +147,13 @@ class FastTracker(object):
         return n, dst
 
 
-def as_dicts(arr, dets=None, stream=0, calib=None, carried=None):
+def as_dicts(arr, dets=None, stream=0, calib=None, carried=None, trans_inv=None):
     """structured result array -> the reference's list of dicts.  Fields the native rows do not carry are attached
     from ``dets`` (the decode dict of the frame) via the source row, like generic_post_process does
     (post_process.py:56-88): dep, dim, the observation angle ``alpha`` from the 8-bin ``rot``, and with ``calib``
     the 3D location / yaw (``loc``, ``rot_y``; the amodal centre is already the row's ``ct``), nuscenes_att,
-    velocity.  ``carried``: optional dict {tracking_id: extras} owned by the caller; tracks kept alive without a
+    velocity; with ``trans_inv`` (the float32 [2,3] output-grid -> image affine of the frame) the key points ``hps``
+    of the pose task in image coordinates (post_process.py:51-54, native ``ct_transform_points``).  ``carried``: optional dict {tracking_id: extras} owned by the caller; tracks kept alive without a
     detection (row < 0, ``max_age``) get back the extras of their last detection, as the reference's track dicts do."""
     from .post_process import ddd2locrot, get_alpha
     out = []
@@ -176,6 +177,13 @@ def as_dicts(arr, dets=None, stream=0, calib=None, carried=None):
             for k in ('nuscenes_att', 'velocity'):
                 if k in dets:
                     extras[k] = np.array(dets[k][stream][row])
+            if 'hps' in dets and trans_inv is not None:
+                pts = np.ascontiguousarray(dets['hps'][stream][row], np.float32)
+                out_pts = np.empty_like(pts)
+                if _lib.load().ct_transform_points(trans_inv.ctypes.data, pts.ctypes.data, pts.size // 2,
+                                                   out_pts.ctypes.data) < 0:
+                    _lib.check(1, 'ct_transform_points')
+                extras['hps'] = out_pts
             d.update(extras)
             if carried is not None:
                 carried[d['tracking_id']] = extras

@@ -391,13 +391,13 @@ class DLASegHIP(torch.nn.Module):
         inputs exist: main(L) = first t with 2t > time(x); finish(L) = first t' >= main(L) with 2t'+1 > time(skip).
         The layers sharing a slot go out as ONE ct_dcn_v2_group launch each for M_t and F_t: 8 + 7 launches for the
         16 nodes instead of 16 + (offset convs) + 8 reductions, and at one stream 768 .. 1536 workgroups per launch
-        instead of 128 .. 512.  knobs = (fuse_max_cin, chunks_per_split, kw_below): the offset/mask conv is computed
+        instead of 128 .. 512.  knobs = (fuse_max_cin, chunks_per_split, nkk): the offset/mask conv is computed
         inside the DCN launch for Cin <= fuse_max_cin (else by its own conv launch just before the slot), every
-        workgroup contracts chunks_per_split 32-channel chunks, and slots with fewer than kw_below workgroups run
-        the 8-wave shape (two K groups per workgroup)."""
+        workgroup contracts chunks_per_split 32-channel chunks, in steps of 16 * nkk channels (nkk = 2 / 4: 16 / 32
+        MFMAs per wave between barriers)."""
         lib = _lib.load()
         P = self._prepared
-        fuse_max_cin, cps, kw_below = knobs
+        fuse_max_cin, cps, nkk = knobs
         time_of = dict(produced0)                    # buffer id -> time after which it is readable
 
         def t_of(view):
@@ -443,14 +443,14 @@ class DLASegHIP(torch.nn.Module):
                 slots.setdefault(ly.finish, {'main': [], 'finish': []})['finish'].append(ly)
         out = []
 
-        def group(lys, phases, tag, kw):
+        def group(lys, phases, tag):
             for i in range(0, len(lys), 4):
                 part = lys[i:i + 4]
                 arr = (_lib.DcnDesc * len(part))()
                 keep = []
                 for j, ly in enumerate(part):
                     ctypes.memmove(ctypes.byref(arr[j]), ctypes.byref(ly.desc[0]), ctypes.sizeof(_lib.DcnDesc))
-                    arr[j].algo = 23264 if kw == 2 else 3264
+                    arr[j].algo = 43264 if nkk == 4 else 3264
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
@@ -459,10 +459,9 @@ class DLASegHIP(torch.nn.Module):
             out.extend(convs.get(t, []))
             lys = slots[t]['main']
             if lys:
-                wgs = sum(N * ((ly.x.H + 1) // 2) * ((ly.x.W + 15) // 16) * ((ly.cout + 63) // 64) * ly.splits for ly in lys)
-                group(lys, _lib.CT_DCN_MAIN, 'dcn', 2 if wgs < kw_below else 1)
+                group(lys, _lib.CT_DCN_MAIN, 'dcn')
             if slots[t]['finish']:
-                group(slots[t]['finish'], _lib.CT_DCN_FINISH, 'dcn.finish', 1)
+                group(slots[t]['finish'], _lib.CT_DCN_FINISH, 'dcn.finish')
         return out
 
     def _time_launches(self, launches, reps=10):
@@ -506,10 +505,10 @@ class DLASegHIP(torch.nn.Module):
         if env:
             knobs = tuple(int(v) for v in env.split(','))
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
-        default = (128, 2, 768)
+        default = (128, 4, 4)
         if not tune:
             return default, self._schedule_dcn(layers, produced0, N, dev, default)
-        key = 'dcnplan:%d,%d,%d' % (N, H, W)
+        key = 'dcnplan2:%d,%d,%d' % (N, H, W)
         autotune._load_file()
         if key in autotune._CACHE:
             knobs = tuple(int(v) for v in autotune._CACHE[key][:3])
@@ -517,8 +516,8 @@ class DLASegHIP(torch.nn.Module):
         best = None
         for fuse_max in (64, 128, 256):
             for cps in (2, 4):
-                for kw_below in (0, 768, 1 << 30):
-                    knobs = (fuse_max, cps, kw_below)
+                for nkk in (2, 4):
+                    knobs = (fuse_max, cps, nkk)
                     launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
                     us = self._time_launches(launches)
                     if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):

@@ -110,10 +110,8 @@ typedef struct ct_dcn_desc {
     int split_k;
     int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
                                                    workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts;
-                                                   23264 / 232128 = the same with 8 waves per workgroup (two wave
-                                                   groups split the (chunk, tap) steps and are summed through LDS:
-                                                   half the dependent chain of a workgroup, for launches that leave
-                                                   a CU only one or two workgroups) */
+                                                   43264 / 432128 = the same stepping through 64 instead of 32
+                                                   channels per barrier (Cin % 64 == 0) */
     int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
                                                    unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile */
@@ -128,8 +126,8 @@ size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
 /* Up to 4 INDEPENDENT DeformConv layers in one launch (+ one reduce launch that finishes all of them): the IDAUp /
  * DLAUp tree (dla.py:539-574) has several layers ready at the same time -- every `proj_i` only needs a finished
  * level, `node_i` of different IDAUp stages do not depend on each other -- and at one stream each of them alone
- * cannot fill 256 CUs.  All layers run on 32-pixel x 64-cout tiles (algo 0 / 3264, or 23264 for all of them);
- * split_k == 0 gives every workgroup two 32-channel chunks (18 (chunk, tap) steps), so the layers of a group finish
+ * cannot fill 256 CUs.  All layers run on the same 32-pixel tile shape (algo 0 / 3264 / 32128 / 43264 / 432128);
+ * split_k == 0 gives every workgroup two 32-channel chunks (64 input channels), so the layers of a group finish
  * together whatever their Cin; fuse_offset is per layer; a fused IDAUp step (up_w) always goes through the
  * workspace (y is then not written).  Each layer needs its OWN workspace of ct_dcn_v2_group_workspace_bytes(d)
  * bytes (the layers run concurrently).  `phases`: CT_DCN_MAIN | CT_DCN_FINISH runs both launches back to back;
@@ -285,6 +283,10 @@ int ct_tracker_step_public(void *tracker, const float *rows, int K, int F, const
                            const float *trans_inv, const float *public_cts, int n_public, ct_track *out, int cap);
 int ct_tracker_step_dets(void *tracker, const ct_track *dets, int n, const float *public_cts, int n_public,
                          ct_track *out, int cap);
+/* Key points of the pose task (`hps`, src/lib/utils/post_process.py:51-54): n (x, y) pairs on the output grid ->
+ * image coordinates with the same float32 [2,3] affine and operation order as the boxes / centres of
+ * ct_tracker_step (transform_preds_with_trans, src/lib/utils/image.py:20-26); returns n or -1. */
+int ct_transform_points(const float *trans_inv, const float *xy, int n, float *out);
 /* (cx, cy, radius) int32 triples of the next frame's prior heat-map; trans_input float64 [2,3] */
 int ct_tracker_prehm_params(void *tracker, float pre_thresh, const double *trans_input, int inp_w, int inp_h,
                             int *params, int cap);

@@ -262,3 +262,29 @@ def test_native_host_path_serves_hungarian_public_det_and_pre_dets(device, hunga
         assert [key(r) for r in a] == [key(r) for r in b], 'frame %d' % t
         pre = b
     assert nat.tracker.id_count == pyt.tracker.id_count and nat.tracker.id_count > 1
+
+
+def test_run_on_an_image_path_equals_run_on_the_decoded_array(device, tmp_path):
+    """Detector.run(path) -- test.py's --not_prefetch_test loop (test.py:163) -- decodes the file and takes the raw-frame
+    path: same tracks as handing over the decoded array"""
+    from PIL import Image
+    from centertrack_amd import scenarios as S
+    from centertrack_amd.detector import Detector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    mk = lambda: default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'],
+                             input_h=cfg['H'], input_w=cfg['W'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    a, b = Detector(mk(), model=model), Detector(mk(), model=model)
+    rs = np.random.RandomState(6)
+    base = rs.randint(0, 256, (cfg['orig_h'], cfg['orig_w'] + 16, 3)).astype(np.uint8)
+    for t in range(2):
+        frame = np.ascontiguousarray(base[:, 8 * t:8 * t + cfg['orig_w']])
+        path = str(tmp_path / ('%d.png' % t))
+        Image.fromarray(frame[:, :, ::-1]).save(path)
+        ra, rb = a.run(path)['results'], b.run(frame)['results']
+        assert len(ra) == len(rb) and len(ra) > 0
+        assert [(r['tracking_id'], float(r['score']), list(map(float, r['bbox']))) for r in ra] == \
+               [(r['tracking_id'], float(r['score']), list(map(float, r['bbox']))) for r in rb]

@@ -216,10 +216,10 @@ DCN_CASES = [
     (1, 16, 16, 128, 128, 1.0, 1),
     (6, 32, 32, 64, 128, 1.0, 1),     # BN=128 config (>= 512 tiles)
     (1, 8, 8, 256, 64, 1.0, 4),
-    (1, 8, 16, 64, 64, 0.5, 1, 23264),    # 8 waves per workgroup: two K groups (18 steps -> 9 + 9)
-    (2, 7, 19, 96, 96, 3.0, 1, 23264),    # ... odd step count (27 = 14 + 13), ragged, out-of-range taps
-    (1, 6, 16, 128, 256, 1.0, 2, 232128), # ... 128-cout tiles + split-K
-    (1, 5, 9, 32, 64, 1.0, 1, 23264),     # ... one chunk: 9 steps = 5 + 4
+    (1, 8, 16, 64, 64, 0.5, 1, 43264),    # 64-channel steps (32 MFMAs per barrier)
+    (2, 7, 19, 128, 96, 3.0, 1, 43264),   # ... ragged, out-of-range taps
+    (1, 6, 16, 256, 256, 1.0, 2, 432128), # ... 128 couts + split-K (2 units of 64 channels per split)
+    (1, 4, 4, 512, 256, 1.0, 0, 43264),   # ... heuristic split-K
 ]
 
 
@@ -276,8 +276,8 @@ def test_offset_conv_plus_dcn_is_DCN_module(device):
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k', [(1, 12, 20, 64, 64, 3264, 1), (2, 9, 21, 128, 64, 0, 2),
                                                        (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8),
-                                                       (1, 12, 20, 64, 64, 23264, 1), (2, 9, 21, 128, 64, 23264, 2),
-                                                       (1, 8, 8, 256, 256, 232128, 4)])
+                                                       (1, 12, 20, 64, 64, 43264, 1), (2, 9, 21, 128, 64, 43264, 2),
+                                                       (1, 8, 8, 256, 256, 432128, 4)])
 def test_dcn_with_fused_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, algo, split_k):
     """one launch: conv_offset_mask + sigmoid(mask) + deformable conv == upstream DCN.forward (oracle)"""
     from centertrack_amd import ops
@@ -319,12 +319,12 @@ def test_dcn_with_fused_idaup_step(device, f, split_k):
     assert torch.equal(two.to_nchw(), up_out.to_nchw())
 
 
-@pytest.mark.parametrize('kw', [1, 2])
-def test_dcn_group_launch_equals_single_launches(device, kw):
+@pytest.mark.parametrize('galgo', [3264, 43264])
+def test_dcn_group_launch_equals_single_launches(device, galgo):
     """ct_dcn_v2_group: three independent layers of different shapes -- fused offset conv + IDAUp step with split-K,
     offset/mask map read from HBM, fused offset conv without split -- in ONE gather/contraction launch and ONE
-    finishing launch == the same layers launched one by one (bit for bit at kw = 1: same tiles, same split-K, same
-    reduction order), also when the two phases are issued separately, and == the oracle."""
+    finishing launch == the same layers launched one by one (bit for bit: same tiles, same split-K, same reduction
+    order; for every tile shape a group can run on), also when the two phases are issued separately, and == the oracle."""
     import ctypes
     from centertrack_amd import _lib, ops
     from oracle import dcn_v2 as odcn
@@ -357,7 +357,7 @@ def test_dcn_group_launch_equals_single_launches(device, kw):
             up1 = (wt, f, sv, ops.new_view(N, H * f, W * f, Cout, device))
         want.append(y)
         fuse_kw = dict(w_off=wop, b_off=bo_d) if sp['fuse'] else {}
-        d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sp['split'], algo=23264 if kw == 2 else 3264,
+        d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sp['split'], algo=galgo,
                               up=up, **fuse_kw)
         need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d))
         assert (need > 0) == (sp['split'] > 1 or sp['f'] > 0)
@@ -366,7 +366,7 @@ def test_dcn_group_launch_equals_single_launches(device, kw):
         descs.append(d)
         keep += [xv, wp, wop, sc_d, b_d, bo_d, om, up, ws, out]
         # the same layer alone (legacy entry point, same tile shape and split)
-        one = ops.dcn_v2(xv, om, wp, Cout, sc_d, b_d, relu=True, split_k=sp['split'], algo=23264 if kw == 2 else 3264,
+        one = ops.dcn_v2(xv, om, wp, Cout, sc_d, b_d, relu=True, split_k=sp['split'], algo=galgo,
                          up=up1, **fuse_kw)
         single.append(up1[3] if up1 is not None else one)
     arr = (_lib.DcnDesc * 3)(*descs)

@@ -368,3 +368,34 @@ def test_native_tracker_grows_past_its_initial_capacity():
     assert len(got) > cap0 and ft.cap > cap0
     n, prm = ft.prehm_params(0.3, meta['trans_input'], 512, 512)
     assert n == K                                         # only this frame's detections are active
+
+
+def test_native_key_points_equal_the_python_post_process():
+    """pose task: the native rows + as_dicts(trans_inv) give the key points `hps` of generic_post_process
+    (post_process.py:51-54) bit for bit -- ct_transform_points is the float32 [2,3] affine of the boxes"""
+    rs = np.random.RandomState(12)
+    lay_list, F0 = ops.decode_layout(['reg', 'wh', 'tracking'])
+    J = 17
+    F = F0 + 2 * J + 1
+    lay = FT.row_layout(lay_list)
+    K = 30
+    meta = IM.make_meta(512, 512, 480, 640)
+    trans = np.ascontiguousarray(IM.get_affine_transform(
+        meta['c'], meta['s'], 0, (meta['out_width'], meta['out_height']), inv=1).astype(np.float32))
+    opt = types.SimpleNamespace(out_thresh=0.3, new_thresh=0.3, max_age=-1, hungarian=False, public_det=False)
+    rows = np.zeros((K, F), np.float32)
+    rows[:, 0] = np.sort(rs.uniform(0.05, 1, K).astype(np.float32))[::-1]
+    rows[:, 2:4] = np.floor(rs.uniform(5, 120, (K, 2)))
+    rows[:, 4:8] = np.concatenate((rows[:, 2:4] - 4, rows[:, 2:4] + 4), 1)
+    rows[:, F0:F0 + 2 * J] = rs.uniform(-5, 130, (K, 2 * J)).astype(np.float32)
+    dec = {n: (rows[None, :, s] if n in ('scores', 'clses', 'xs', 'ys') else rows[None, :, s:s + w]) for n, s, w in lay_list}
+    dec['cts'] = rows[None, :, 2:4]
+    dec['hps'] = rows[None, :, F0:F0 + 2 * J]
+    ft = FT.FastTracker(0.3, -1, K)
+    got = FT.as_dicts(ft.step(rows, lay, 0.3, trans).copy(), dec, 0, None, None, trans)
+    want = PP.generic_post_process(opt, dec, [meta['c']], [meta['s']], meta['out_height'], meta['out_width'])[0]
+    want = [r for r in want if r['score'] > 0.3]
+    assert len(got) == len(want) > 5
+    for a, b in zip(got, want):
+        np.testing.assert_array_equal(a['hps'], b['hps'])
+        np.testing.assert_array_equal(a['bbox'], b['bbox'])

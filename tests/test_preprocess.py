@@ -160,3 +160,18 @@ def test_warp_stays_within_the_fixed_point_bound_of_an_independent_bilinear_samp
         gy = np.abs(np.diff(padded, axis=0)).max()
         assert err.max() <= (gx + gy) / 64.0 + 1.0, err.max()
         assert err.mean() < 0.5, err.mean()
+
+
+def test_imread_bgr_is_cv2_imread_for_lossless_files(tmp_path):
+    """Detector.run(path) (detector.py:65-66): the file decodes to the uint8 BGR array cv2.imread returns"""
+    from PIL import Image
+    from centertrack_amd.detector import imread_bgr
+    bgr = np.random.RandomState(3).randint(0, 256, (37, 53, 3)).astype(np.uint8)
+    for name in ('f.png', 'f.bmp'):
+        Image.fromarray(bgr[:, :, ::-1]).save(tmp_path / name)
+        got = imread_bgr(str(tmp_path / name))
+        assert got.dtype == np.uint8 and got.flags['C_CONTIGUOUS']
+        np.testing.assert_array_equal(got, bgr)
+    gray = np.random.RandomState(4).randint(0, 256, (9, 11)).astype(np.uint8)
+    Image.fromarray(gray).save(tmp_path / 'g.png')                 # (cv2.imread's default flag also yields 3 channels)
+    np.testing.assert_array_equal(imread_bgr(tmp_path / 'g.png'), np.repeat(gray[:, :, None], 3, 2))

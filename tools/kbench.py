@@ -51,6 +51,9 @@ def main():
     ap.add_argument('--xcd', action='store_true', help='A/B of the XCD-aware workgroup order only')
     ap.add_argument('--no-dcn', action='store_true')
     ap.add_argument('--no-conv', action='store_true')
+    ap.add_argument('--dcn-layers', default='', help='substring filter on the DCN layer name')
+    ap.add_argument('--dvariant', default='', help='run only this DCN variant')
+    ap.add_argument('--off-scale', type=float, default=1.0, help='std (pixels) of the synthetic DCN offsets')
     ap.add_argument('--variant', default='', help='run only this conv variant (e.g. w64x32)')
     args = ap.parse_args()
     lib = _lib.load()
@@ -135,11 +138,14 @@ def main():
              ('32x128/1', dict(algo=32128, split=1)), ('32x128/4', dict(algo=32128, split=4)),
              ('F32x64/1', dict(algo=3264, split=1, fuse=1)), ('F32x64/2', dict(algo=3264, split=2, fuse=1)),
              ('F32x64/4', dict(algo=3264, split=4, fuse=1)), ('F32x64/8', dict(algo=3264, split=8, fuse=1)),
-             ('2F32x64/1', dict(algo=23264, split=1, fuse=1)), ('2F32x64/2', dict(algo=23264, split=2, fuse=1)),
-             ('2F32x64/4', dict(algo=23264, split=4, fuse=1)), ('2x32x64/1', dict(algo=23264, split=1)),
-             ('2x32x64/4', dict(algo=23264, split=4)), ('2x32x128/1', dict(algo=232128, split=1))]
+             ('4x32x64/1', dict(algo=43264, split=1)), ('4x32x64/2', dict(algo=43264, split=2)), ('4x32x64/4', dict(algo=43264, split=4)),
+             ('4x32x128/1', dict(algo=432128, split=1)), ('4x32x128/4', dict(algo=432128, split=4)),
+             ('4F32x64/1', dict(algo=43264, split=1, fuse=1)), ('4F32x64/2', dict(algo=43264, split=2, fuse=1))]
     if args.no_conv:       # (the DCN study of round 2: 4- vs 8-wave workgroups)
-        dvars = [v for v in dvars if v[0] in ('auto', '32x64/1', '32x64/4', 'F32x64/1', 'F32x64/2', 'F32x64/4', '32x128/1') or v[0].startswith('2')]
+        dvars = [v for v in dvars if v[0] in ('32x64/1', '32x64/2', '32x64/4', 'F32x64/1', 'F32x64/2', '32x128/1', '32x128/4') or v[0].startswith('4')]
+    dcns = [c for c in dcns if args.dcn_layers in c[0]]
+    if args.dvariant:
+        dvars = [v for v in dvars if v[0] == args.dvariant]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in dvars))
     dtot = {v[0]: 0.0 for v in dvars}
     for name, cnt, H, Cin, Cout in dcns:
@@ -147,6 +153,7 @@ def main():
         x.buf.normal_()
         om = ops.new_view(N, H, H, 32, dev)
         om.buf.normal_()
+        om.buf[..., :18] *= args.off_scale
         om.buf[..., 18:].sigmoid_()
         w = ops.pack_weight(torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05)
         out = ops.new_view(N, H, H, Cout, dev)
@@ -155,7 +162,7 @@ def main():
         gf = 2.0 * 9 * Cin * Cout * N * H * H / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in dvars:
-            if kw.get('algo', 0) in (32128, 232128) and Cout < 128:
+            if kw.get('algo', 0) in (32128, 432128) and Cout < 128:
                 line += ' %12s' % '-'
                 continue
             fz = dict(w_off=w_off, b_off=b_off) if kw.get('fuse') else {}
