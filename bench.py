@@ -86,13 +86,15 @@ def kernel_pass(model, plan, reps=10):
         if kind == 'dcn':       # the grouped DCN launches (MAIN + FINISH) and the offset/mask convs of the un-fused layers
             launches = [l for l in plan['launches'] if l.fn == 'dcn_group' or l.name.endswith('.offset')]
         else:
-            launches = [l for l in plan['launches'] if l.fn == 'conv' and not l.name.endswith('.offset')]
+            launches = [l for l in plan['launches'] if l.fn in ('conv', 'heads') and not l.name.endswith('.offset')]
 
         def run():
             st = _lib.stream_ptr()
             for l in launches:
                 if l.fn == 'dcn_group':
                     lib.ct_dcn_v2_group(l.args[0], l.args[1], l.args[2], st)
+                elif l.fn == 'heads':
+                    lib.ct_heads_fused(ctypes.byref(l.args), st)
                 else:
                     lib.ct_conv2d(ctypes.byref(l.args), st)
         side = torch.cuda.Stream()
@@ -126,6 +128,12 @@ def kernel_pass(model, plan, reps=10):
                     flops_main += 2.0 * 9 * d.Cin * d.Cout * hw
                     flops += 2.0 * 9 * d.Cin * d.Cout * hw + 2.0 * 9 * d.Cin * 27 * hw      # main + offset/mask conv
                     bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout + 9 * d.Cin * 27 + 27)
+            elif l.fn == 'heads':        # conv3x3 64 -> 256 + conv1x1 256 -> c of every fused head
+                d = l.args
+                hw = d.N * d.H * d.W
+                cs = sum(d.cout[i] for i in range(d.nheads))
+                flops += 2.0 * hw * (9 * 64 * 256 * d.nheads + 256 * cs)
+                bytes_ += 4.0 * (64 * hw + cs * hw + 9 * 64 * 256 * d.nheads)
             elif kind == 'conv':
                 d = l.args
                 pad = d.ks // 2
@@ -338,7 +346,7 @@ def main():
                                        'algorithmic_bytes_per_launch': round(d['bytes'] / nl)}}
             c = st['conv']
             ctf = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            out['roofline_conv'] = {'kernel': 'conv_mfma_kernel (%d dense conv launches)' % c['launches'], 'bound': 'mfma',
+            out['roofline_conv'] = {'kernel': 'conv_mfma / wino_conv kernels (%d dense conv launches incl. the fused heads)' % c['launches'], 'bound': 'mfma',
                                     'achieved': round(ctf, 3), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
                                     'frac': round(ctf / PEAK_FP32_TFLOPS, 4), 'total_ms': round(c['ms'], 4)}
             out['roofline']['total_ms'] = round(d['ms'], 4)

@@ -55,6 +55,20 @@ class DcnDesc(ctypes.Structure):
                 ('up_y', ctypes.c_void_p), ('up_ldy', ctypes.c_int)]
 
 
+CT_MAX_FUSED_HEADS = 8
+
+
+class HeadsDesc(ctypes.Structure):
+    _fields_ = [('x', ctypes.c_void_p), ('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int),
+                ('Cin', ctypes.c_int), ('ldx', ctypes.c_int),
+                ('w0_winograd', ctypes.c_void_p), ('b0', ctypes.c_void_p), ('nheads', ctypes.c_int),
+                ('w2', ctypes.c_void_p), ('b2', ctypes.c_void_p),
+                ('cout', ctypes.c_int * CT_MAX_FUSED_HEADS), ('coff', ctypes.c_int * CT_MAX_FUSED_HEADS),
+                ('out', ctypes.c_void_p), ('ctot', ctypes.c_int),
+                ('sig_lo', ctypes.c_int), ('sig_hi', ctypes.c_int), ('dep_lo', ctypes.c_int), ('dep_hi', ctypes.c_int),
+                ('depth_scale', ctypes.c_float)]
+
+
 class DecodeDesc(ctypes.Structure):
     _fields_ = [('hm', ctypes.c_void_p), ('B', ctypes.c_int), ('C', ctypes.c_int), ('h', ctypes.c_int),
                 ('w', ctypes.c_int), ('K', ctypes.c_int),
@@ -98,7 +112,7 @@ class Track(ctypes.Structure):
 
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
-           'ct_conv2d_workspace_bytes', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_stem_forward',
+           'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_decode_pose_workspace_bytes',
            'ct_decode_pose', 'ct_render_pre_hm',
@@ -138,6 +152,7 @@ def load():
     lib.ct_conv2d.argtypes = [ctypes.POINTER(ConvDesc), p]
     lib.ct_conv2d_workspace_bytes.restype = sz
     lib.ct_conv2d_workspace_bytes.argtypes = [ctypes.POINTER(ConvDesc)]
+    lib.ct_heads_fused.argtypes = [ctypes.POINTER(HeadsDesc), p]
     lib.ct_dcn_v2.argtypes = [ctypes.POINTER(DcnDesc), p]
     lib.ct_dcn_v2_workspace_bytes.restype = sz
     lib.ct_dcn_v2_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]

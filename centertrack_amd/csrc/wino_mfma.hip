@@ -28,6 +28,13 @@ struct WinoArgs {
     int NT;                   // CoutPad / 16
     int nchunks;              // Cin / 64
     EpiArgs epi;
+    // HEADS instances (ct_heads_fused): the workgroup's 256 couts are the hidden layer of head `cb`; its 1x1 output
+    // layer is applied in the epilogue and only the head's <= 8 channels are written (NCHW)
+    const float *hw2;         // [heads][8][256] output-layer weights (rows past the head's channels: zero)
+    const float *hb2;         // [heads][8]
+    float *hout;              // [N, hctot, H, W]
+    int hctot;
+    int hcout[CT_MAX_FUSED_HEADS], hcoff[CT_MAX_FUSED_HEADS];
 };
 
 // WM = m-tiles (blocks of 4 x 16 output pixels = 16 Winograd tiles) stacked vertically per workgroup
@@ -57,13 +64,20 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 // same pixel tile.  The patch is staged and input-transformed ONCE (the 16 transformed fragments of a lane stay
 // in 64 VGPRs), every further block costs only its B loads, MFMAs and output transform -- for a short-K layer
 // like the heads conv (64 -> 1280) the per-block VALU work drops from ~6 to ~3 instructions per MFMA.
-template <int WM, int WN, int KS, bool MULTI, int NB = 1>
+// HEADS (NB = 8, 32 couts per block: one workgroup = 64 pixels x the 256 hidden channels of ONE head, base_model.py:
+// 24-65): conv3x3 + bias + ReLU never leaves the workgroup -- every lane multiplies the 4 hidden channels it holds
+// after the output transform with the head's 1x1 weights (kept in LDS) and accumulates <= 8 output channels per
+// pixel over the 8 blocks; the partial sums of the 4 channel quads (lanes) and the 2 n-tiles (waves) are added in a
+// fixed order, then bias, sigmoid / depth transform (detector.py:300-308) and ONE NCHW store per output value.  The
+// 256-channel intermediate (84 MB per frame at 512x512 with 5 heads) is neither written nor read back.
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 // (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
 __global__ __launch_bounds__(256 * KS)
 __attribute__((amdgpu_waves_per_eu(NB > 1 ? 3 : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
 void wino_conv_kernel(WinoArgs a)
 {
     static_assert(NB == 1 || (!MULTI && KS == 1), "NB > 1 is a single-chunk, unsplit shape");
+    static_assert(!HEADS || (NB == 8 && WM == 1 && WN == 2), "the fused heads run on 64 px x 8 blocks of 32 couts");
     using C = WCfg<WM>;
     constexpr int NTHR = 256 * KS;
     constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS;
@@ -144,6 +158,15 @@ void wino_conv_kernel(WinoArgs a)
     float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
     constexpr int TN = WM * WN;
     float *ybuf = lds + KS * 4 * 2 * TN * 256;      // per-wave 32 x 16 transpose slabs behind the exchange buffer
+    float *w2l = ybuf + 4 * KS * 32 * 16;           // HEADS: the head's [8][256] output-layer weights ...
+    float *hred = w2l + 8 * 256;                    // ... and the n-tile-1 waves' partial sums [2][64][2][8]
+    float hacc[HEADS ? 2 : 1][HEADS ? 8 : 1];       // HEADS: output channels of this lane's two pixels, its 4-channel quads
+    if (HEADS) {
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) hacc[h2][j] = 0.0f;
+    }
     const bool wide = (a.epi.Cout % 4 == 0) && (a.epi.ldy % 4 == 0) && (!a.epi.res || a.epi.ldr % 4 == 0) &&
                       (((uintptr_t)a.epi.y & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
     const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
@@ -174,6 +197,11 @@ void wino_conv_kernel(WinoArgs a)
 #pragma unroll
         for (int kk = 0; kk < (NB > 1 ? 4 : 1); ++kk) transform(vall[kk], lds, kk);
         __syncthreads();                            // the patch is dead from here on: its LDS becomes the exchange buffer
+        if (HEADS) {                                // (visible to every wave after the first block's exchange barrier)
+            const float *src = a.hw2 + (size_t)cb * 2048;
+            *reinterpret_cast<f32x4 *>(w2l + tid * 4) = *reinterpret_cast<const f32x4 *>(src + tid * 4);
+            *reinterpret_cast<f32x4 *>(w2l + 1024 + tid * 4) = *reinterpret_cast<const f32x4 *>(src + 1024 + tid * 4);
+        }
     }
 
 #pragma unroll 1
@@ -287,7 +315,33 @@ void wino_conv_kernel(WinoArgs a)
             const f32x4 y0 = t[0] + t[1] + t[2];
             const f32x4 y1 = t[1] - t[2] - t[3];
             const int co = (nt0 + nt) * 16 + li;
-            if (wide) {
+            if (HEADS) {
+                float *yb = ybuf + wv * (32 * 16);
+#pragma unroll
+                for (int ee = 0; ee < 4; ++ee) {
+                    const int tile = lg * 4 + ee;
+                    yb[(tile * 2 + 0) * 16 + li] = y0[ee];
+                    yb[(tile * 2 + 1) * 16 + li] = y1[ee];
+                }
+                __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+#pragma unroll
+                for (int h2 = 0; h2 < 2; ++h2) {
+                    const int item = lane + 64 * h2;              // (tile*2 + p) * 4 + cout quad
+                    const int cq = item & 3, tp = item >> 2;
+                    const int c4 = (nt0 + nt) * 16 + cq * 4;      // hidden channel (global); local = c4 - cb * 256
+                    const f32x4 raw = *reinterpret_cast<const f32x4 *>(yb + tp * 16 + cq * 4);
+                    const f32x4 sh4 = *reinterpret_cast<const f32x4 *>(a.epi.shift + c4);
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = fmaxf(raw[i] + sh4[i], 0.0f);      // + bias, ReLU
+                    const float *wrow = w2l + (c4 - cb * 256);
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const f32x4 w = *reinterpret_cast<const f32x4 *>(wrow + j * 256);
+                        hacc[h2][j] += (o[0] * w[0] + o[1] * w[1]) + (o[2] * w[2] + o[3] * w[3]);
+                    }
+                }
+            } else if (wide) {
                 // 32 pixels x 16 couts of this job: transpose through this wave's private LDS slab so that a lane
                 // stores 4 consecutive couts of one pixel as ONE 16-byte store (the epilogue of a short-K layer
                 // like the heads conv is store-issue bound: 8 dword stores per lane become 2 dwordx4 stores)
@@ -342,6 +396,45 @@ void wino_conv_kernel(WinoArgs a)
     }
     if (NB > 1) __syncthreads();                    // every job has read the exchange buffer: the next block may overwrite it
     }                                               // (cout block nb)
+    if (HEADS) {
+        // wave wv handled (q = wv & 1, n-tile wv >> 1) of every block; lane: pixels tp = (lane + 64 h2) >> 2, quad lane & 3
+        const int q = wv & 1, ntile = wv >> 1;
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float v = hacc[h2][j];
+                v += __shfl_xor(v, 1);              // the 4 channel quads of a pixel sit in 4 neighbouring lanes
+                v += __shfl_xor(v, 2);
+                hacc[h2][j] = v;
+            }
+        if (ntile == 1) {
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) hred[((q * 64 + lane) * 2 + h2) * 8 + j] = hacc[h2][j];
+        }
+        __syncthreads();
+        if (ntile == 0 && (lane & 3) == 0) {
+            const int hc = a.hcout[cb], g0 = a.hcoff[cb];
+#pragma unroll
+            for (int h2 = 0; h2 < 2; ++h2) {
+                const int tp = (lane + 64 * h2) >> 2;
+                const int tile = tp >> 1, pp = tp & 1;
+                const int oy = oy0 + 2 * (tile >> 3) + pp;
+                const int ox = ox0 + 2 * (tile & 7) + q;
+                if (oy >= a.epi.Ho || ox >= a.epi.Wo) continue;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    if (j >= hc) break;
+                    const int gc = g0 + j;
+                    const float v = (hacc[h2][j] + hred[((q * 64 + lane) * 2 + h2) * 8 + j]) + a.hb2[cb * 8 + j];
+                    a.hout[(((size_t)n * a.hctot + gc) * a.epi.Ho + oy) * a.epi.Wo + ox] =
+                        ct_epilogue_value(a.epi, v, gc, 1.0f, 0.0f, 0.0f);
+                }
+            }
+        }
+    }
 }
 
 // U[pos][co][ci] = (G g G^T)[r][c], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -367,13 +460,13 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, floa
     p[idx] = u;
 }
 
-template <int WM, int WN, int KS, bool MULTI, int NB = 1>
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
     using C = WCfg<WM>;
-    auto k = wino_conv_kernel<WM, WN, KS, MULTI, NB>;
+    auto k = wino_conv_kernel<WM, WN, KS, MULTI, NB, HEADS>;
     const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
-    const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256 + 4 * KS * 32 * 16);
+    const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256 + 4 * KS * 32 * 16 + (HEADS ? 8 * 256 + 2 * 64 * 2 * 8 : 0));
     const size_t lds = patch > exch ? patch : exch;
     static bool attr_set = false;
     if (!attr_set) {
@@ -447,5 +540,38 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     default: rc = launch_wino<1, 1, 4>(a, grid, st); break;
     }
     CT_CHECK_LAUNCH("ct_conv2d(winograd)");
+    return rc;
+}
+
+// The heads of the network in one launch (ct_heads_desc): conv3x3 64 -> 256 + bias + ReLU -> conv1x1 256 -> c + bias (+ the
+// sigmoid / depth transform) for every listed head
+extern "C" int ct_heads_fused(const ct_heads_desc *d, void *stream)
+{
+    if (!d || !d->x || !d->w0_winograd || !d->b0 || !d->w2 || !d->b2 || !d->out) CT_FAIL_ARG("ct_heads_fused: null pointer");
+    if (d->Cin != 64) CT_FAIL_ARG("ct_heads_fused: the heads read a 64-channel feature map (got %d)", d->Cin);
+    if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_heads_fused: input view must be 16-byte aligned");
+    if (d->nheads < 1 || d->nheads > CT_MAX_FUSED_HEADS) CT_FAIL_ARG("ct_heads_fused: 1..%d heads", CT_MAX_FUSED_HEADS);
+    if (d->N <= 0 || d->H <= 0 || d->W <= 0 || d->ctot <= 0) CT_FAIL_ARG("ct_heads_fused: bad shape");
+    if (((uintptr_t)d->b0 & 15) || ((uintptr_t)d->w2 & 15)) CT_FAIL_ARG("ct_heads_fused: b0 / w2 must be 16-byte aligned");
+    WinoArgs a;
+    a.x = d->x; a.up = d->w0_winograd;
+    a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = 64; a.ldx = d->ldx;
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.coutBlocks = d->nheads; a.xcdPer = 0;
+    a.NT = d->nheads * 16; a.nchunks = 1;
+    a.epi.scale = nullptr; a.epi.shift = d->b0; a.epi.res = nullptr; a.epi.y = nullptr;
+    a.epi.ldr = 0; a.epi.ldy = 0; a.epi.Cout = d->nheads * 256; a.epi.Ho = d->H; a.epi.Wo = d->W;
+    a.epi.flags = 0; a.epi.sig_lo = d->sig_lo; a.epi.sig_hi = d->sig_hi; a.epi.dep_lo = d->dep_lo; a.epi.dep_hi = d->dep_hi;
+    a.epi.depth_scale = d->depth_scale;
+    a.hw2 = d->w2; a.hb2 = d->b2; a.hout = d->out; a.hctot = d->ctot;
+    for (int i = 0; i < CT_MAX_FUSED_HEADS; ++i) { a.hcout[i] = 0; a.hcoff[i] = 0; }
+    for (int i = 0; i < d->nheads; ++i) {
+        if (d->cout[i] < 1 || d->cout[i] > 8 || d->coff[i] < 0 || d->coff[i] + d->cout[i] > d->ctot)
+            CT_FAIL_ARG("ct_heads_fused: head %d: 1..8 channels inside [0, ctot)", i);
+        a.hcout[i] = d->cout[i]; a.hcoff[i] = d->coff[i];
+    }
+    const long blocks = (long)d->N * a.tilesX * a.tilesY * a.coutBlocks;
+    if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_heads_fused: grid too large");
+    const int rc = launch_wino2<1, 2, 1, false, 8, true>(a, dim3((unsigned)blocks), (hipStream_t)stream);
+    CT_CHECK_LAUNCH("ct_heads_fused");
     return rc;
 }

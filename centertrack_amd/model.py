@@ -22,6 +22,7 @@ from .weights import CHANNELS, LEVELS, dla34_param_shapes
 BN_EPS = 1e-5
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
+FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
 
 
 def _fold_bn(sd, p):
@@ -162,6 +163,28 @@ class DLASegHIP(torch.nn.Module):
                 P['%s.proj_%d' % (p, k)] = deform('%s.proj_%d' % (p, k))
                 P['%s.node_%d' % (p, k)] = deform('%s.node_%d' % (p, k))
                 P['%s.up_%d' % (p, k)] = ops.upsample_weight(sd['%s.up_%d.weight' % (p, k)])
+        # heads with <= 8 output channels: ONE launch for conv3x3 + ReLU + conv1x1 of all of them (ct_heads_fused)
+        hc = self.head_conv
+        small = [h for h, c in self.heads.items() if c <= 8] if (FUSE_HEADS and WINOGRAD and hc == 256) else []
+        small = small[:_lib.CT_MAX_FUSED_HEADS]
+        P['heads_small'] = small
+        if small:
+            w0s = torch.cat([sd[h + '.0.weight'] for h in small], 0)
+            w2s = torch.zeros((len(small), 8, hc), device=dev)
+            b2s = torch.zeros((len(small), 8), device=dev)
+            for i, h in enumerate(small):
+                c = self.heads[h]
+                w2s[i, :c] = sd[h + '.2.weight'].reshape(c, hc)
+                b2s[i, :c] = sd[h + '.2.bias']
+            P['hs_w0'] = ops.pack_winograd(w0s)
+            P['hs_b0'] = torch.cat([sd[h + '.0.bias'] for h in small], 0).contiguous()
+            P['hs_w2'], P['hs_b2'] = w2s.contiguous(), b2s.contiguous()
+        big = [h for h in self.heads if h not in small]
+        P['heads_big'] = big
+        if small and big:                  # the remaining (wide) heads keep the two-launch form on their own channels
+            w0b = torch.cat([sd[h + '.0.weight'] for h in big], 0)
+            P['hb_w'], P['hb_ww'] = ops.pack_weight(w0b), wino(w0b)
+            P['hb_b'] = torch.cat([sd[h + '.0.bias'] for h in big], 0).contiguous()
         # heads: all first layers share their input -> one 64 -> 256*nh conv
         w0 = torch.cat([sd[h + '.0.weight'] for h in self.heads], 0)
         P['head0_w'] = ops.pack_weight(w0)
@@ -297,47 +320,51 @@ class DLASegHIP(torch.nn.Module):
         plan['dcn_layers'] = {ly.name: (ly.up[3] if ly.up is not None else ly.out) for ly in dcn_layers}   # name -> result view
         L.extend(dcn_launches)
 
-        nh = len(self.heads)
-        hc = self.head_conv
-        mid = alloc(feat.H, feat.W, hc * nh)
-        d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid,
-                               w_wino=P['head0_ww'])
-        us = autotune.tune_conv(d, dev)[2] if tune else 200.0
-        L.append(_Launch('heads.0', 'conv', d, (feat, mid), reads=(feat,), writes=(mid,), us=us,
-                         ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-        ctot = sum(self.heads.values())
-        comb = torch.empty((N, ctot, feat.H, feat.W), device=dev)
-        sig, dep = (0, 0), (0, 0)
-        c0 = 0
-        outputs = OrderedDict()
-        for hname, c in self.heads.items():
-            if fuse_sigmoid and hname == 'hm':                 # (hm_hp -> per-head tail below: one sigmoid range per launch)
-                sig = (c0, c0 + c)
-            if fuse_sigmoid and hname == 'dep':
-                dep = (c0, c0 + c)
-            outputs[hname] = comb[:, c0:c0 + c]            # channel-slice views of the combined tensor
-            c0 += c
-        if ctot <= 32 and 'hm_hp' not in self.heads:
-            # few output channels (MOT 11, KITTI 9, nuScenes 30): one block-diagonal conv over the whole intermediate
-            d = ops.make_conv_desc(mid, P['head2_w'], ctot, 1, 1, shift=P['head2_b'], out_nchw=comb, sig=sig, dep=dep,
-                                   depth_scale=self.depth_scale)
-            us = autotune.tune_conv(d, dev)[2] if tune else 20.0
-            L.append(_Launch('heads.2', 'conv', d, (mid, comb), reads=(mid,), writes=(comb,), us=us,
-                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+        small, big = P['heads_small'], P['heads_big']
+        if small:
+            outputs = self._plan_heads_fused(plan, L, P, feat, N, dev, tune, fuse_sigmoid, small, big)
         else:
-            # a wide head (COCO: 80 classes): the block-diagonal form would multiply its flops by the number of heads
+            nh = len(self.heads)
+            hc = self.head_conv
+            mid = alloc(feat.H, feat.W, hc * nh)
+            d = ops.make_conv_desc(feat, P['head0_w'], hc * nh, 3, 1, shift=P['head0_b'], relu=True, out=mid,
+                                   w_wino=P['head0_ww'])
+            us = autotune.tune_conv(d, dev)[2] if tune else 200.0
+            L.append(_Launch('heads.0', 'conv', d, (feat, mid), reads=(feat,), writes=(mid,), us=us,
+                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            ctot = sum(self.heads.values())
+            comb = torch.empty((N, ctot, feat.H, feat.W), device=dev)
+            sig, dep = (0, 0), (0, 0)
+            c0 = 0
             outputs = OrderedDict()
-            for j, (hname, c) in enumerate(self.heads.items()):
-                o = torch.empty((N, c, feat.H, feat.W), device=dev)
-                wp, b = P[hname + '.2']
-                hsig = (0, c) if (fuse_sigmoid and hname in ('hm', 'hm_hp')) else (0, 0)   # detector.py:300-304
-                hdep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
-                d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=hsig, dep=hdep,
+            for hname, c in self.heads.items():
+                if fuse_sigmoid and hname == 'hm':                 # (hm_hp -> per-head tail below: one sigmoid range per launch)
+                    sig = (c0, c0 + c)
+                if fuse_sigmoid and hname == 'dep':
+                    dep = (c0, c0 + c)
+                outputs[hname] = comb[:, c0:c0 + c]            # channel-slice views of the combined tensor
+                c0 += c
+            if ctot <= 32 and 'hm_hp' not in self.heads:
+                # few output channels (MOT 11, KITTI 9, nuScenes 30): one block-diagonal conv over the whole intermediate
+                d = ops.make_conv_desc(mid, P['head2_w'], ctot, 1, 1, shift=P['head2_b'], out_nchw=comb, sig=sig, dep=dep,
                                        depth_scale=self.depth_scale)
-                us = autotune.tune_conv(d, dev)[2] if tune else 7.0
-                L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o), reads=(mid.slice(hc * j, hc),), writes=(o,),
-                                 us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-                outputs[hname] = o
+                us = autotune.tune_conv(d, dev)[2] if tune else 20.0
+                L.append(_Launch('heads.2', 'conv', d, (mid, comb), reads=(mid,), writes=(comb,), us=us,
+                                 ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            else:
+                # a wide head (COCO: 80 classes): the block-diagonal form would multiply its flops by the number of heads
+                outputs = OrderedDict()
+                for j, (hname, c) in enumerate(self.heads.items()):
+                    o = torch.empty((N, c, feat.H, feat.W), device=dev)
+                    wp, b = P[hname + '.2']
+                    hsig = (0, c) if (fuse_sigmoid and hname in ('hm', 'hm_hp')) else (0, 0)   # detector.py:300-304
+                    hdep = (0, c) if (fuse_sigmoid and hname == 'dep') else (0, 0)
+                    d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=hsig, dep=hdep,
+                                           depth_scale=self.depth_scale)
+                    us = autotune.tune_conv(d, dev)[2] if tune else 7.0
+                    L.append(_Launch('heads.%s.2' % hname, 'conv', d, (mid, o), reads=(mid.slice(hc * j, hc),), writes=(o,),
+                                     us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+                    outputs[hname] = o
         plan['outputs'] = outputs
         # split-K partials of the dense convs: one workspace shared by all of them (the launches of a frame are
         # sequential); every DCN layer owns its workspace (the layers of a group run concurrently)
@@ -349,6 +376,50 @@ class DLASegHIP(torch.nn.Module):
                 l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         plan['ws_need'] = ws.numel() * 4
         return plan
+
+    def _plan_heads_fused(self, plan, L, P, feat, N, dev, tune, fuse_sigmoid, small, big):
+        """Heads (base_model.py:24-65,86-90): every head with <= 8 output channels in ONE ct_heads_fused launch (hidden
+        256-channel maps stay in the workgroups); wider heads (80-class hm, hps, hm_hp) as conv3x3 + per-head conv1x1."""
+        lib = _lib.load()
+        hc = self.head_conv
+        outputs = {}
+        ctot = sum(self.heads[h] for h in small)
+        comb = torch.empty((N, ctot, feat.H, feat.W), device=dev)
+        hd = _lib.HeadsDesc()
+        hd.x, hd.N, hd.H, hd.W, hd.Cin, hd.ldx = feat.ptr, N, feat.H, feat.W, feat.C, feat.ld
+        hd.w0_winograd, hd.b0, hd.nheads = P['hs_w0'].data_ptr(), P['hs_b0'].data_ptr(), len(small)
+        hd.w2, hd.b2, hd.out, hd.ctot = P['hs_w2'].data_ptr(), P['hs_b2'].data_ptr(), comb.data_ptr(), ctot
+        hd.depth_scale = self.depth_scale
+        c0 = 0
+        for i, h in enumerate(small):
+            c = self.heads[h]
+            hd.cout[i], hd.coff[i] = c, c0
+            if fuse_sigmoid and h == 'hm':
+                hd.sig_lo, hd.sig_hi = c0, c0 + c
+            if fuse_sigmoid and h == 'dep':
+                hd.dep_lo, hd.dep_hi = c0, c0 + c
+            outputs[h] = comb[:, c0:c0 + c]
+            c0 += c
+        L.append(_Launch('heads.fused[%s]' % ' + '.join(small), 'heads', hd, (feat, comb, P['hs_w0'], P['hs_b0'], P['hs_w2'], P['hs_b2']),
+                         us=100.0))
+        if big:
+            mid = ops.new_view(N, feat.H, feat.W, hc * len(big), dev)
+            d = ops.make_conv_desc(feat, P['hb_w'], hc * len(big), 3, 1, shift=P['hb_b'], relu=True, out=mid, w_wino=P['hb_ww'])
+            us = autotune.tune_conv(d, dev)[2] if tune else 100.0
+            L.append(_Launch('heads.0', 'conv', d, (feat, mid), us=us, ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            for j, h in enumerate(big):
+                c = self.heads[h]
+                o = torch.empty((N, c, feat.H, feat.W), device=dev)
+                wp, b = P[h + '.2']
+                hsig = (0, c) if (fuse_sigmoid and h in ('hm', 'hm_hp')) else (0, 0)       # detector.py:300-304
+                hdep = (0, c) if (fuse_sigmoid and h == 'dep') else (0, 0)
+                d = ops.make_conv_desc(mid.slice(hc * j, hc), wp, c, 1, 1, shift=b, out_nchw=o, sig=hsig, dep=hdep,
+                                       depth_scale=self.depth_scale)
+                us = autotune.tune_conv(d, dev)[2] if tune else 7.0
+                L.append(_Launch('heads.%s.2' % h, 'conv', d, (mid, o), us=us,
+                                 ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+                outputs[h] = o
+        return OrderedDict((h, outputs[h]) for h in self.heads)
 
     def _run_plan(self, plan, inputs=None):
         """Enqueue every launch of the plan on the current stream.  ``inputs`` = (x, pre_img, pre_hm) tensors to read
@@ -363,6 +434,8 @@ class DLASegHIP(torch.nn.Module):
             elif l.fn == 'dcn_group':
                 arr, n, phases = l.args
                 rc = lib.ct_dcn_v2_group(arr, n, phases, st)
+            elif l.fn == 'heads':
+                rc = lib.ct_heads_fused(ctypes.byref(l.args), st)
             elif l.fn == 'pool':
                 x, y = l.args
                 rc = lib.ct_maxpool2x2(x.ptr, x.N, x.H, x.W, x.C, x.ld, y.ptr, y.ld, st)

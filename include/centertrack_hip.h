@@ -91,6 +91,27 @@ typedef struct ct_conv_desc {
 int ct_conv2d(const ct_conv_desc *d, void *stream);
 size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);
 
+/* ---- the heads of the network, fused ------------------------------------------------------------------
+ * Replaces the per-head nn.Sequential(conv3x3 64 -> 256 + bias, ReLU, conv1x1 256 -> c + bias) of BaseModel
+ * (src/lib/model/networks/base_model.py:24-65,86-90) for every listed head, with Detector._sigmoid_output
+ * (src/lib/detector.py:300-308) on the channels [sig_lo,sig_hi) / [dep_lo,dep_hi) of `out`, in ONE launch: the
+ * 256-channel hidden maps (16.8 MB per head and frame at 512x512) stay inside the workgroups.  x: NHWC feature map
+ * (64 channels, pitch ldx); w0_winograd: ct_pack_winograd_weight() of the heads' first-layer weights concatenated
+ * along Cout ([nheads*256, 64, 3, 3]); b0 [nheads*256]; w2 [nheads][8][256] = the heads' 1x1 weights, rows >= cout[i]
+ * zero; b2 [nheads][8]; head i writes channels coff[i] .. coff[i]+cout[i]-1 of out (NCHW [N, ctot, H, W]).  Heads
+ * with more than 8 output channels (hm of an 80-class model, hps, hm_hp) go through ct_conv2d. */
+#define CT_MAX_FUSED_HEADS 8
+typedef struct ct_heads_desc {
+    const float *x; int N, H, W, Cin, ldx;
+    const float *w0_winograd; const float *b0;
+    int nheads;
+    const float *w2; const float *b2;
+    int cout[CT_MAX_FUSED_HEADS], coff[CT_MAX_FUSED_HEADS];
+    float *out; int ctot;
+    int sig_lo, sig_hi, dep_lo, dep_hi; float depth_scale;
+} ct_heads_desc;
+int ct_heads_fused(const ct_heads_desc *d, void *stream);
+
 /* ---- modulated deformable convolution v2 (3x3, stride 1, pad 1, dil 1, dg 1) -------
  * Replaces DCNv2's _ext.dcn_v2_forward (modulated_deformable_im2col + SGEMM; upstream
  * src/cuda/dcn_v2_cuda.cu, dcn_v2_im2col_cuda.cu) as called from DeformConv.forward,

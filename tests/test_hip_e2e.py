@@ -201,7 +201,7 @@ def test_pose_tracking_stream_matches_oracle(device, flip):
     model = DLASegHIP(heads)
     model.load_state_dict(sd)
     det = Detector(opt, model=model)
-    assert not det.impl.native                                        # key points ride on the Python host path
+    assert det.impl.native                                            # the pose task runs on the native host path too
     oopt = odet.default_opt(track_thresh=0.3, flip_test=flip, input_h=64, input_w=96, num_classes=1)
     oracle = odet.Detector(oopt, sd, heads)
     meta = make_meta(64, 96, 480, 720)

@@ -752,3 +752,53 @@ def test_flip_images_mirrors_rows(device, W):
     _lib.check(_lib.load().ct_flip_images(x.data_ptr(), y.data_ptr(), 2 * 3 * 9, W, _lib.stream_ptr()))
     torch.cuda.synchronize()
     assert torch.equal(y.cpu(), torch.flip(x.cpu(), [3]))
+
+
+@pytest.mark.parametrize('N,H,W,heads,sig,dep', [
+    (1, 12, 24, [('hm', 1), ('reg', 2), ('wh', 2), ('tracking', 2), ('ltrb_amodal', 4)], 'hm', None),
+    (2, 9, 19, [('hm', 3), ('dep', 1), ('rot', 8), ('dim', 3)], 'hm', 'dep'),        # ragged tiles, an 8-channel head
+    (1, 16, 16, [('wh', 2)], None, None)])
+def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
+    """ct_heads_fused: conv3x3 64 -> 256 + bias + ReLU + conv1x1 256 -> c + bias (+ sigmoid / depth transform) of several
+    heads in one launch == the torch fp32 reference of base_model.py:24-65 + detector.py:300-308"""
+    import ctypes
+    from centertrack_amd import _lib, ops
+    x = F.relu(_rand(N, 64, H, W, seed=200))
+    nh = len(heads)
+    w0 = [_rand(256, 64, 3, 3, seed=210 + i, scale=(64 * 9) ** -0.5) for i in range(nh)]
+    b0 = [_rand(256, seed=220 + i, scale=0.2) for i in range(nh)]
+    w2 = [_rand(c, 256, 1, 1, seed=230 + i, scale=256 ** -0.5) for i, (_, c) in enumerate(heads)]
+    b2 = [_rand(c, seed=240 + i) for i, (_, c) in enumerate(heads)]
+    want = []
+    for i, (name, c) in enumerate(heads):
+        y = F.conv2d(F.relu(F.conv2d(x, w0[i], b0[i], padding=1)), w2[i], b2[i])
+        if name == sig:
+            y = torch.sigmoid(y)
+        if name == dep:
+            y = (1. / (torch.sigmoid(y) + 1e-6) - 1.) * 2.0
+        want.append(y)
+    want = torch.cat(want, 1)
+    ctot = want.shape[1]
+    xv = ops.view_from_nchw(x.to(device))
+    w0p = ops.pack_winograd(torch.cat(w0, 0).to(device))
+    b0d = torch.cat(b0, 0).to(device)
+    w2d = torch.zeros((nh, 8, 256), device=device)
+    b2d = torch.zeros((nh, 8), device=device)
+    out = torch.full((N, ctot, H, W), float('nan'), device=device)
+    hd = _lib.HeadsDesc()
+    hd.x, hd.N, hd.H, hd.W, hd.Cin, hd.ldx = xv.ptr, N, H, W, 64, xv.ld
+    hd.w0_winograd, hd.b0, hd.nheads = w0p.data_ptr(), b0d.data_ptr(), nh
+    c0 = 0
+    for i, (name, c) in enumerate(heads):
+        w2d[i, :c] = w2[i].reshape(c, 256).to(device)
+        b2d[i, :c] = b2[i].to(device)
+        hd.cout[i], hd.coff[i] = c, c0
+        if name == sig:
+            hd.sig_lo, hd.sig_hi = c0, c0 + c
+        if name == dep:
+            hd.dep_lo, hd.dep_hi = c0, c0 + c
+        c0 += c
+    hd.w2, hd.b2, hd.out, hd.ctot, hd.depth_scale = w2d.data_ptr(), b2d.data_ptr(), out.data_ptr(), ctot, 2.0
+    _lib.check(_lib.load().ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()), 'ct_heads_fused')
+    torch.cuda.synchronize()
+    _close(out, want, atol=5e-4, rtol=2e-4, msg='fused heads')       # (Winograd tolerance of this suite)
