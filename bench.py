@@ -9,7 +9,9 @@ The metric is SURVEY.md section 8(d)'s: the end-to-end ``Detector.run`` equivale
 **H2D of a ready fp32 frame (pinned host memory, src/lib/detector.py:93-94)** -> three stems +
 DLA-34 + 16 DCNv2 nodes + heads (fp32, sigmoid fused) -> NMS / top-K / gather decode -> one
 packed D2H -> host post-process -> track association (and, for N > 1, the RCCL all-gather of
-the packed detections).  The H2D is INSIDE the timed step; the rate with frames already
+the packed detections).  The H2D is INSIDE the timed region -- every frame is uploaded, the upload
+of frame t+1 being enqueued on a second stream while frame t is computed, as the reference's
+pinned DataLoader + non_blocking copy does (test.py:74-76) -- and the rate with frames already
 resident in HBM is reported next to it (``resident_frames_fps``), never as ``value``.
 
 A "step" is one clip: ``frames_per_step`` consecutive frames of every stream the rank owns
@@ -296,14 +298,14 @@ def main():
         'vs_baseline': None, 'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': '%s: %s heads, DLA-34, %dx%d, %d stream(s)/GPU, K=%d, flip_test=%s, seeded random-init '
                                'weights; one step = %d consecutive frames of every stream, each frame uploaded from '
-                               'pinned host memory inside the step' % (args.config, cfg['heads'], cfg['H'], cfg['W'], B,
+                               'pinned host memory inside the step (frame t+1 on a copy stream while frame t runs)' % (args.config, cfg['heads'], cfg['H'], cfg['W'], B,
                                                                       opt.K, cfg['flip'], fps_step),
                    'global_batch': total_streams, 'frames_per_step': fps_step,
                    'parallelism': 'streams sharded dp%d, all-gather of packed detections' % world,
                    'hip_graph': det._ctx['graph'] is not None,
                    'mean_detections_per_frame': round(ndet / max(1, nfr * B), 1)},
         'fps_per_gpu': round(fps / world, 2), 'ms_per_frame_batch': round(1000.0 * dt / max(1, nfr), 4),
-        'timed_region_s': round(dt, 3), 'h2d_in_timed_region': True, 'rccl_ranks': rccl_ranks,
+        'timed_region_s': round(dt, 3), 'h2d_in_timed_region': True, 'h2d_overlaps_previous_frame': True, 'rccl_ranks': rccl_ranks,
     }
     if not args.no_resident:
         frames = [f.to(device) for f in frames_cpu]

@@ -127,6 +127,7 @@ class _HipGraph(object):
 
 class StreamDetector(object):
     """B independent streams, one frame each per ``step``."""
+    supports_prefetch = True
 
     def __init__(self, opt, model=None, num_streams=1, use_graph=True, native_host=True):
         if not torch.cuda.is_available():
@@ -153,6 +154,7 @@ class StreamDetector(object):
                                             public_det=getattr(opt, 'public_det', False))
                      for _ in range(self.B)] if self.native else None
         self._last_dets = None
+        self._prefetched = None    # ((host pointer, shape), event) of a frame uploaded ahead by step(prefetch=...)
         self.started = [False] * self.B
         # device-side pre-processing of raw u8 frames (ct_preprocess_device): normalisation table + staging buffers
         lut = np.empty((3, 256), np.float32)
@@ -319,11 +321,16 @@ class StreamDetector(object):
                    'ct_preprocess_device')
 
     # ---- one frame for every stream -------------------------------------------------------
-    def step(self, images, metas, timers=None):
+    def step(self, images, metas, timers=None, prefetch=None):
         """images: float32 [B,3,H,W] (already normalised, like PrefetchDataset hands over), or a list of B raw
         uint8 HxWx3 frames, which are uploaded as bytes and warped / normalised on the device
         (``ct_preprocess_device``, bit-identical to ``Detector.pre_process``);
-        metas: list of B ``meta`` dicts (image.make_meta).  Returns a list of B result lists."""
+        metas: list of B ``meta`` dicts (image.make_meta).  Returns a list of B result lists.
+        ``prefetch``: the float32 host tensor the NEXT call will pass as ``images`` (optional): its H2D copy is enqueued
+        on a second HIP stream as soon as this frame's graph is launched and overlaps with it -- what the reference's
+        ``DataLoader(pin_memory=True)`` + ``images.to(device, non_blocking=True)`` (test.py:74-76, detector.py:93-94) is
+        for; the next call then finds the frame in HBM (a staging buffer: the previous frame must stay intact as
+        ``pre_img`` while this one runs)."""
         opt = self.opt
         t0 = time.time()
         B = self.B
@@ -348,7 +355,16 @@ class StreamDetector(object):
                 images = images[:B]                            # (a pre-flipped batch: the copy is rebuilt on device)
             if tuple(images.shape) != (B, 3, H, W):
                 raise _lib.CTError('step() expects [%d,3,%d,%d] frames, got %s' % (B, H, W, tuple(images.shape)))
-            if images.dtype == torch.float32 and images.is_contiguous():
+            pf = self._prefetched
+            if pf is not None and pf[0] == (images.data_ptr(), tuple(images.shape)):
+                # uploaded by the previous step's ``prefetch`` while that frame was computed: staging -> frame buffer
+                torch.cuda.current_stream().wait_event(pf[1])
+                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), ctx['stage'].data_ptr(), images.numel() * 4, 0,
+                                               _lib.stream_ptr()), 'frame copy')
+                self._prefetched = None
+                ctx['stage_free'] = torch.cuda.Event()         # the staging buffer may be refilled once this copy ran
+                ctx['stage_free'].record(torch.cuda.current_stream())
+            elif images.dtype == torch.float32 and images.is_contiguous():
                 # one DMA from wherever the caller keeps the frame: H2D for a host tensor (detector.py:93-94 -- pinned
                 # memory makes it asynchronous), D2D for a resident one
                 kind = 0 if images.device.type == 'cuda' else 1
@@ -404,6 +420,20 @@ class StreamDetector(object):
             ctx['device_frame'](par)
         if img_in is not None:
             ctx['parity'] ^= 1                                 # this frame is the next step's pre_img
+        if (prefetch is not None and torch.is_tensor(prefetch) and prefetch.device.type == 'cpu'
+                and prefetch.dtype == torch.float32 and prefetch.is_contiguous() and tuple(prefetch.shape) == (B, 3, H, W)):
+            if 'stage' not in ctx:
+                ctx['stage'] = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
+                ctx['copy_stream'] = torch.cuda.Stream(device=self.device)
+                ctx['stage_free'] = None
+            cs = ctx['copy_stream']
+            if ctx['stage_free'] is not None:                  # (the staging buffer was read by the D2D of this step)
+                cs.wait_event(ctx['stage_free'])
+            _lib.check(lib.ct_memcpy_async(ctx['stage'].data_ptr(), prefetch.data_ptr(), prefetch.numel() * 4, 1,
+                                           ctypes.c_void_p(cs.cuda_stream)), 'prefetch')
+            ev = torch.cuda.Event()
+            ev.record(cs)
+            self._prefetched = ((prefetch.data_ptr(), tuple(prefetch.shape)), ev)
         if self.gather_fn is not None:
             self.gather_fn(ctx['decoder'].out)
         if ctx['raw']:                                         # (the D2H of the rows is the graph's last node)

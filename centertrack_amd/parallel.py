@@ -122,9 +122,14 @@ def run_steps(det, frame_of, metas, steps, frames_per_step, first=0):
     inside ``det.step``.  Returns (frames processed per stream, detections returned)."""
     t = first
     ndet = 0
+    ahead = bool(getattr(det, 'supports_prefetch', False))    # upload frame t+1 while frame t is computed
+    last = first + steps * frames_per_step - 1
     for _ in range(steps):
         for _ in range(frames_per_step):
-            res = det.step(frame_of(t), metas)
+            if ahead:
+                res = det.step(frame_of(t), metas, prefetch=frame_of(t + 1) if t < last else None)
+            else:
+                res = det.step(frame_of(t), metas)
             ndet += sum(len(r) for r in res)
             t += 1
     return t - first, ndet

@@ -288,3 +288,27 @@ def test_run_on_an_image_path_equals_run_on_the_decoded_array(device, tmp_path):
         assert len(ra) == len(rb) and len(ra) > 0
         assert [(r['tracking_id'], float(r['score']), list(map(float, r['bbox']))) for r in ra] == \
                [(r['tracking_id'], float(r['score']), list(map(float, r['bbox']))) for r in rb]
+
+
+def test_prefetched_frames_give_the_same_stream(device):
+    """step(prefetch=next frame): the next frame's H2D runs on a second stream during this frame's graph; results are
+    those of plain steps (ids, scores, boxes bit-identical), also when a prefetched frame is NOT the one that comes next"""
+    from centertrack_amd import scenarios as S
+    from centertrack_amd.detector import StreamDetector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    mk = lambda: default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    frames = [(img.pin_memory(), meta) for img, meta in S.e2e_frames(cfg)]
+    a, b = StreamDetector(mk(), model=model), StreamDetector(mk(), model=model)
+    for t, (img, meta) in enumerate(frames):
+        nxt = frames[t + 1][0] if t + 1 < len(frames) else None
+        if t == 1:
+            nxt = frames[0][0]                                  # a wrong guess: the next step must upload its own frame
+        ra = a.step(img, [dict(meta)], prefetch=nxt)[0]
+        rb = b.step(img, [dict(meta)])[0]
+        assert len(ra) == len(rb) > 0
+        for k in ('tracking_id', 'score', 'bbox', 'ct'):
+            np.testing.assert_array_equal(ra[k], rb[k])

@@ -26,7 +26,7 @@ run() {  # config streams
     fi
 }
 for B in 1 8 16 32; do run mot17_512 $B; done
-for B in 1 8 16 32; do run nusc_800x448 $B; done
+for B in 1 4 8 16 32; do run nusc_800x448 $B; done
 run kitti_1280x384 4
 run coco_512 4
 cat $OUT/${TAG}_sweep.jsonl | python -c "
