@@ -59,9 +59,34 @@ struct DcnGroup {
 // NKK = 16-channel slabs per step: 2 (32 channels x 1 tap, 16 * WN MFMAs per wave between barriers) or 4 (64 channels:
 // 32 * WN MFMAs per barrier -- every step pays the same few hundred cycles of LDS round trips, waits and barrier skew, so
 // the matrix pipe's share of a step grows with the work per barrier: measured 47 % busy at 16, 60 % at 32 MFMAs per step).
+#if defined(CT_DCN_STAMPS)
+// tools/dcn_phases.py: per-workgroup phase stamps (debug build only, never part of the shipped library)
+#define CT_STAMP_WORDS 10
+__device__ unsigned long long ct_dcn_stamps[CT_STAMP_WORDS * 8192];
+#define CT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ct_dcn_stamps[blockIdx.x * CT_STAMP_WORDS + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+#define CT_STAMP_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ct_dcn_stamps[blockIdx.x * CT_STAMP_WORDS + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define CT_STAMP_VAL(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ct_dcn_stamps[blockIdx.x * CT_STAMP_WORDS + (i)] = (unsigned long long)(v); } while (0)
+extern "C" int ct_dcn_read_stamps(unsigned long long *host, int nblocks)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ct_dcn_stamps), sizeof(unsigned long long) * CT_STAMP_WORDS * nblocks);
+}
+extern "C" int ct_dcn_clear_stamps(void)
+{
+    void *p = nullptr;
+    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ct_dcn_stamps)) != hipSuccess) return 1;
+    return (int)hipMemset(p, 0, sizeof(unsigned long long) * CT_STAMP_WORDS * 8192);
+}
+#else
+#define CT_STAMP(i)
+#define CT_STAMP_RT(i)
+#define CT_STAMP_VAL(i, v)
+#endif
+
 template <int BM, int WN, bool FUSE, int NKK = 2>
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 {
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
     constexpr int WM = 2;
     constexpr int WGM = BM / 32, WGN = 4 / WGM;
     constexpr int ROWS = BM / 16;
@@ -131,6 +156,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
         __syncthreads();
     }
+    CT_STAMP(2);
     // ---- B fragment addressing (set up first so that the weights of step 0 are in flight while
     //      the sampling table is built) --------------------------------------------------------
     const int li = lane & 15, lg = lane >> 4;
@@ -211,6 +237,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         }
     }
     __syncthreads();
+    CT_STAMP(3);
 
     // ---- gather assignment: thread -> pixel, channel quad, slab(s) ----
     // BM = 64: thread -> (pixel tl>>2, quad tl&3), every slab; BM = 32: (pixel tl>>3, quad tl&3), slabs (tl>>2)&1, +2, ..
@@ -266,45 +293,64 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         gather_load(1, ch, tp);
         gather_store(0, 0);
         __syncthreads();
-        // one step: G(s+2) | M(s) | ST(s+1) | barrier; P = s & 1 is static (loop unrolled by 2)
+        CT_STAMP(4);
+        // one step (P = s & 1 is static, two steps per loop iteration): A fragments of step s (LDS -> VGPR, all of them
+        // up front) | weights of s+1, corners of s+2 (global) | MFMAs of s | blend + LDS store of s+1's tile | barrier
         auto step = [&](auto ptag, int s) {
             constexpr int P = decltype(ptag)::value;
             int c1, t1, c2, t2;
             step_ct(s + 1, c1, t1);
             step_ct(s + 2, c2, t2);
+            f32x4 af[NKK][WM];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+                    af[kk][mt] = *reinterpret_cast<const f32x4 *>(lds_g + P * BUF + kk * SLAB + aoff[mt]);
             load_b(bq[P ^ 1], c1, t1);
             // slot P held step s, already blended into LDS buffer P by the previous iteration
             gather_load(P, c2, t2);
+            // step s+1's A tile (corners loaded one step ago); past the last step this blends the clamped re-fetch
+            // into a buffer nobody reads
+            f32x4 v[GK];
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+                v[kk] = gw[P ^ 1][0] * cv[P ^ 1][kk][0] + gw[P ^ 1][1] * cv[P ^ 1][kk][1] +
+                        gw[P ^ 1][2] * cv[P ^ 1][kk][2] + gw[P ^ 1][3] * cv[P ^ 1][kk][3];
             // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
             // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
-            {
-                const float *buf = lds_g + P * BUF;
 #pragma unroll
-                for (int kk = 0; kk < NKK; ++kk) {
-                    f32x4 af[WM];
+            for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-                    for (int mt = 0; mt < WM; ++mt) af[mt] = *reinterpret_cast<const f32x4 *>(buf + kk * SLAB + aoff[mt]);
+                for (int e = 0; e < 4; ++e)
 #pragma unroll
-                    for (int e = 0; e < 4; ++e)
+                    for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-                        for (int mt = 0; mt < WM; ++mt)
-#pragma unroll
-                            for (int nt = 0; nt < WN; ++nt)
-                                acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], bq[P][kk][nt][e],
-                                                                                  acc[mt][nt], 0, 0, 0);
-                }
-            }
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][mt][e], bq[P][kk][nt][e],
+                                                                              acc[mt][nt], 0, 0, 0);
             __builtin_amdgcn_sched_barrier(0x386);
-            if (s + 1 < nmax) gather_store(P ^ 1, P ^ 1);        // step s+1's A tile (loaded one step ago)
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+                *reinterpret_cast<f32x4 *>(lds_g + (P ^ 1) * BUF + (gk0 + kk * SSTR) * SLAB + lslot) = v[kk];
             __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);                   // (steps are scheduled one by one)
         };
-        for (int s = 0; s < nmax; s += 2) {
+        // Both steps of an iteration sit in ONE basic block and an odd last step is peeled: with a branch between them
+        // (`if (s + 1 < nmax)`) the waitcnt insertion drained every load in flight -- vmcnt(0), the corners of s+1
+        // included -- at the top of every other step.
+        int s = 0;
+        for (; s + 1 < nmax; s += 2) {
             step(std::integral_constant<int, 0>{}, s);
-            if (s + 1 < nmax) step(std::integral_constant<int, 1>{}, s + 1);
+            step(std::integral_constant<int, 1>{}, s + 1);
         }
+        if (s < nmax) step(std::integral_constant<int, 0>{}, s);
     }
 
+    CT_STAMP(5);
+    CT_STAMP_VAL(8, pi);
+    CT_STAMP_VAL(9, nmax);
     if (a.ws) {
         const size_t Mtot = (size_t)a.N * a.H * a.W;
         float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
@@ -330,6 +376,8 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
             for (int nt = 0; nt < WN; ++nt)
                 ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
     }
+    CT_STAMP(6);
+    CT_STAMP_RT(7);
 }
 
 // Measured and dropped in round 2 (tools/kbench.py, profiles/r02_kbench_dcn_*.txt; every variant was parity-green):
@@ -339,6 +387,11 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 //   * gathering the bilinear corners from an LDS-staged window of the input (+-2 px halo, zero-filled border, global
 //     fall-back per wave-step) on 32- and 64-pixel tiles: 4x fewer vector-memory instructions (SQ_INSTS_VMEM_RD 0.51 M
 //     against 2.03 M per launch) and the same 132 us.
+//   * forcing one MFMA / two VALU alternation inside a step (sched_group_barrier; blend of s+1 between the MFMAs of
+//     s): 157-159 us against 113-118 us at 8 streams (VALU between dependent MFMAs costs more than the idle issue
+//     slots it fills), 19.8 against 20.5 us at one stream; A fragments double-buffered in registers (LDS reads of tile
+//     s+1 issued one step early, no LDS round trip between a barrier and the first MFMA): equal to this kernel at
+//     both sizes (tools/kbench.py, libraries built with each variant, same box).
 // PMC of this kernel on that layer: MFMA busy 0.46, 4 waves per SIMD resident, 58 % of the wave cycles in
 // s_waitcnt, 4.1 VALU + 3.7 SALU instructions per MFMA.  A loop of the same MFMAs with LDS fragment reads and a barrier
 // every 16 MFMAs sustains 137-148 TFLOP/s on the same box (tools/micro/mfma_peak.py), so the matrix side is not what

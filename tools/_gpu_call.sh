@@ -1,5 +1,9 @@
 cd $GRAFT_REPO_ROOT
-for nt in "" "--dcn-nt"; do
-python tools/kbench.py --no-conv --reps 10 --batch 8 --off-scale 0.4 $nt 2>&1 | cut -c1-250 | tail -9
-done
-python tools/kbench.py --no-conv --reps 20 --off-scale 0.4 --dcn-nt 2>&1 | cut -c1-250 | tail -9
+D=$PWD/centertrack_amd/build/dbg
+for dv in 32x64/1 4x32x64/1 F32x64/1; do
+for b in 1 8; do
+for v in s0 s3 final; do
+L=$D/libct_$v.so; [ $v = final ] && L=$PWD/centertrack_amd/libcentertrack_hip.so
+echo "== $dv B=$b $v"; CENTERTRACK_LIB=$L python tools/kbench.py --no-conv --batch $b --dvariant $dv 2>&1 | grep "^dcn" | cut -c1-60 | tr '\n' ';' ; echo
+done; done; done
+python tools/dcn_slots.py 2>&1 | tail -17
