@@ -22,7 +22,8 @@ HEAD_CH = {'reg': 2, 'wh': 2, 'tracking': 2, 'ltrb': 4, 'ltrb_amodal': 4, 'dep':
 
 CT_RELU = 1
 CT_OUT_NCHW = 2
-CT_DCN_MAIN, CT_DCN_FINISH = 1, 2
+CT_DCN_MAIN, CT_DCN_FINISH, CT_DCN_OFFSETS = 1, 2, 4
+CT_OK, CT_ERR_ARG, CT_ERR_LAUNCH, CT_ERR_WORKSPACE = 0, 1, 2, 3
 
 
 class ConvDesc(ctypes.Structure):
@@ -52,7 +53,8 @@ class DcnDesc(ctypes.Structure):
                 ('split_k', ctypes.c_int), ('algo', ctypes.c_int), ('fuse_offset', ctypes.c_int),
                 ('w_off_packed', ctypes.c_void_p), ('b_off', ctypes.c_void_p),
                 ('up_w', ctypes.c_void_p), ('up_f', ctypes.c_int), ('up_skip', ctypes.c_void_p), ('up_lds', ctypes.c_int),
-                ('up_y', ctypes.c_void_p), ('up_ldy', ctypes.c_int)]
+                ('up_y', ctypes.c_void_p), ('up_ldy', ctypes.c_int),
+                ('om_partial', ctypes.c_void_p), ('om_partial_bytes', ctypes.c_size_t)]
 
 
 CT_MAX_FUSED_HEADS = 8
@@ -112,7 +114,7 @@ class Track(ctypes.Structure):
 
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
-           'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_stem_forward',
+           'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_offsets_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_decode_pose_workspace_bytes',
            'ct_decode_pose', 'ct_render_pre_hm',
@@ -138,6 +140,10 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise CTError('%s not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                       '(hipcc --offload-arch=gfx950); there is no CPU fallback' % LIB_PATH)
+    # torch first: its wheel bundles its own libamdhip64 / HSA runtime, and the library must bind to THAT copy (same
+    # soname as /opt/rocm's).  Loaded the other way round (this library, then torch) the process ends up with the
+    # system runtime under torch's allocator and every launch fails with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     i, p, sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     lib.ct_last_error.restype = ctypes.c_char_p
@@ -156,6 +162,8 @@ def load():
     lib.ct_dcn_v2.argtypes = [ctypes.POINTER(DcnDesc), p]
     lib.ct_dcn_v2_workspace_bytes.restype = sz
     lib.ct_dcn_v2_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
+    lib.ct_dcn_v2_offsets_bytes.restype = sz
+    lib.ct_dcn_v2_offsets_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
     lib.ct_dcn_v2_group.argtypes = [ctypes.POINTER(DcnDesc), i, i, p]
     lib.ct_dcn_v2_group_workspace_bytes.restype = sz
     lib.ct_dcn_v2_group_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]

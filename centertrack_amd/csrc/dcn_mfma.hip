@@ -37,6 +37,12 @@ struct DcnArgs {
     int wsCout;
     const float *w_off;              // fused offset/mask conv (FUSE kernels; per layer: nullptr = read `om`):
     const float *b_off;              //   packed 3x3 Cin -> 27 weights, bias
+    // offset/mask conv split over 64-channel chunks (ct_dcn_desc::fuse_offset == 2): omPart = [omSplits][N*H*W][32] raw
+    // partial sums, written by the CT_DCN_OFFSETS launch (offsOnly workgroups: one 32-pixel tile x one chunk each) and
+    // summed (+ bias, mask sigmoid) by the MAIN launch while it builds its sampling table
+    float *omPart;
+    int omSplits;
+    int offsOnly;
     EpiArgs epi;
 };
 
@@ -138,8 +144,24 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     const int c_end = min(nunits, c_begin + a.chunksPerSplit / UPC2);
 
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
+    if (FUSE && a.offsOnly) {
+        // ---- CT_DCN_OFFSETS: chunk `split` (64 input channels) of the offset/mask conv of this tile, raw ----
+        float *part = a.omPart + ((size_t)split * a.N + n) * a.H * a.W * 32;
+        auto fin = [&](int mt, int nt, f32x4 sum) {
+            const int co = nt * 16 + (lane & 15);
+            const int oy = oy0 + mt;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ox = ox0 + (lane >> 4) * 4 + e;
+                if (oy < a.H && ox < a.W) part[((size_t)oy * a.W + ox) * 32 + co] = sum[e];
+            }
+        };
+        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, split, split + 1, lds_a, fin);
+        return;
+    }
     const bool fuse = FUSE && a.w_off != nullptr;                // (uniform)
-    const float *omn = fuse ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
+    const bool parts = a.omSplits > 0;                           // (uniform)
+    const float *omn = (fuse || parts) ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
 
     if (fuse) {
         // ---- offset / mask conv of this tile (all input channels, whatever K range this split owns) ----
@@ -204,6 +226,22 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
             const int m = it / 9, k = it - m * 9;
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             const bool in = it < BM * 9 && oy < a.H && ox < a.W;
+            if (parts) {
+                // partial sums of the K-split offset conv: chunk order, then the bias (and the mask's sigmoid)
+                const size_t plane = (size_t)a.N * a.H * a.W * 32;
+                const float *pp = a.omPart + (in ? (((size_t)n * a.H + oy) * a.W + ox) * 32 : 0);
+                const int kk = in ? k : 0;
+                float dy = pp[2 * kk], dx = pp[2 * kk + 1], mk = pp[18 + kk];
+                for (int sp = 1; sp < a.omSplits; ++sp) {
+                    dy += pp[sp * plane + 2 * kk];
+                    dx += pp[sp * plane + 2 * kk + 1];
+                    mk += pp[sp * plane + 18 + kk];
+                }
+                tdy[i] = dy + a.b_off[2 * kk];
+                tdx[i] = dx + a.b_off[2 * kk + 1];
+                tmk[i] = 1.0f / (1.0f + expf(-(mk + a.b_off[18 + kk])));
+                continue;
+            }
             const float *omp = fuse ? om_lds + (in ? m * 32 : 0) : omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
             tdy[i] = omp[in ? 2 * k : 0];
             tdx[i] = omp[in ? 2 * k + 1 : 0];
@@ -396,8 +434,19 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 // s_waitcnt, 4.1 VALU + 3.7 SALU instructions per MFMA.  A loop of the same MFMAs with LDS fragment reads and a barrier
 // every 16 MFMAs sustains 137-148 TFLOP/s on the same box (tools/micro/mfma_peak.py), so the matrix side is not what
 // holds these kernels near 75-95 TFLOP/s.
+}  // namespace
+
+extern "C" size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d)
+{
+    if (!d || d->fuse_offset != 2 || d->Cin % 64 || d->Cin <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) return 0;
+    return (size_t)(d->Cin / 64) * d->N * d->H * d->W * 32 * sizeof(float);
+}
+
+namespace {
+
 struct DcnPlan {
     int fuse;
+    int parts;                       // offset/mask conv K-split into Cin / 64 partial maps (fuse_offset == 2)
     int BM, BN, NKK, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
     int use_ws;                      // partial / raw tiles go through the workspace (split-K, or a fused IDAUp step of a group)
 };
@@ -407,10 +456,19 @@ struct DcnPlan {
 int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
 {
     if (!d || !d->x || !d->w_packed || !d->y) CT_FAIL_ARG("ct_dcn_v2: null pointer");
-    p->fuse = d->fuse_offset ? 1 : 0;
-    if (p->fuse && (!d->w_off_packed || !d->b_off)) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
-    if (p->fuse && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs Cin %% 64 == 0 (got %d)", d->Cin);
-    if (!p->fuse && !d->om) CT_FAIL_ARG("ct_dcn_v2: null offset/mask map");
+    if (d->fuse_offset < 0 || d->fuse_offset > 2) CT_FAIL_ARG("ct_dcn_v2: fuse_offset=%d (0, 1 or 2)", d->fuse_offset);
+    p->fuse = d->fuse_offset == 1;
+    p->parts = d->fuse_offset == 2 ? d->Cin / 64 : 0;
+    if (d->fuse_offset && (!d->w_off_packed || !d->b_off)) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
+    if (d->fuse_offset && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs Cin %% 64 == 0 (got %d)", d->Cin);
+    if (p->parts) {
+        const size_t need = ct_dcn_v2_offsets_bytes(d);
+        if (!d->om_partial || d->om_partial_bytes < need) {
+            ct_set_error("ct_dcn_v2: fuse_offset=2 needs %zu bytes of om_partial, got %zu", need, d->om_partial ? d->om_partial_bytes : (size_t)0);
+            return CT_ERR_WORKSPACE;
+        }
+    }
+    if (!d->fuse_offset && !d->om) CT_FAIL_ARG("ct_dcn_v2: null offset/mask map");
     if (d->up_w) {
         if (!d->up_skip || !d->up_y) CT_FAIL_ARG("ct_dcn_v2: up_w given without up_skip / up_y");
         if (d->up_f != 2 && d->up_f != 4 && d->up_f != 8) CT_FAIL_ARG("ct_dcn_v2: up_f=%d unsupported", d->up_f);
@@ -419,7 +477,7 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     }
     if (d->Cin % 32 || d->Cin <= 0) CT_FAIL_ARG("ct_dcn_v2: Cin=%d must be a positive multiple of 32", d->Cin);
     if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_dcn_v2: input view must be 16-byte aligned");
-    if (!p->fuse && d->ldom < 27) CT_FAIL_ARG("ct_dcn_v2: offset/mask map needs >= 27 channels");
+    if (!d->fuse_offset && d->ldom < 27) CT_FAIL_ARG("ct_dcn_v2: offset/mask map needs >= 27 channels");
     if (d->Cout <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) CT_FAIL_ARG("ct_dcn_v2: bad shape");
     if (d->flags & CT_OUT_NCHW) CT_FAIL_ARG("ct_dcn_v2: NCHW output unsupported");
     p->NT = ct_cdiv(d->Cout, 16);
@@ -586,7 +644,10 @@ void fill_args(const ct_dcn_desc *d, const DcnPlan &p, DcnArgs *a)
     a->epi.flags = d->flags & CT_RELU; a->epi.sig_lo = a->epi.sig_hi = 0; a->epi.dep_lo = a->epi.dep_hi = 0;
     a->epi.depth_scale = 1.0f;
     a->w_off = p.fuse ? d->w_off_packed : nullptr;
-    a->b_off = p.fuse ? d->b_off : nullptr;
+    a->b_off = d->fuse_offset ? d->b_off : nullptr;
+    a->omPart = p.parts ? d->om_partial : nullptr;
+    a->omSplits = p.parts;
+    a->offsOnly = 0;
 }
 
 // dynamic LDS of one workgroup: A double buffers + the two tables (+ om tile and the offset-conv scratch when fused)
@@ -655,6 +716,32 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
     for (int i = n; i < DCN_MAX_GROUP; ++i) g.p[i] = g.p[0];
     const DcnPlan &p0 = plans[0];
     hipStream_t s = (hipStream_t)stream;
+    if (phases & CT_DCN_OFFSETS) {
+        // the K-split offset/mask convs of the layers that asked for them (fuse_offset == 2), all in one launch
+        DcnGroup og;
+        og.n = 0;
+        long oblocks = 0;
+        for (int i = 0; i < n; ++i) {
+            if (!plans[i].parts) continue;
+            const ct_dcn_desc *d = descs + i;
+            DcnArgs &a = og.p[og.n];
+            a = g.p[i];
+            a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 2); a.coutBlocks = 1;
+            a.tiles = d->N * a.tilesX * a.tilesY;
+            a.w_off = d->w_off_packed;
+            a.offsOnly = 1;
+            og.first[og.n] = (int)oblocks;
+            oblocks += (long)a.tiles * plans[i].parts;
+            ++og.n;
+        }
+        if (og.n > 0) {
+            if (oblocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
+            for (int i = og.n; i <= DCN_MAX_GROUP; ++i) og.first[i] = (int)oblocks;
+            for (int i = og.n; i < DCN_MAX_GROUP; ++i) og.p[i] = og.p[0];
+            hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), dim3((unsigned)oblocks), dim3(256), lds_bytes(32, true, true), s, og);
+            CT_CHECK_LAUNCH("ct_dcn_v2(offset/mask conv)");
+        }
+    }
     const dim3 grid((unsigned)blocks);
     if (!(phases & CT_DCN_MAIN)) {
         // finish only: the partials were written by an earlier CT_DCN_MAIN call on the same descriptors
@@ -721,10 +808,14 @@ extern "C" size_t ct_dcn_v2_group_workspace_bytes(const ct_dcn_desc *d)
     return ws_bytes(&t, p);
 }
 
-extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream) { return launch_group(d, 1, false, CT_DCN_MAIN | CT_DCN_FINISH, stream); }
+extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
+{
+    return launch_group(d, 1, false, CT_DCN_OFFSETS | CT_DCN_MAIN | CT_DCN_FINISH, stream);
+}
 
 extern "C" int ct_dcn_v2_group(const ct_dcn_desc *descs, int n, int phases, void *stream)
 {
-    if (!(phases & (CT_DCN_MAIN | CT_DCN_FINISH))) CT_FAIL_ARG("ct_dcn_v2_group: phases must name CT_DCN_MAIN and / or CT_DCN_FINISH");
+    if (!(phases & (CT_DCN_OFFSETS | CT_DCN_MAIN | CT_DCN_FINISH)) || (phases & ~(CT_DCN_OFFSETS | CT_DCN_MAIN | CT_DCN_FINISH)))
+        CT_FAIL_ARG("ct_dcn_v2_group: phases must be a combination of CT_DCN_OFFSETS, CT_DCN_MAIN and CT_DCN_FINISH");
     return launch_group(descs, n, true, phases, stream);
 }

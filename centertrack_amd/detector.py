@@ -113,8 +113,8 @@ class _HipGraph(object):
             raise _lib.CTError('ct_graph_end failed: %s' % lib.ct_last_error().decode())
         self._lib = lib
 
-    def replay(self):
-        rc = self._lib.ct_graph_launch(self.exec, _lib.stream_ptr())
+    def replay(self, sp=None):
+        rc = self._lib.ct_graph_launch(self.exec, sp if sp is not None else _lib.stream_ptr())
         if rc:
             _lib.check(rc, 'ct_graph_launch')
 
@@ -343,6 +343,10 @@ class StreamDetector(object):
         ctx = self._context(H, W)
         x_in, img_in, hm_in = ctx['plan']['inputs']
         lib = _lib.load()
+        # (torch.cuda.current_stream() costs ~5 us of host time per call and the GPU idles while the host prepares a
+        # frame: looked up once per step)
+        cur = torch.cuda.current_stream()
+        sp = ctypes.c_void_p(cur.cuda_stream)
         par = ctx['parity'] if img_in is not None else 0
         fr = ctx['frames'][par]
         # ---- the frame goes straight into the graph's frame buffer (images [0, B); the mirrored images [B, 2B) of
@@ -358,18 +362,19 @@ class StreamDetector(object):
             pf = self._prefetched
             if pf is not None and pf[0] == (images.data_ptr(), tuple(images.shape)):
                 # uploaded by the previous step's ``prefetch`` while that frame was computed: staging -> frame buffer
-                torch.cuda.current_stream().wait_event(pf[1])
-                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), ctx['stage'].data_ptr(), images.numel() * 4, 0,
-                                               _lib.stream_ptr()), 'frame copy')
+                cur.wait_event(pf[1])
+                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), ctx['stage'].data_ptr(), images.numel() * 4, 0, sp),
+                           'frame copy')
                 self._prefetched = None
-                ctx['stage_free'] = torch.cuda.Event()         # the staging buffer may be refilled once this copy ran
-                ctx['stage_free'].record(torch.cuda.current_stream())
+                if ctx['stage_free'] is None:
+                    ctx['stage_free'] = torch.cuda.Event()
+                ctx['stage_free'].record(cur)                  # the staging buffer may be refilled once this copy ran
             elif images.dtype == torch.float32 and images.is_contiguous():
                 # one DMA from wherever the caller keeps the frame: H2D for a host tensor (detector.py:93-94 -- pinned
                 # memory makes it asynchronous), D2D for a resident one
                 kind = 0 if images.device.type == 'cuda' else 1
-                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), images.data_ptr(), images.numel() * 4, kind,
-                                               _lib.stream_ptr()), 'frame copy')
+                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), images.data_ptr(), images.numel() * 4, kind, sp),
+                           'frame copy')
             else:
                 fr[:B].copy_(images)
         tracking = bool(getattr(opt, 'tracking', False))
@@ -386,8 +391,7 @@ class StreamDetector(object):
                 prev = ctx['frames'][par ^ 1]
                 fresh = [s for s in range(B) if not self.started[s]]
                 if fresh and self.flip:
-                    _lib.check(lib.ct_flip_images(fr.data_ptr(), fr[B:].data_ptr(), B * 3 * H, W, _lib.stream_ptr()),
-                               'ct_flip_images')
+                    _lib.check(lib.ct_flip_images(fr.data_ptr(), fr[B:].data_ptr(), B * 3 * H, W, sp), 'ct_flip_images')
                 if len(fresh) == B:
                     prev.copy_(fr)
                 else:
@@ -414,7 +418,9 @@ class StreamDetector(object):
             for s in range(B):
                 self.started[s] = True
         t1 = time.time()
-        if ctx['graphs'][par] is not None:
+        if ctx['raw']:
+            ctx['graphs'][par].replay(sp)
+        elif ctx['graphs'][par] is not None:
             ctx['graphs'][par].replay()
         else:
             ctx['device_frame'](par)
@@ -426,21 +432,23 @@ class StreamDetector(object):
                 ctx['stage'] = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
                 ctx['copy_stream'] = torch.cuda.Stream(device=self.device)
                 ctx['stage_free'] = None
+                ctx['stage_ready'] = torch.cuda.Event()
+                ctx['copy_sp'] = ctypes.c_void_p(ctx['copy_stream'].cuda_stream)
             cs = ctx['copy_stream']
             if ctx['stage_free'] is not None:                  # (the staging buffer was read by the D2D of this step)
                 cs.wait_event(ctx['stage_free'])
             _lib.check(lib.ct_memcpy_async(ctx['stage'].data_ptr(), prefetch.data_ptr(), prefetch.numel() * 4, 1,
-                                           ctypes.c_void_p(cs.cuda_stream)), 'prefetch')
-            ev = torch.cuda.Event()
-            ev.record(cs)
+                                           ctx['copy_sp']), 'prefetch')
+            ev = ctx['stage_ready']                            # (re-recorded every step; the waiter of the previous
+            ev.record(cs)                                      #  recording was enqueued at the top of this step)
             self._prefetched = ((prefetch.data_ptr(), tuple(prefetch.shape)), ev)
         if self.gather_fn is not None:
             self.gather_fn(ctx['decoder'].out)
         if ctx['raw']:                                         # (the D2H of the rows is the graph's last node)
-            _lib.check(_lib.load().ct_stream_synchronize(_lib.stream_ptr()), 'ct_stream_synchronize')
+            _lib.check(lib.ct_stream_synchronize(sp), 'ct_stream_synchronize')
         else:
             ctx['host_out'].copy_(ctx['decoder'].out, non_blocking=True)
-            torch.cuda.current_stream().synchronize()
+            cur.synchronize()
         t2 = time.time()
         rows = ctx['host_rows']
         self._last_dets = None                                 # unpacked on demand (last_dets)
@@ -453,8 +461,9 @@ class StreamDetector(object):
                 # float32 inverse output affine (post_process.py:30), cached in the meta dict, keyed on the VALUES
                 # of c / s (an in-place edit or a recycled object id must not resurrect a stale transform)
                 cached = m.get('_trans_inv')
-                ident = (tuple(np.ravel(m['c']).tolist()), tuple(np.ravel(m['s']).tolist()), m['out_width'],
-                         m['out_height'])
+                c_, s_ = m['c'], m['s']
+                ident = (float(c_[0]), float(c_[1]), float(s_) if np.ndim(s_) == 0 else tuple(np.ravel(s_).tolist()),
+                         m['out_width'], m['out_height'])
                 if cached is None or cached[0] != ident:
                     tinv = np.ascontiguousarray(get_affine_transform(
                         m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1).astype(np.float32))

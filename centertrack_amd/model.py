@@ -464,13 +464,17 @@ class DLASegHIP(torch.nn.Module):
         inputs exist: main(L) = first t with 2t > time(x); finish(L) = first t' >= main(L) with 2t'+1 > time(skip).
         The layers sharing a slot go out as ONE ct_dcn_v2_group launch each for M_t and F_t: 8 + 7 launches for the
         16 nodes instead of 16 + (offset convs) + 8 reductions, and at one stream 768 .. 1536 workgroups per launch
-        instead of 128 .. 512.  knobs = (fuse_max_cin, chunks_per_split, nkk): the offset/mask conv is computed
-        inside the DCN launch for Cin <= fuse_max_cin (else by its own conv launch just before the slot), every
-        workgroup contracts chunks_per_split 32-channel chunks, in steps of 16 * nkk channels (nkk = 2 / 4: 16 / 32
-        MFMAs per wave between barriers)."""
+        instead of 128 .. 512.  knobs = (fuse_max_cin, chunks_per_split, nkk, split_offsets): the offset/mask conv
+        is computed inside the DCN launch for Cin <= fuse_max_cin -- every workgroup of a split-K layer then repeats
+        it over ALL input channels, 47 % of a 256-channel layer's time at one stream -- else ahead of the slot: K-split
+        over 64-channel chunks in ONE CT_DCN_OFFSETS launch for all layers of the slot (split_offsets = 1, one
+        workgroup per 32-pixel tile and chunk whatever Cin) or by one conv launch per layer (0); every workgroup
+        contracts chunks_per_split 32-channel chunks, in steps of 16 * nkk channels (nkk = 2 / 4: 16 / 32 MFMAs per
+        wave between barriers)."""
         lib = _lib.load()
         P = self._prepared
-        fuse_max_cin, cps, nkk = knobs
+        fuse_max_cin, cps, nkk = knobs[:3]
+        split_offsets = knobs[3] if len(knobs) > 3 else 1
         time_of = dict(produced0)                    # buffer id -> time after which it is readable
 
         def t_of(view):
@@ -478,14 +482,18 @@ class DLASegHIP(torch.nn.Module):
 
         slots = {}
         convs = {}
+        offs = {}
         for ly in layers:                            # (reference order: producers come first)
             pk = P[ly.name]
             ly.fused = ly.x.C % 64 == 0 and ly.x.C <= fuse_max_cin and FUSE_OFFSET
             nchunks = ly.x.C // 32
             ly.splits = max(1, nchunks // cps)
             ly.main = t_of(ly.x) // 2 + 1
-            om = None
-            if not ly.fused:
+            om = part = None
+            if not ly.fused and split_offsets and ly.x.C % 64 == 0:
+                part = torch.empty((ly.x.C // 64) * N * ly.x.H * ly.x.W * 32, dtype=torch.float32, device=dev)
+                offs.setdefault(ly.main, []).append(ly)
+            elif not ly.fused:
                 om = ops.new_view(N, ly.x.H, ly.x.W, 32, dev)
                 d = ops.make_conv_desc(ly.x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
                 if autotune.enabled():
@@ -493,12 +501,13 @@ class DLASegHIP(torch.nn.Module):
                 convs.setdefault(ly.main, []).append(
                     _Launch(ly.name + '.offset', 'conv', d, (ly.x, om, pk),
                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            own = ly.fused or part is not None
             dd = ops.make_dcn_desc(ly.x, om, pk['w'], ly.cout, pk['scale'], pk['shift'], True, ly.out, up=ly.up,
-                                   split_k=ly.splits, algo=3264,
-                                   w_off=pk['w_off'] if ly.fused else None, b_off=pk['b_off'] if ly.fused else None)
+                                   split_k=ly.splits, algo=3264, om_partial=part,
+                                   w_off=pk['w_off'] if own else None, b_off=pk['b_off'] if own else None)
             need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(dd))
             ly.use_ws = need > 0
-            keep = [ly.x, om, ly.out, pk, ly.up]
+            keep = [ly.x, om, part, ly.out, pk, ly.up]
             if need:
                 ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
                 dd.workspace, dd.workspace_bytes = ws.data_ptr(), need
@@ -530,6 +539,8 @@ class DLASegHIP(torch.nn.Module):
 
         for t in sorted(slots):
             out.extend(convs.get(t, []))
+            if offs.get(t):
+                group(offs[t], _lib.CT_DCN_OFFSETS, 'dcn.offsets')
             lys = slots[t]['main']
             if lys:
                 group(lys, _lib.CT_DCN_MAIN, 'dcn')
@@ -578,27 +589,30 @@ class DLASegHIP(torch.nn.Module):
         if env:
             knobs = tuple(int(v) for v in env.split(','))
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
-        default = (128, 4, 4)
+        default = (128, 4, 2, 1)
         if not tune:
             return default, self._schedule_dcn(layers, produced0, N, dev, default)
-        key = 'dcnplan2:%d,%d,%d' % (N, H, W)
+        key = 'dcnplan3:%d,%d,%d' % (N, H, W)
         autotune._load_file()
         if key in autotune._CACHE:
-            knobs = tuple(int(v) for v in autotune._CACHE[key][:3])
+            knobs = tuple(int(v) for v in autotune._CACHE[key][:4])
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         best = None
-        for fuse_max in (64, 128, 256):
-            for cps in (2, 4):
+        # (split_offsets = 0 -- one conv launch per un-fused layer -- never won in round 2's sweeps: 368 against 336 us
+        # at one stream, 1932 against 1818 us at eight; it stays reachable through CENTERTRACK_DCN_KNOBS)
+        for fuse_max in (0, 64, 128, 256):
+            for cps in (2, 4, 8):
                 for nkk in (2, 4):
-                    knobs = (fuse_max, cps, nkk)
-                    launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
-                    us = self._time_launches(launches)
-                    if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
-                        print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us' % (N, H, W, knobs, len(launches), us))
-                    if best is None or us < best[0]:
-                        best = (us, knobs)
-                    del launches
-        autotune._CACHE[key] = (best[1][0], best[1][1], best[1][2], round(best[0], 1))
+                    for so in (1,):
+                        knobs = (fuse_max, cps, nkk, so)
+                        launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
+                        us = self._time_launches(launches)
+                        if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
+                            print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us' % (N, H, W, knobs, len(launches), us))
+                        if best is None or us < best[0]:
+                            best = (us, knobs)
+                        del launches
+        autotune._CACHE[key] = tuple(best[1]) + (round(best[0], 1),)
         autotune._save_file()
         return best[1], self._schedule_dcn(layers, produced0, N, dev, best[1])
 

@@ -134,15 +134,19 @@ def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
 
 
 def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0, w_off=None,
-                  b_off=None, up=None):
+                  b_off=None, up=None, om_partial=None):
     """``w_off`` (packed conv_offset_mask weight) + ``b_off`` given: the offset/mask conv runs inside the DCN
-    launch (``om`` may be None); otherwise ``om`` is the precomputed NHWC offset/mask map."""
+    launch (``om`` may be None) -- or, with ``om_partial`` (a float buffer of ct_dcn_v2_offsets_bytes), K-split by
+    the CT_DCN_OFFSETS launch; otherwise ``om`` is the precomputed NHWC offset/mask map."""
     d = DcnDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
     if om is not None:
         d.om, d.ldom = om.ptr, om.ld
     if w_off is not None:
         d.fuse_offset, d.w_off_packed, d.b_off = 1, w_off.data_ptr(), b_off.data_ptr()
+        if om_partial is not None:
+            d.fuse_offset = 2
+            d.om_partial, d.om_partial_bytes = om_partial.data_ptr(), om_partial.numel() * om_partial.element_size()
     if up is not None:                 # (upsample_weight [4f^2,C], f, skip view, output view): fused IDAUp step
         w_up, f, skip, up_out = up
         d.up_w, d.up_f, d.up_skip, d.up_lds = w_up.data_ptr(), f, skip.ptr, skip.ld
@@ -159,12 +163,15 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
 
 
 def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0, w_off=None, b_off=None,
-           up=None):
+           up=None, split_offsets=False):
     lib = _lib.load()
     if out is None:
         out = new_view(x.N, x.H, x.W, Cout, x.buf.device)
+    part = None
+    if split_offsets:
+        part = torch.empty((x.C // 64) * x.N * x.H * x.W * 32, dtype=torch.float32, device=x.buf.device)
     d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo, w_off=w_off, b_off=b_off,
-                      up=up)
+                      up=up, om_partial=part)
     ws = None
     if split_k != 1:
         need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))

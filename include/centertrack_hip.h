@@ -135,15 +135,21 @@ typedef struct ct_dcn_desc {
                                                    channels per barrier (Cin % 64 == 0) */
     int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
-                                                   unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile */
+                                                   unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile.
+                                                   2: the same conv K-split over Cin / 64 chunks by the CT_DCN_OFFSETS
+                                                   launch (one workgroup per 32-pixel tile and chunk, whatever Cin) into
+                                                   om_partial; the main launch sums the chunks (+ bias, mask sigmoid)
+                                                   while it builds its sampling table; `om` unused */
     const float *w_off_packed; const float *b_off;
     /* optional fused IDAUp step (dla.py:543-545) for a `proj` DCN: when up_w != NULL the layer's result goes
      * through ct_upsample_add(result, up_w, up_f, up_skip) into up_y; with split-K the reduction kernel does
      * it directly from the partials (`y` is then never written), otherwise `y` holds the DCN output. */
     const float *up_w; int up_f; const float *up_skip; int up_lds; float *up_y; int up_ldy;
+    float *om_partial; size_t om_partial_bytes; /* fuse_offset == 2: [Cin/64][N,H,W,32] floats = ct_dcn_v2_offsets_bytes(d) */
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
+size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d);   /* 0 unless fuse_offset == 2 */
 /* Up to 4 INDEPENDENT DeformConv layers in one launch (+ one reduce launch that finishes all of them): the IDAUp /
  * DLAUp tree (dla.py:539-574) has several layers ready at the same time -- every `proj_i` only needs a finished
  * level, `node_i` of different IDAUp stages do not depend on each other -- and at one stream each of them alone
@@ -156,7 +162,9 @@ size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
  * tensor (the previous node's output) only in the finishing launch, so the contraction can start before that
  * tensor exists.  Results are bit-identical to ct_dcn_v2 with the same split_k. */
 enum { CT_DCN_MAIN = 1,      /* the gather + contraction launch (results or split-K partials) */
-       CT_DCN_FINISH = 2     /* the launch that finishes the layers holding partials: reduction + BN + ReLU (+ IDAUp step) */ };
+       CT_DCN_FINISH = 2,    /* the launch that finishes the layers holding partials: reduction + BN + ReLU (+ IDAUp step) */
+       CT_DCN_OFFSETS = 4    /* the K-split offset/mask convs of the layers with fuse_offset == 2 (no-op for the others);
+                                must precede CT_DCN_MAIN of the same layers */ };
 int ct_dcn_v2_group(const ct_dcn_desc *descs, int n, int phases, void *stream);
 size_t ct_dcn_v2_group_workspace_bytes(const ct_dcn_desc *d);
 

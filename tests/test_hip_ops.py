@@ -291,6 +291,46 @@ def test_dcn_with_fused_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, al
     _close(out.to_nchw(), y, msg='fused DCN')
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k', [(1, 12, 20, 64, 64, 3264, 1), (2, 9, 21, 128, 64, 0, 2),
+                                                       (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8),
+                                                       (2, 9, 21, 128, 64, 43264, 2), (1, 7, 33, 256, 128, 64, 1)])
+def test_dcn_with_split_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, algo, split_k):
+    """fuse_offset = 2: conv_offset_mask K-split over Cin / 64 chunks by the CT_DCN_OFFSETS launch (raw partial maps),
+    summed + bias + mask sigmoid by the main launch == upstream DCN.forward (oracle), on every tile shape"""
+    from centertrack_amd import ops
+    from oracle import dcn_v2 as odcn
+    x = F.relu(_rand(N, Cin, H, W, seed=140))
+    w, b = _rand(Cout, Cin, 3, 3, seed=141, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=142)
+    wo, bo = _rand(27, Cin, 3, 3, seed=143, scale=0.6 * (Cin * 9) ** -0.5), _rand(27, seed=144, scale=0.3)
+    y = odcn.dcn_forward(x, w, b, wo, bo)
+    out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), None, ops.pack_weight(w.to(device)), Cout, shift=b.to(device),
+                     algo=algo, split_k=split_k, w_off=ops.pack_weight(wo.to(device)), b_off=bo.to(device),
+                     split_offsets=True)
+    _close(out.to_nchw(), y, msg='DCN with K-split offset conv')
+
+
+def test_dcn_split_offsets_argument_errors(device):
+    import ctypes
+    from centertrack_amd import _lib, ops
+    lib = _lib.load()
+    xv = ops.view_from_nchw(torch.zeros(1, 64, 8, 16, device=device))
+    wp, wop = ops.pack_weight(torch.zeros(64, 64, 3, 3, device=device)), ops.pack_weight(torch.zeros(27, 64, 3, 3, device=device))
+    bo = torch.zeros(27, device=device)
+    out = ops.new_view(1, 8, 16, 64, device)
+    part = torch.empty(8 * 16 * 32, device=device)
+    d = ops.make_dcn_desc(xv, None, wp, 64, None, None, False, out, split_k=1, w_off=wop, b_off=bo, om_partial=part)
+    assert lib.ct_dcn_v2_offsets_bytes(ctypes.byref(d)) == 8 * 16 * 32 * 4
+    d.om_partial_bytes = 16
+    assert lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()) == _lib.CT_ERR_WORKSPACE
+    d.om_partial_bytes = part.numel() * 4
+    d.fuse_offset = 3
+    assert lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()) == _lib.CT_ERR_ARG
+    d.fuse_offset = 2
+    assert lib.ct_dcn_v2_group(ctypes.byref(d), 1, 8, _lib.stream_ptr()) == _lib.CT_ERR_ARG
+    assert lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()) == 0
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize('f,split_k', [(2, 4), (2, 1), (4, 2)])
 def test_dcn_with_fused_idaup_step(device, f, split_k):
     """proj DCN + BN + ReLU + `up(.) + skip` in one C-ABI call (fused into the split-K reduction when there is
@@ -321,8 +361,9 @@ def test_dcn_with_fused_idaup_step(device, f, split_k):
 
 @pytest.mark.parametrize('galgo', [3264, 43264])
 def test_dcn_group_launch_equals_single_launches(device, galgo):
-    """ct_dcn_v2_group: three independent layers of different shapes -- fused offset conv + IDAUp step with split-K,
-    offset/mask map read from HBM, fused offset conv without split -- in ONE gather/contraction launch and ONE
+    """ct_dcn_v2_group: four independent layers of different shapes -- fused offset conv + IDAUp step with split-K,
+    offset/mask map read from HBM, fused offset conv without split, K-split offset conv (own launch) + IDAUp step
+    -- in ONE gather/contraction launch and ONE
     finishing launch == the same layers launched one by one (bit for bit: same tiles, same split-K, same reduction
     order; for every tile shape a group can run on), also when the two phases are issued separately, and == the oracle."""
     import ctypes
@@ -331,7 +372,9 @@ def test_dcn_group_launch_equals_single_launches(device, galgo):
     lib = _lib.load()
     specs = [dict(N=1, H=6, W=10, Cin=128, Cout=64, split=2, fuse=True, f=2),
              dict(N=2, H=5, W=17, Cin=256, Cout=128, split=4, fuse=False, f=0),
-             dict(N=1, H=12, W=20, Cin=64, Cout=64, split=1, fuse=True, f=0)]
+             dict(N=1, H=12, W=20, Cin=64, Cout=64, split=1, fuse=True, f=0),
+             dict(N=1, H=7, W=18, Cin=256, Cout=64, split=2, fuse='split', f=2)]
+    NL = len(specs)
     descs, keep, want, single = [], [], [], []
     for i, sp in enumerate(specs):
         N, H, W, Cin, Cout = sp['N'], sp['H'], sp['W'], sp['Cin'], sp['Cout']
@@ -357,39 +400,43 @@ def test_dcn_group_launch_equals_single_launches(device, galgo):
             up1 = (wt, f, sv, ops.new_view(N, H * f, W * f, Cout, device))
         want.append(y)
         fuse_kw = dict(w_off=wop, b_off=bo_d) if sp['fuse'] else {}
+        part = torch.empty((Cin // 64) * N * H * W * 32, device=device) if sp['fuse'] == 'split' else None
         d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sp['split'], algo=galgo,
-                              up=up, **fuse_kw)
+                              up=up, om_partial=part, **fuse_kw)
         need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d))
         assert (need > 0) == (sp['split'] > 1 or sp['f'] > 0)
         ws = torch.empty(max(need, 4) // 4, device=device)
         d.workspace, d.workspace_bytes = ws.data_ptr(), need
         descs.append(d)
-        keep += [xv, wp, wop, sc_d, b_d, bo_d, om, up, ws, out]
+        keep += [xv, wp, wop, sc_d, b_d, bo_d, om, up, ws, out, part]
         # the same layer alone (legacy entry point, same tile shape and split)
         one = ops.dcn_v2(xv, om, wp, Cout, sc_d, b_d, relu=True, split_k=sp['split'], algo=galgo,
-                         up=up1, **fuse_kw)
+                         up=up1, split_offsets=sp['fuse'] == 'split', **fuse_kw)
         single.append(up1[3] if up1 is not None else one)
-    arr = (_lib.DcnDesc * 3)(*descs)
+    arr = (_lib.DcnDesc * NL)(*descs)
 
     def results():
         torch.cuda.synchronize()
-        return [(specs[i]['f'] and keep[10 * i + 7][3] or keep[10 * i + 9]).to_nchw().clone() for i in range(3)]
+        return [(specs[i]['f'] and keep[11 * i + 7][3] or keep[11 * i + 9]).to_nchw().clone() for i in range(NL)]
 
-    _lib.check(lib.ct_dcn_v2_group(arr, 3, _lib.CT_DCN_MAIN | _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'group')
+    allp = _lib.CT_DCN_OFFSETS | _lib.CT_DCN_MAIN | _lib.CT_DCN_FINISH
+    _lib.check(lib.ct_dcn_v2_group(arr, NL, allp, _lib.stream_ptr()), 'group')
     got = results()
-    for i in range(3):
+    for i in range(NL):
         _close(got[i], want[i], msg='group layer %d vs oracle' % i)
         assert torch.equal(got[i], single[i].to_nchw()), 'group layer %d vs single launch' % i
     for r in got:
         r.zero_()
-    for i in range(3):
-        (keep[10 * i + 7][3] if specs[i]['f'] else keep[10 * i + 9]).buf.zero_()
-    # phases issued separately, the finishing launch with another grouping (layer 1 then layers 0 + 2)
-    _lib.check(lib.ct_dcn_v2_group(arr, 3, _lib.CT_DCN_MAIN, _lib.stream_ptr()), 'main')
+    for i in range(NL):
+        (keep[11 * i + 7][3] if specs[i]['f'] else keep[11 * i + 9]).buf.zero_()
+    keep[11 * 3 + 10].zero_()
+    # phases issued separately, the offsets and the finishing launches with other groupings
+    _lib.check(lib.ct_dcn_v2_group((_lib.DcnDesc * 2)(descs[3], descs[0]), 2, _lib.CT_DCN_OFFSETS, _lib.stream_ptr()), 'offsets')
+    _lib.check(lib.ct_dcn_v2_group(arr, NL, _lib.CT_DCN_MAIN, _lib.stream_ptr()), 'main')
     _lib.check(lib.ct_dcn_v2_group((_lib.DcnDesc * 1)(descs[1]), 1, _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'finish 1')
-    _lib.check(lib.ct_dcn_v2_group((_lib.DcnDesc * 2)(descs[0], descs[2]), 2, _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'finish 0,2')
+    _lib.check(lib.ct_dcn_v2_group((_lib.DcnDesc * 3)(descs[0], descs[2], descs[3]), 3, _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'finish 0,2,3')
     again = results()
-    for i in range(3):
+    for i in range(NL):
         assert torch.equal(again[i], single[i].to_nchw()), 'separate phases, layer %d' % i
 
 

@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Re-measure the DCN schedule knobs (`dcnplan3:N,H,W`) for every (streams, size) the pinned table holds and write the
+merged table: run on the GPU box with CENTERTRACK_TUNE_CACHE=<out.json>; the conv entries of the pinned table are
+kept, stale `dcnplan2:*` entries dropped.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
+import json
+import os
+import sys
+
+out = sys.argv[1]
+os.environ['CENTERTRACK_TUNE_CACHE'] = out
+os.environ.setdefault('CENTERTRACK_TUNE_VERBOSE', '')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+import torch  # noqa: E402
+
+from centertrack_amd import autotune, scenarios as S, weights as W  # noqa: E402
+from centertrack_amd.model import DLASegHIP  # noqa: E402
+
+table = autotune._read_table(autotune.PINNED_TABLE)
+shapes = sorted({tuple(int(v) for v in k.split(':')[1].split(',')) for k in table if k.startswith('dcnplan')},
+                key=lambda t: t[0] * t[1] * t[2])
+heads = S.HEAD_SETS['mot']
+sd = W.make_synthetic_state_dict(heads, seed=317)
+for (N, H, Wd) in shapes:
+    model = DLASegHIP(heads)
+    model.load_state_dict(sd)
+    model = model.to('cuda')
+    plan = model.get_plan(N, H, Wd, True, True, True)
+    print('dcnplan3:%d,%d,%d -> %s' % (N, H, Wd, (plan['dcn_knobs'],)), flush=True)
+    del plan, model
+    torch.cuda.empty_cache()
+merged = {k: list(v) for k, v in autotune._CACHE.items() if not k.startswith('dcnplan2:')}
+with open(out, 'w') as f:
+    json.dump(dict(sorted(merged.items())), f, indent=0)
+print('%d keys -> %s' % (len(merged), out))

@@ -13,6 +13,7 @@ OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 export CENTERTRACK_TUNE_CACHE=${CENTERTRACK_TUNE_CACHE:-/tmp/tune_sweep.json}
 : > $OUT/${TAG}_sweep.jsonl
+python $R/tools/box_calib.py > $OUT/${TAG}_box.json 2>/dev/null
 run() {  # config streams
     cd $R
     python bench.py --config $1 --streams $2 --steps 10 --warmup 3 --no-cpu-baseline \
@@ -29,6 +30,7 @@ for B in 1 8 16 32; do run mot17_512 $B; done
 for B in 1 4 8 16 32; do run nusc_800x448 $B; done
 run kitti_1280x384 4
 run coco_512 4
+cat $OUT/${TAG}_box.json
 cat $OUT/${TAG}_sweep.jsonl | python -c "
 import json, sys
 for line in sys.stdin:
