@@ -122,14 +122,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 #pragma unroll
     for (int i = 1; i < DCN_MAX_GROUP; ++i)
         if (i < g.n && bid >= g.first[i]) pi = i;
-#if defined(CT_DBG_STATIC0)
-    const DcnArgs &a = g.p[0];
-    pi = 0;
-#elif defined(CT_DBG_BRANCH)
-    const DcnArgs &a = (pi == 0) ? g.p[0] : ((pi == 1) ? g.p[1] : ((pi == 2) ? g.p[2] : g.p[3]));
-#else
     const DcnArgs &a = g.p[pi];
-#endif
     bid -= g.first[pi];
     const int split = bid / a.tiles;
     bid -= split * a.tiles;
@@ -438,8 +431,9 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 
 extern "C" size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d)
 {
-    if (!d || d->fuse_offset != 2 || d->Cin % 64 || d->Cin <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0) return 0;
-    return (size_t)(d->Cin / 64) * d->N * d->H * d->W * 32 * sizeof(float);
+    if (!d || (d->fuse_offset != 2 && d->fuse_offset != 3) || d->Cin % 64 || d->Cin <= 0 || d->N <= 0 || d->H <= 0 || d->W <= 0)
+        return 0;
+    return (size_t)(d->fuse_offset == 3 ? 1 : d->Cin / 64) * d->N * d->H * d->W * 32 * sizeof(float);
 }
 
 namespace {
@@ -456,15 +450,16 @@ struct DcnPlan {
 int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
 {
     if (!d || !d->x || !d->w_packed || !d->y) CT_FAIL_ARG("ct_dcn_v2: null pointer");
-    if (d->fuse_offset < 0 || d->fuse_offset > 2) CT_FAIL_ARG("ct_dcn_v2: fuse_offset=%d (0, 1 or 2)", d->fuse_offset);
+    if (d->fuse_offset < 0 || d->fuse_offset > 3) CT_FAIL_ARG("ct_dcn_v2: fuse_offset=%d (0 .. 3)", d->fuse_offset);
     p->fuse = d->fuse_offset == 1;
-    p->parts = d->fuse_offset == 2 ? d->Cin / 64 : 0;
-    if (d->fuse_offset && (!d->w_off_packed || !d->b_off)) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
+    p->parts = d->fuse_offset == 2 ? d->Cin / 64 : (d->fuse_offset == 3 ? 1 : 0);
+    if (d->fuse_offset && (!d->b_off || (d->fuse_offset != 3 && !d->w_off_packed)))
+        CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
     if (d->fuse_offset && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs Cin %% 64 == 0 (got %d)", d->Cin);
     if (p->parts) {
         const size_t need = ct_dcn_v2_offsets_bytes(d);
         if (!d->om_partial || d->om_partial_bytes < need) {
-            ct_set_error("ct_dcn_v2: fuse_offset=2 needs %zu bytes of om_partial, got %zu", need, d->om_partial ? d->om_partial_bytes : (size_t)0);
+            ct_set_error("ct_dcn_v2: fuse_offset=%d needs %zu bytes of om_partial, got %zu", d->fuse_offset, need, d->om_partial ? d->om_partial_bytes : (size_t)0);
             return CT_ERR_WORKSPACE;
         }
     }
@@ -722,8 +717,8 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         og.n = 0;
         long oblocks = 0;
         for (int i = 0; i < n; ++i) {
-            if (!plans[i].parts) continue;
             const ct_dcn_desc *d = descs + i;
+            if (d->fuse_offset != 2) continue;            // (3: another launch wrote the raw sums)
             DcnArgs &a = og.p[og.n];
             a = g.p[i];
             a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 2); a.coutBlocks = 1;

@@ -156,6 +156,7 @@ class DLASegHIP(torch.nn.Module):
             sh = (sd[p + '.conv.bias'].double() * sc.double() + sh.double()).float().contiguous()
             return {'w': ops.pack_weight(sd[p + '.conv.weight']), 'scale': sc, 'shift': sh,
                     'w_off': ops.pack_weight(sd[p + '.conv.conv_offset_mask.weight']),
+                    'w_off_wino': wino(sd[p + '.conv.conv_offset_mask.weight']),
                     'b_off': sd[p + '.conv.conv_offset_mask.bias'].contiguous()}
 
         for p, n in (('dla_up.ida_0', 1), ('dla_up.ida_1', 2), ('dla_up.ida_2', 3), ('ida_up', 2)):
@@ -490,7 +491,20 @@ class DLASegHIP(torch.nn.Module):
             ly.splits = max(1, nchunks // cps)
             ly.main = t_of(ly.x) // 2 + 1
             om = part = None
-            if not ly.fused and split_offsets and ly.x.C % 64 == 0:
+            raw = False
+            if not ly.fused and split_offsets == 2 and ly.x.C % 64 == 0 and pk['w_off_wino'] is not None:
+                # raw sums by a conv launch of its own, free to use the Winograd shapes (2.25x fewer MFMAs): the bias
+                # and the mask sigmoid are applied by the DCN launch
+                raw = True
+                omv = ops.new_view(N, ly.x.H, ly.x.W, 32, dev)
+                part = omv.buf
+                d = ops.make_conv_desc(ly.x, pk['w_off'], 27, 3, 1, out=omv, w_wino=pk['w_off_wino'])
+                if autotune.enabled():
+                    autotune.tune_conv(d, dev)
+                convs.setdefault(ly.main, []).append(
+                    _Launch(ly.name + '.offset', 'conv', d, (ly.x, omv, pk),
+                            ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
+            elif not ly.fused and split_offsets and ly.x.C % 64 == 0:
                 part = torch.empty((ly.x.C // 64) * N * ly.x.H * ly.x.W * 32, dtype=torch.float32, device=dev)
                 offs.setdefault(ly.main, []).append(ly)
             elif not ly.fused:
@@ -503,7 +517,7 @@ class DLASegHIP(torch.nn.Module):
                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             own = ly.fused or part is not None
             dd = ops.make_dcn_desc(ly.x, om, pk['w'], ly.cout, pk['scale'], pk['shift'], True, ly.out, up=ly.up,
-                                   split_k=ly.splits, algo=3264, om_partial=part,
+                                   split_k=ly.splits, algo=3264, om_partial=part, raw_offsets=raw,
                                    w_off=pk['w_off'] if own else None, b_off=pk['b_off'] if own else None)
             need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(dd))
             ly.use_ws = need > 0
@@ -599,11 +613,13 @@ class DLASegHIP(torch.nn.Module):
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         best = None
         # (split_offsets = 0 -- one conv launch per un-fused layer -- never won in round 2's sweeps: 368 against 336 us
-        # at one stream, 1932 against 1818 us at eight; it stays reachable through CENTERTRACK_DCN_KNOBS)
+        # at one stream, 1932 against 1818 us at eight; it stays reachable through CENTERTRACK_DCN_KNOBS.  Neither did
+        # 128-cout tiles for the layers with >= 128 couts in a MAIN launch of their own: 6866 against 6830 us at 32
+        # streams, 1826 against 1806 at eight -- the second launch per slot costs what the wider tile gains)
         for fuse_max in (0, 64, 128, 256):
             for cps in (2, 4, 8):
                 for nkk in (2, 4):
-                    for so in (1,):
+                    for so in ((1, 2) if fuse_max < 256 else (1,)):
                         knobs = (fuse_max, cps, nkk, so)
                         launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
                         us = self._time_launches(launches)

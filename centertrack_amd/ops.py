@@ -134,7 +134,7 @@ def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
 
 
 def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0, w_off=None,
-                  b_off=None, up=None, om_partial=None):
+                  b_off=None, up=None, om_partial=None, raw_offsets=False):
     """``w_off`` (packed conv_offset_mask weight) + ``b_off`` given: the offset/mask conv runs inside the DCN
     launch (``om`` may be None) -- or, with ``om_partial`` (a float buffer of ct_dcn_v2_offsets_bytes), K-split by
     the CT_DCN_OFFSETS launch; otherwise ``om`` is the precomputed NHWC offset/mask map."""
@@ -145,7 +145,7 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
     if w_off is not None:
         d.fuse_offset, d.w_off_packed, d.b_off = 1, w_off.data_ptr(), b_off.data_ptr()
         if om_partial is not None:
-            d.fuse_offset = 2
+            d.fuse_offset = 3 if raw_offsets else 2          # (3: another launch writes the raw sums into om_partial)
             d.om_partial, d.om_partial_bytes = om_partial.data_ptr(), om_partial.numel() * om_partial.element_size()
     if up is not None:                 # (upsample_weight [4f^2,C], f, skip view, output view): fused IDAUp step
         w_up, f, skip, up_out = up

@@ -139,17 +139,21 @@ typedef struct ct_dcn_desc {
                                                    2: the same conv K-split over Cin / 64 chunks by the CT_DCN_OFFSETS
                                                    launch (one workgroup per 32-pixel tile and chunk, whatever Cin) into
                                                    om_partial; the main launch sums the chunks (+ bias, mask sigmoid)
-                                                   while it builds its sampling table; `om` unused */
+                                                   while it builds its sampling table; `om` unused.
+                                                   3: om_partial holds ONE map of raw sums (no bias, no sigmoid; channel
+                                                   pitch 32) written by any earlier launch -- e.g. ct_conv2d's Winograd
+                                                   shapes, which have no sigmoid epilogue; the main launch adds b_off and
+                                                   the mask sigmoid (w_off_packed is not read) */
     const float *w_off_packed; const float *b_off;
     /* optional fused IDAUp step (dla.py:543-545) for a `proj` DCN: when up_w != NULL the layer's result goes
      * through ct_upsample_add(result, up_w, up_f, up_skip) into up_y; with split-K the reduction kernel does
      * it directly from the partials (`y` is then never written), otherwise `y` holds the DCN output. */
     const float *up_w; int up_f; const float *up_skip; int up_lds; float *up_y; int up_ldy;
-    float *om_partial; size_t om_partial_bytes; /* fuse_offset == 2: [Cin/64][N,H,W,32] floats = ct_dcn_v2_offsets_bytes(d) */
+    float *om_partial; size_t om_partial_bytes; /* fuse_offset == 2: [Cin/64][N,H,W,32] floats, 3: [N,H,W,32] = ct_dcn_v2_offsets_bytes(d) */
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
-size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d);   /* 0 unless fuse_offset == 2 */
+size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d);   /* 0 unless fuse_offset == 2 or 3 */
 /* Up to 4 INDEPENDENT DeformConv layers in one launch (+ one reduce launch that finishes all of them): the IDAUp /
  * DLAUp tree (dla.py:539-574) has several layers ready at the same time -- every `proj_i` only needs a finished
  * level, `node_i` of different IDAUp stages do not depend on each other -- and at one stream each of them alone

@@ -7,6 +7,10 @@ north_star's bar, as asserted here:
   * heat-map scores and every decode-level value (boxes, centres, tracking displacement, 3D heads) on the OUTPUT
     GRID: within ``ATOL`` = 1e-3 absolute (depth, an unbounded 1/sigmoid - 1: 1e-3 relative on top);
   * image-space results (after the inverse affine): within ATOL x (image px per output cell) + fp32 slack;
+  * a detection whose oracle score lies within ``TIE`` of a threshold (out / new-track / prior-heat-map) is a
+    *threshold tie*: which side it falls on is as unresolvable as a rank tie, and since it adds or removes a result --
+    possibly a birth, shifting every later id -- the synthetic streams are chosen to contain none; ``check`` refuses a
+    stream that has one (that is a statement about the test data, made from the ORACLE's scores alone);
   * track IDs: a consistent bijection oracle-id <-> our-id over the WHOLE stream that is the identity, except for ids
     handed out inside one birth tie group (new ids are numbered in rank order, tracker.py:104-111, so a tie swap of
     two births swaps their ids for the rest of the stream).  Every non-identity pair is enumerated and must be
@@ -33,11 +37,16 @@ class StreamParity(object):
     def _key(d, b, i):
         return (int(d['clses'][b, i]), int(d['ys'][b, i]), int(d['xs'][b, i]))
 
-    def check(self, t, gd, gb, od, got, want, out_thresh, px_per_cell, min_dets=1):
+    def check(self, t, gd, gb, od, got, want, out_thresh, px_per_cell, min_dets=1, thresholds=()):
         """gd / od: our / the oracle's decode dict ([B,K,...] numpy; ours at batch index ``gb``, the oracle's at 0);
-        got / want: result lists (dicts) of the frame; px_per_cell: image pixels per output-grid cell."""
+        got / want: result lists (dicts) of the frame; px_per_cell: image pixels per output-grid cell; thresholds: the
+        other score thresholds of the run (new_thresh, pre_thresh)."""
         tag = '%s frame %d' % (self.tag, t)
         sc = od['scores'][0]
+        for th in set((out_thresh,) + tuple(thresholds)):
+            edge = float(np.abs(sc.astype(np.float64) - th).min())
+            assert edge >= TIE, ('%s: TEST DATA: an oracle score lies %.1e from the threshold %.3f (a threshold tie, see the '
+                                 'module docstring): pick another stream seed' % (tag, edge, th))
         n = int((sc >= out_thresh).sum())
         assert n >= min_dets, '%s: the synthetic stream must produce detections (%d)' % (tag, n)
         np.testing.assert_allclose(gd['scores'][gb, :n], sc[:n], atol=ATOL, err_msg=tag + ' scores')

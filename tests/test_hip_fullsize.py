@@ -46,10 +46,10 @@ def _setup(name, streams, **optkw):
     return cfg, opt, oopt, model, det, oracles, meta, px_per_cell
 
 
-def _run_config(name, streams, T, strict=False, min_tracks=5, **kw):
+def _run_config(name, streams, T, strict=False, min_tracks=5, seed0=317 + 7, **kw):
     cfg, opt, oopt, model, det, oracles, meta, ppc = _setup(name, streams, **kw)
     H, W = cfg['H'], cfg['W']
-    frames = [scrolled_stream(H, W, T, 317 + 7 + 100 * s) for s in range(streams)]
+    frames = [scrolled_stream(H, W, T, seed0 + 100 * s) for s in range(streams)]
     checks = [StreamParity('%s stream %d' % (name, s), strict=strict) for s in range(streams)]
     for t in range(T):
         res = det.step(torch.cat([frames[s][t] for s in range(streams)], 0), [dict(meta) for _ in range(streams)])
@@ -58,7 +58,8 @@ def _run_config(name, streams, T, strict=False, min_tracks=5, **kw):
             img = frames[s][t]
             want = oracles[s].run(torch.cat((img, torch.flip(img, [3])), 0) if cfg['flip'] else img, dict(meta))
             got = det.results_as_dicts(res[s], s, meta)
-            checks[s].check(t, gd, s, oracles[s].last_dets, got, want, oopt.out_thresh, ppc, min_dets=5)
+            checks[s].check(t, gd, s, oracles[s].last_dets, got, want, oopt.out_thresh, ppc, min_dets=5,
+                            thresholds=(oopt.new_thresh, oopt.pre_thresh))
     swaps = [c.finish(min_tracks=min_tracks) for c in checks]
     return checks, swaps
 
@@ -79,13 +80,16 @@ def test_kitti_1280x384_flip_two_streams_match_oracle(device):
 
 def test_coco_512_80_classes_two_streams_match_oracle(device):
     """BASELINE config 4: 80-class heat map (per-head 1x1 tail, cross-class top-K)"""
-    checks, _ = _run_config('coco_512', 2, 2)
+    # (seed 324, the other configs' stream, puts an oracle score 1.8e-6 below the 0.3 threshold in frame 0 of stream 0:
+    # a threshold tie, tests/_parity.py; with 331 every score stays >= 1.2e-3 away from it)
+    checks, _ = _run_config('coco_512', 2, 2, seed0=331)
     assert checks[0].detections > 10
 
 
 def test_nusc_800x448_3d_heads_match_oracle(device):
     """BASELINE config 5: dep / rot / dim / amodel_offset heads, 3D location and yaw in the results"""
-    _run_config('nusc_800x448', 1, 2)
+    # (stream seed 345: the default one has an oracle score 5.7e-6 from the 0.1 threshold -- a threshold tie)
+    _run_config('nusc_800x448', 1, 2, seed0=345)
 
 
 def test_two_launch_shape_choices_give_identical_ids(device, monkeypatch):

@@ -309,6 +309,39 @@ def test_dcn_with_split_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, al
     _close(out.to_nchw(), y, msg='DCN with K-split offset conv')
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k,conv_algo', [(1, 12, 20, 64, 64, 3264, 1, 202),
+                                                                 (2, 9, 21, 128, 64, 43264, 2, 206),
+                                                                 (1, 8, 8, 256, 256, 32128, 4, 0)])
+def test_dcn_with_raw_offset_sums_from_another_launch(device, N, H, W, Cin, Cout, algo, split_k, conv_algo):
+    """fuse_offset = 3: conv_offset_mask computed by a plain conv launch WITHOUT bias / sigmoid (here ct_conv2d's
+    Winograd shapes, which have no such epilogue, and the direct kernel) into one [N,H,W,32] map; the DCN launch adds
+    the bias and the mask sigmoid == upstream DCN.forward (oracle)"""
+    import ctypes
+    from centertrack_amd import _lib, ops
+    from oracle import dcn_v2 as odcn
+    lib = _lib.load()
+    x = F.relu(_rand(N, Cin, H, W, seed=150))
+    w, b = _rand(Cout, Cin, 3, 3, seed=151, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=152)
+    wo, bo = _rand(27, Cin, 3, 3, seed=153, scale=0.6 * (Cin * 9) ** -0.5), _rand(27, seed=154, scale=0.3)
+    y = odcn.dcn_forward(x, w, b, wo, bo)
+    xv = ops.view_from_nchw(x.to(device))
+    wod = wo.to(device)
+    omv = ops.new_view(N, H, W, 32, device)
+    ops.conv2d(xv, ops.pack_weight(wod), 27, 3, 1, out=omv, algo=conv_algo,
+               w_wino=ops.pack_winograd(wod) if conv_algo else None)
+    out = ops.new_view(N, H, W, Cout, device)
+    wp, bod, bd = ops.pack_weight(w.to(device)), bo.to(device), b.to(device)
+    d = ops.make_dcn_desc(xv, None, wp, Cout, None, bd, False, out, split_k=split_k, algo=algo, w_off=wp, b_off=bod,
+                          om_partial=omv.buf, raw_offsets=True)
+    assert d.fuse_offset == 3 and lib.ct_dcn_v2_offsets_bytes(ctypes.byref(d)) == N * H * W * 32 * 4
+    d.w_off_packed = None                                   # not read in this mode
+    need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))
+    ws = torch.empty(max(need, 4) // 4, device=device)
+    d.workspace, d.workspace_bytes = ws.data_ptr(), need
+    _lib.check(lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()), 'ct_dcn_v2')
+    _close(out.to_nchw(), y, msg='DCN on raw offset sums')
+
+
 def test_dcn_split_offsets_argument_errors(device):
     import ctypes
     from centertrack_amd import _lib, ops
@@ -323,7 +356,7 @@ def test_dcn_split_offsets_argument_errors(device):
     d.om_partial_bytes = 16
     assert lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()) == _lib.CT_ERR_WORKSPACE
     d.om_partial_bytes = part.numel() * 4
-    d.fuse_offset = 3
+    d.fuse_offset = 4
     assert lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()) == _lib.CT_ERR_ARG
     d.fuse_offset = 2
     assert lib.ct_dcn_v2_group(ctypes.byref(d), 1, 8, _lib.stream_ptr()) == _lib.CT_ERR_ARG

@@ -1,5 +1,2 @@
 cd $GRAFT_REPO_ROOT
-python __graft_entry__.py smoke 2>&1 | tail -1
-python -c "
-import __graft_entry__ as g
-g.build(); g.smoke()" 2>&1 | tail -1
+timeout 900 python -m pytest tests/test_hip_fullsize.py -q -m gpu -x 2>&1 | tail -4

@@ -18,6 +18,9 @@ from centertrack_amd.model import DLASegHIP  # noqa: E402
 table = autotune._read_table(autotune.PINNED_TABLE)
 shapes = sorted({tuple(int(v) for v in k.split(':')[1].split(',')) for k in table if k.startswith('dcnplan')},
                 key=lambda t: t[0] * t[1] * t[2])
+autotune._load_file()
+for k in [k for k in autotune._CACHE if k.startswith('dcnplan')]:      # (measured again below)
+    del autotune._CACHE[k]
 heads = S.HEAD_SETS['mot']
 sd = W.make_synthetic_state_dict(heads, seed=317)
 for (N, H, Wd) in shapes:
