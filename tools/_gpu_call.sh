@@ -1,2 +1,6 @@
 cd $GRAFT_REPO_ROOT
-timeout 900 python -m pytest tests/test_hip_fullsize.py -q -m gpu -x 2>&1 | tail -4
+timeout 1200 python -m pytest tests -q -m gpu 2>&1 | tail -4
+python -c "
+import __graft_entry__ as g
+g.build(); g.smoke()" 2>&1 | tail -1
+python bench.py --no-cpu-baseline 2>&1 | tail -1 | cut -c1-400
