@@ -68,3 +68,91 @@ def test_header_is_plain_c99(tmp_path):
     r = subprocess.run([gcc, '-std=c99', '-Wall', '-Wextra', '-pedantic', '-Werror', '-I' + os.path.join(root, 'include'),
                         '-fsyntax-only', str(src)], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+
+
+def test_ctypes_descriptors_match_the_header_layout(tmp_path):
+    """the ctypes mirrors of the descriptors (centertrack_amd/_lib.py) must have the size and the field offsets a C
+    compiler gives the structs of include/centertrack_hip.h (ct_dcn_desc grew in round 2: om_partial)"""
+    import shutil
+    import subprocess
+    from centertrack_amd import _lib
+    gcc = shutil.which('gcc')
+    if gcc is None:
+        pytest.skip('no gcc')
+    checks = {'ct_dcn_desc': (_lib.DcnDesc, ['x', 'om', 'w_packed', 'workspace', 'fuse_offset', 'w_off_packed', 'up_w',
+                                             'up_ldy', 'om_partial', 'om_partial_bytes']),
+              'ct_conv_desc': (_lib.ConvDesc, ['x', 'split_k', 'algo', 'w_winograd'])}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "centertrack_hip.h"', 'int main(void) {']
+    for cname, (_, fields) in checks.items():
+        lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))
+        for f in fields:
+            lines.append('printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (cname, f, cname, f))
+    lines += ['return 0; }']
+    src = tmp_path / 'lay.c'
+    src.write_text('\n'.join(lines))
+    exe = tmp_path / 'lay'
+    r = subprocess.run([gcc, '-std=c99', '-I' + os.path.join(ROOT, 'include'), str(src), '-o', str(exe)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    got = dict(l.split() for l in subprocess.run([str(exe)], capture_output=True, text=True).stdout.splitlines())
+    for cname, (cls, fields) in checks.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for f in fields:
+            assert int(got['%s.%s' % (cname, f)]) == getattr(cls, f).offset, '%s.%s' % (cname, f)
+
+
+def test_dcn_argument_validation_without_gpu(lib):
+    """make_plan rejects bad fuse_offset modes / missing buffers before anything is launched"""
+    from centertrack_amd import _lib
+    l = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    d = _lib.DcnDesc()
+    d.x = d.w_packed = d.y = d.om = p
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ldx, d.ldy, d.ldom = 1, 4, 4, 64, 64, 64, 64, 32
+    d.fuse_offset = 4
+    assert l.ct_dcn_v2(ctypes.byref(d), None) == _lib.CT_ERR_ARG and b'fuse_offset' in l.ct_last_error()
+    d.fuse_offset = 2                                          # K-split offsets without weights / bias
+    assert l.ct_dcn_v2(ctypes.byref(d), None) == _lib.CT_ERR_ARG
+    d.w_off_packed = d.b_off = p
+    assert l.ct_dcn_v2_offsets_bytes(ctypes.byref(d)) == 1 * 4 * 4 * 32 * 4
+    assert l.ct_dcn_v2(ctypes.byref(d), None) == _lib.CT_ERR_WORKSPACE      # no om_partial
+    d.fuse_offset = 3
+    assert l.ct_dcn_v2_offsets_bytes(ctypes.byref(d)) == 1 * 4 * 4 * 32 * 4
+    d.Cin = 96
+    d.fuse_offset = 1
+    assert l.ct_dcn_v2(ctypes.byref(d), None) == _lib.CT_ERR_ARG            # fused offsets need Cin % 64 == 0
+    assert l.ct_dcn_v2_group(ctypes.byref(d), 1, 0, None) == _lib.CT_ERR_ARG  # no phase named
+    assert l.ct_dcn_v2_group(ctypes.byref(d), 5, _lib.CT_DCN_MAIN, None) == _lib.CT_ERR_ARG
+
+
+def test_pinned_tune_table_is_well_formed():
+    """centertrack_amd/tune_table.json: conv entries (algo, split_k, us), DCN schedule entries `dcnplan3:N,H,W` ->
+    (fuse_max_cin, chunks_per_split, nkk, offset mode, us) with values the scheduler understands; no stale keys"""
+    import json
+    from centertrack_amd import autotune
+    with open(autotune.PINNED_TABLE) as f:
+        t = json.load(f)
+    plans = {k: v for k, v in t.items() if k.startswith('dcnplan')}
+    assert len(plans) >= 20 and all(k.startswith('dcnplan3:') for k in plans)
+    for k, v in plans.items():
+        n, h, w = (int(x) for x in k.split(':')[1].split(','))
+        assert n >= 1 and h % 32 == 0 and w % 32 == 0
+        assert len(v) == 5 and v[0] in (0, 64, 128, 256) and v[1] in (2, 4, 8) and v[2] in (2, 4) and v[3] in (1, 2), (k, v)
+        assert v[4] > 0
+    for k, v in t.items():
+        if k.startswith('conv'):
+            assert len(v) == 3 and v[2] > 0, (k, v)
+    for must in ('dcnplan3:1,512,512', 'dcnplan3:8,384,1280', 'dcnplan3:4,512,512', 'dcnplan3:4,448,800'):
+        assert must in t, must                                 # BASELINE configs 2 / 3 / 4 / 5
+
+
+def test_tools_compile():
+    import py_compile
+    tools = os.path.join(ROOT, 'tools')
+    for dirpath, _, files in os.walk(tools):
+        for fn in files:
+            if fn.endswith('.py'):
+                py_compile.compile(os.path.join(dirpath, fn), doraise=True)
+    py_compile.compile(os.path.join(ROOT, 'bench.py'), doraise=True)
+    py_compile.compile(os.path.join(ROOT, '__graft_entry__.py'), doraise=True)
