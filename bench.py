@@ -57,7 +57,7 @@ def parse():
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--frames-per-step', type=int, default=0,
                     help='consecutive frames of every stream in one step; 0 = max(4, 64 // streams)')
-    ap.add_argument('--config', default='mot17_512', help='workload name (centertrack_amd.scenarios.CONFIGS)')
+    ap.add_argument('--config', default='mot17_512', help='workload name (scenarios.CONFIGS)')
     ap.add_argument('--streams', type=int, default=0, help='streams (batch) per GPU; 0 = 1 (the headline config)')
     ap.add_argument('--height', type=int, default=0)
     ap.add_argument('--width', type=int, default=0)
@@ -226,7 +226,7 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
 
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd import weights as W
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.image import make_meta

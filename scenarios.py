@@ -8,7 +8,7 @@ from collections import OrderedDict
 import numpy as np
 import torch
 
-from . import weights as W
+from centertrack_amd import weights as W
 
 HEAD_SETS = {'mot': W.MOT_HEADS, 'kitti': W.KITTI_HEADS, 'coco': W.COCO_HEADS, 'nusc': W.NUSC_HEADS}
 
@@ -203,7 +203,7 @@ def tracker_sequences():
 
 # ----------------------------------------------------------------------------- pre-hm
 def pre_hm_cases():
-    from .image import make_meta
+    from centertrack_amd.image import make_meta
     cases = []
     rs = np.random.RandomState(5)
     for name, (ih, iw, oh, ow), flip in [('mot', (720, 1280, 512, 512), False),
@@ -240,7 +240,7 @@ def e2e_state_dict(cfg):
 def e2e_frames(cfg):
     """T frames of one synthetic stream: a fixed N(0,1) image scrolled by 4 input px/frame
     (so detections drift by one output cell) + the per-frame ``meta`` of pre_process."""
-    from .image import make_meta
+    from centertrack_amd.image import make_meta
     g = torch.Generator().manual_seed(cfg['seed'] + 7)
     base = torch.randn((3, cfg['H'], cfg['W'] + 4 * cfg['T']), generator=g, dtype=torch.float64).float()
     meta = make_meta(cfg['H'], cfg['W'], cfg['orig_h'], cfg['orig_w'], down_ratio=4)

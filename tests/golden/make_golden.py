@@ -28,8 +28,8 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from centertrack_amd import weights as W  # noqa: E402
-from centertrack_amd.scenarios import (decode_cases, make_head_maps, postprocess_cases,  # noqa: E402
-                                        tracker_sequences, e2e_config, writer_case, pose_flip_inputs)
+from scenarios import (decode_cases, make_head_maps, postprocess_cases,  # noqa: E402
+                       tracker_sequences, e2e_config, writer_case, pose_flip_inputs)
 
 torch.set_num_threads(8)
 
@@ -134,7 +134,7 @@ def gen_e2e():
     heads = cfg['heads']
     opt = ref_opt(cfg['ref_args'] + ['--input_h', str(cfg['H']), '--input_w', str(cfg['W'])],
                   heads['hm'])
-    from centertrack_amd.scenarios import e2e_state_dict
+    from scenarios import e2e_state_dict
     sd = e2e_state_dict(cfg)
     ref_detector.create_model = lambda arch, h, hc, opt=None: create_model(arch, h, hc, opt=opt)
 
@@ -143,7 +143,7 @@ def gen_e2e():
         return model
     ref_detector.load_model = fake_load
     det = ref_detector.Detector(opt)
-    from centertrack_amd.scenarios import e2e_frames
+    from scenarios import e2e_frames
     out = {'pre_hm_sums': [], 'frames': []}
     for t, (images, meta) in enumerate(e2e_frames(cfg)):
         # the PrefetchDataset dict of test.py:31-48, collated with a leading batch dim of 1
@@ -163,7 +163,7 @@ def gen_e2e():
 def gen_pre_hm():
     """reference Detector._get_additional_inputs + meta transforms"""
     import detector as ref_detector
-    from centertrack_amd.scenarios import pre_hm_cases
+    from scenarios import pre_hm_cases
     from utils.image import get_affine_transform
     out = {}
     for case in pre_hm_cases():

@@ -30,7 +30,8 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, 'tests'))
 
 from _parity import scrolled_stream  # noqa: E402
-from centertrack_amd import scenarios as S, weights as Wt  # noqa: E402
+import scenarios as S  # noqa: E402
+from centertrack_amd import weights as Wt  # noqa: E402
 from oracle import dla34  # noqa: E402
 
 B0 = -4.6

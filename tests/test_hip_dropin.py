@@ -75,7 +75,7 @@ def test_DCN_rejects_what_it_does_not_implement(device):
 
 def test_generic_decode_dropin(device):
     from types import SimpleNamespace
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.decode import generic_decode
     from oracle import decode as odecode
     assert generic_decode({'reg': torch.zeros(1, 2, 4, 4)}, 10, None) == {}

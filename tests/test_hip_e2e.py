@@ -27,7 +27,7 @@ def _check_frame(res, ref, t, tag):
 
 @pytest.mark.parametrize('use_graph,native_host', [(False, True), (True, True), (True, False)])
 def test_detector_stream_matches_reference(device, golden_dir, use_graph, native_host):
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import Detector, default_opt
     from centertrack_amd.model import DLASegHIP
     from oracle import detector as odet
@@ -64,7 +64,7 @@ def test_detector_stream_matches_reference(device, golden_dir, use_graph, native
 
 def test_batched_streams_equal_single_streams(device):
     """3 streams advanced together give, per stream, what a lone detector gives (IDs exact)."""
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.model import DLASegHIP
     cfg = S.e2e_config()
@@ -119,7 +119,7 @@ def test_run_on_raw_uint8_frames(device):
     """Detector.run(ndarray) = u8 upload + device pre-processing (ct_preprocess_device) + the hot path: the
     warped frame is bit-identical to the oracle's restatement of the pre-processing and to the host
     pre_process, and the tracks equal the oracle's and those of a detector that pre-processes on the host."""
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import MEAN, STD, Detector, default_opt
     from centertrack_amd.model import DLASegHIP
     from oracle import detector as odet, image as oimage
@@ -235,7 +235,7 @@ def test_native_host_path_serves_hungarian_public_det_and_pre_dets(device, hunga
     """--hungarian / --public_det / meta['pre_dets'] through the native host path (ct_tracker_set_mode,
     ct_tracker_step_public, ct_tracker_init_tracks) == the reference-shaped Python host path on the same frames:
     identical ids, ages, active flags, scores and boxes."""
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import Detector, default_opt
     from centertrack_amd.model import DLASegHIP
     cfg = S.e2e_config()
@@ -268,7 +268,7 @@ def test_run_on_an_image_path_equals_run_on_the_decoded_array(device, tmp_path):
     """Detector.run(path) -- test.py's --not_prefetch_test loop (test.py:163) -- decodes the file and takes the raw-frame
     path: same tracks as handing over the decoded array"""
     from PIL import Image
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import Detector, default_opt
     from centertrack_amd.model import DLASegHIP
     cfg = S.e2e_config()
@@ -293,7 +293,7 @@ def test_run_on_an_image_path_equals_run_on_the_decoded_array(device, tmp_path):
 def test_prefetched_frames_give_the_same_stream(device):
     """step(prefetch=next frame): the next frame's H2D runs on a second stream during this frame's graph; results are
     those of plain steps (ids, scores, boxes bit-identical), also when a prefetched frame is NOT the one that comes next"""
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.model import DLASegHIP
     cfg = S.e2e_config()

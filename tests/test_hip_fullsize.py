@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 
 
 def _setup(name, streams, **optkw):
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.image import make_meta
     from centertrack_amd.model import DLASegHIP
@@ -97,7 +97,7 @@ def test_two_launch_shape_choices_give_identical_ids(device, monkeypatch):
     choice.  Run the same 6-frame mot17_512 stream with the tuned plan and with the built-in heuristics (different
     conv / DCN tile shapes, different split-K): ranks above the threshold, classes and track ids must be identical up
     to enumerated score ties, values within 2e-3 of each other (1e-3 each from the truth)."""
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.image import make_meta
     from centertrack_amd.model import DLASegHIP
@@ -148,7 +148,7 @@ def test_pinned_tune_table_covers_the_baseline_configs():
     from centertrack_amd import autotune
     if not os.path.exists(autotune.PINNED_TABLE):
         pytest.skip('no pinned table committed yet')
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from centertrack_amd.model import DLASegHIP
     saved = dict(autotune._CACHE)
     autotune._CACHE.clear()                                # start from the pinned table alone
@@ -167,7 +167,8 @@ def test_pinned_tune_table_covers_the_baseline_configs():
 def test_kitti_wide_flip_batch_properties(device):
     """config 3 shape (384x1280, flip_test, 2 streams): a batch equals its streams run alone, and the heat map of
     the flip-merged output is the mean of the two passes (checked against the model run on the mirrored image)."""
-    from centertrack_amd import scenarios as S, weights as Wt
+    import scenarios as S
+    from centertrack_amd import weights as Wt
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.image import make_meta
     from centertrack_amd.model import DLASegHIP

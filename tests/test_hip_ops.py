@@ -528,7 +528,7 @@ def _decode_case(device, case, maps):
 
 
 def test_decode_matches_oracle_and_golden(device, golden_dir):
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from oracle import decode as odecode
     g = np.load(os.path.join(golden_dir, 'decode.npz'))
     for case in S.decode_cases():
@@ -553,7 +553,7 @@ def test_decode_pose_branch_variants(device, B, h, w, K, offset):
     batch 1; the oracle's per-image form extends it), the reg head as sub-pixel offset when there is no hp_offset
     head, no offset head at all (+0.5), other K.  Key points exact (they are selections), kps_score to 1e-5."""
     from collections import OrderedDict
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     from oracle import decode as odecode
     heads = OrderedDict([('hm', 1), ('wh', 2), ('hps', 34), ('hm_hp', 17)])
     if offset == 'hp_offset':
@@ -663,7 +663,8 @@ def test_render_pre_hm_matches_reference_golden(device, golden_dir):
     """device Gaussian splatting from the native tracker's blob list == the reference's
     _get_additional_inputs output (golden pre_hm.npz), incl. the flipped copy."""
     import ctypes
-    from centertrack_amd import _lib, fast_track as FT, ops, scenarios as S
+    import scenarios as S
+    from centertrack_amd import _lib, fast_track as FT, ops
     g = np.load(os.path.join(golden_dir, 'pre_hm.npz'))
     lay = FT.row_layout(ops.decode_layout(['reg', 'wh', 'tracking', 'ltrb_amodal'])[0])
     ident = np.array([[1, 0, 0], [0, 1, 0]], np.float32)
@@ -816,7 +817,7 @@ def test_flip_merge_equals_the_reference_formulas_bitwise(device, B, h, w, golde
         assert torch.equal(g_, w_), name
     if (B, h, w) == (1, 6, 10):                            # the reference's own flip_lr / flip_lr_off output
         gold = np.load(os.path.join(golden_dir, 'pose_flip.npz'))
-        from centertrack_amd import scenarios as S
+        import scenarios as S
         x = S.pose_flip_inputs()
         for name, mode in (('hm_hp', _lib.CT_FLIP_JOINTS), ('hps', _lib.CT_FLIP_JOINT_OFFSETS)):
             src = torch.cat((torch.zeros_like(x[name]), x[name]), 0).to(device)      # (0 + mirrored) / 2

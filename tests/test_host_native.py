@@ -104,7 +104,7 @@ def test_python_post_process_matches_reference_golden(golden_dir):
     import json
     import os
     import types
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     g = json.load(open(os.path.join(golden_dir, 'post_process.json')))
     for case in S.postprocess_cases():
         opt = types.SimpleNamespace(out_thresh=case['out_thresh'])
@@ -126,7 +126,7 @@ def test_python_tracker_matches_reference_golden(golden_dir):
     class, max_age re-activation, Hungarian assignment, public-detection births -- ids / ages / active flags exact."""
     import json
     import os
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     g = json.load(open(os.path.join(golden_dir, 'tracker.json')))
     names = set()
     for seq in S.tracker_sequences():
@@ -148,7 +148,7 @@ def test_native_tracker_matches_reference_golden_all_modes(golden_dir):
     tests/golden/tracker.json: ids / ages / active flags / order identical to the reference's Tracker"""
     import json
     import os
-    from centertrack_amd import scenarios as S
+    import scenarios as S
     g = json.load(open(os.path.join(golden_dir, 'tracker.json')))
     for seq in S.tracker_sequences():
         o = seq['opt']

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from centertrack_amd import scenarios as S
+import scenarios as S
 from centertrack_amd import weights as W
 from oracle import decode as odecode
 from oracle import detector as odet

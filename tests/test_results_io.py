@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 from centertrack_amd import results_io
-from centertrack_amd.scenarios import writer_case
+from scenarios import writer_case
 
 
 def _read_tree(d):

@@ -43,7 +43,8 @@ def main():
         os.environ['CENTERTRACK_DCN_KNOBS'] = args.knobs
     import numpy as np
     import torch
-    from centertrack_amd import _lib, scenarios as S, weights as W
+    import scenarios as S
+    from centertrack_amd import _lib, weights as W
     from centertrack_amd.model import DLASegHIP
     heads = S.HEAD_SETS['mot']
     model = DLASegHIP(heads)

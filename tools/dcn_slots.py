@@ -9,7 +9,8 @@ import sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch  # noqa: E402
 
-from centertrack_amd import _lib, scenarios as S, weights as W  # noqa: E402
+import scenarios as S  # noqa: E402
+from centertrack_amd import _lib, weights as W  # noqa: E402
 from centertrack_amd.model import DLASegHIP  # noqa: E402
 
 

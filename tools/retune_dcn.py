@@ -12,7 +12,8 @@ os.environ.setdefault('CENTERTRACK_TUNE_VERBOSE', '')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch  # noqa: E402
 
-from centertrack_amd import autotune, scenarios as S, weights as W  # noqa: E402
+import scenarios as S  # noqa: E402
+from centertrack_amd import autotune, weights as W  # noqa: E402
 from centertrack_amd.model import DLASegHIP  # noqa: E402
 
 table = autotune._read_table(autotune.PINNED_TABLE)
