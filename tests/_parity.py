@@ -6,11 +6,16 @@ north_star's bar, as asserted here:
     a different summation order cannot resolve those (SURVEY.md Appendix D.1), they may swap among themselves;
   * heat-map scores and every decode-level value (boxes, centres, tracking displacement, 3D heads) on the OUTPUT
     GRID: within ``ATOL`` = 1e-3 absolute (depth, an unbounded 1/sigmoid - 1: 1e-3 relative on top);
-  * image-space results (after the inverse affine): within ATOL x (image px per output cell) + fp32 slack;
+  * image-space results (after the inverse affine): within 2 x ATOL x (image px per output cell) + 2e-3 px of fp32 slack
+    -- a box edge is centre + reg -+ wh / 2 (or + an ltrb_amodal entry), i.e. up to 1.5 ATOL on the grid when every head
+    value is within ATOL;
   * a detection whose oracle score lies within ``TIE`` of a threshold (out / new-track / prior-heat-map) is a
     *threshold tie*: which side it falls on is as unresolvable as a rank tie, and since it adds or removes a result --
-    possibly a birth, shifting every later id -- the synthetic streams are chosen to contain none; ``check`` refuses a
-    stream that has one (that is a statement about the test data, made from the ORACLE's scores alone);
+    possibly a birth, shifting every later id -- the hand-picked streams of tests/test_hip_fullsize.py contain none and
+    ``check`` refuses one that does (a statement about the test data, made from the ORACLE's scores alone); the streams
+    of tests/test_hip_plans.py (default seeds, nobody picked them) are compared up to the frame before such a tie
+    (``on_threshold_tie='stop'``), and tools/tie_report.py MEASURES ties instead of avoiding them: how often they occur
+    per 1000 frames and what the HIP path does when they do (profiles/r03_tie_report.json);
   * track IDs: a consistent bijection oracle-id <-> our-id over the WHOLE stream that is the identity, except for ids
     handed out inside one birth tie group (new ids are numbered in rank order, tracker.py:104-111, so a tie swap of
     two births swaps their ids for the rest of the stream).  Every non-identity pair is enumerated and must be
@@ -24,9 +29,14 @@ GRID_FIELDS = ('bboxes', 'bboxes_amodal', 'tracking', 'rot', 'dim', 'amodel_offs
 
 
 class StreamParity(object):
-    def __init__(self, tag, strict=False):
+    def __init__(self, tag, strict=False, on_threshold_tie='refuse'):
         self.tag = tag
         self.strict = strict
+        # 'refuse': a threshold tie is a defect of the TEST DATA (hand-picked streams); 'stop': the stream is compared
+        # up to the frame before the tie and the event is recorded in ``stopped`` (streams nobody picked: the plans
+        # that are benchmarked, tools/tie_report.py measures how often this happens and what the HIP path does then)
+        self.on_threshold_tie = on_threshold_tie
+        self.stopped = None         # (frame, threshold, distance) of the threshold tie that ended the comparison
         self.id_map = {}            # oracle id -> our id
         self.rev = {}
         self.tie_ids = set()        # oracle ids born inside a tie group (the only ones allowed to map off-identity)
@@ -42,9 +52,14 @@ class StreamParity(object):
         got / want: result lists (dicts) of the frame; px_per_cell: image pixels per output-grid cell; thresholds: the
         other score thresholds of the run (new_thresh, pre_thresh)."""
         tag = '%s frame %d' % (self.tag, t)
+        if self.stopped is not None:
+            return False
         sc = od['scores'][0]
-        for th in set((out_thresh,) + tuple(thresholds)):
+        for th in sorted(set((out_thresh,) + tuple(thresholds))):
             edge = float(np.abs(sc.astype(np.float64) - th).min())
+            if edge < TIE and self.on_threshold_tie == 'stop':
+                self.stopped = (t, float(th), edge)
+                return False
             assert edge >= TIE, ('%s: TEST DATA: an oracle score lies %.1e from the threshold %.3f (a threshold tie, see the '
                                  'module docstring): pick another stream seed' % (tag, edge, th))
         n = int((sc >= out_thresh).sum())
@@ -76,7 +91,7 @@ class StreamParity(object):
                                            err_msg='%s dep of rank %d' % (tag, j))
         # ---- image-space results + track ids ----
         assert len(got) == len(want), '%s: %d results, oracle %d' % (tag, len(got), len(want))
-        tol = ATOL * px_per_cell * 2 + 2e-3
+        tol = ATOL * px_per_cell * 2 + 2e-3      # 1e-3 of a cell on either edge of a box / point pair + fp32 slack
         gbox = np.array([np.asarray(r['bbox'], np.float64) for r in got]).reshape(-1, 4)
         used = set()
         for rw in want:
@@ -107,6 +122,7 @@ class StreamParity(object):
             assert self.id_map[wid] == gid, '%s: oracle track %d is our track %d, was %d' % (tag, wid, gid, self.id_map[wid])
         self.frames += 1
         self.detections += len(want)
+        return True
 
     def finish(self, min_tracks=1):
         """every off-identity id pair must come from a birth tie group; returns the enumerated swaps"""
@@ -150,3 +166,54 @@ def calibrated_state_dict(name, heads, box_cells=6.0):
         sd['ltrb_amodal.2.bias'] = torch.tensor([-half, -half, half, half])
     sd['wh.2.bias'] = torch.tensor([box_cells, box_cells])
     return sd
+
+
+def setup_config(name, streams, **optkw):
+    """model + StreamDetector + one CPU oracle per stream for the BASELINE configuration ``name`` (scenarios.CONFIGS) with
+    ``streams`` streams per GPU: seeded random weights with the per-class heat-map calibration (scores spread, classes
+    mixed, ~20-90 detections above the threshold) and 6-cell boxes so that consecutive frames associate"""
+    import scenarios as S
+    from centertrack_amd.detector import StreamDetector, default_opt
+    from centertrack_amd.image import make_meta
+    from centertrack_amd.model import DLASegHIP
+    from oracle import detector as odet
+    cfg = S.CONFIGS[name]
+    heads = S.HEAD_SETS[cfg['heads']]
+    H, W = cfg['H'], cfg['W']
+    sd = calibrated_state_dict(name, heads)
+    kw = dict(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'])
+    kw.update(optkw)
+    opt = default_opt(heads, **kw)
+    model = DLASegHIP(heads)
+    model.load_state_dict(sd)
+    det = StreamDetector(opt, model=model, num_streams=streams)
+    oopt = odet.default_opt(input_h=H, input_w=W, num_classes=heads['hm'], **kw)
+    oracles = [odet.Detector(oopt, sd, heads) for _ in range(streams)]
+    meta = make_meta(H, W, 2 * H, 2 * W)
+    px_per_cell = 2.0 * opt.down_ratio                       # image = 2x the network input; grid = input / 4
+    return cfg, opt, oopt, model, det, oracles, meta, px_per_cell
+
+
+def run_config(name, streams, T, strict=False, min_tracks=5, seed0=317 + 7, sample=None, on_threshold_tie='refuse', **kw):
+    """``streams`` streams advance T frames through ONE StreamDetector (the launch plan of that stream count); the
+    streams in ``sample`` (default: all) are compared with the CPU oracle frame by frame.  Returns (checks, swaps, det)."""
+    import torch
+    cfg, opt, oopt, model, det, oracles, meta, ppc = setup_config(name, streams, **kw)
+    H, W = cfg['H'], cfg['W']
+    sample = list(range(streams)) if sample is None else list(sample)
+    frames = [scrolled_stream(H, W, T, seed0 + 100 * s) for s in range(streams)]
+    checks = {s: StreamParity('%s x%d stream %d' % (name, streams, s), strict=strict, on_threshold_tie=on_threshold_tie)
+              for s in sample}
+    for t in range(T):
+        res = det.step(torch.cat([frames[s][t] for s in range(streams)], 0), [dict(meta) for _ in range(streams)])
+        gd = det.last_dets
+        for s in sample:
+            if checks[s].stopped is not None:
+                continue
+            img = frames[s][t]
+            want = oracles[s].run(torch.cat((img, torch.flip(img, [3])), 0) if cfg['flip'] else img, dict(meta))
+            got = det.results_as_dicts(res[s], s, meta)
+            checks[s].check(t, gd, s, oracles[s].last_dets, got, want, oopt.out_thresh, ppc, min_dets=5,
+                            thresholds=(oopt.new_thresh, oopt.pre_thresh))
+    swaps = [checks[s].finish(min_tracks=min_tracks if checks[s].stopped is None else 0) for s in sample]
+    return [checks[s] for s in sample], swaps, det

@@ -16,51 +16,13 @@ import numpy as np
 import pytest
 import torch
 
-from _parity import StreamParity, calibrated_state_dict, scrolled_stream
+from _parity import calibrated_state_dict, run_config, scrolled_stream
 
 pytestmark = pytest.mark.gpu
 
 
-def _setup(name, streams, **optkw):
-    import scenarios as S
-    from centertrack_amd.detector import StreamDetector, default_opt
-    from centertrack_amd.image import make_meta
-    from centertrack_amd.model import DLASegHIP
-    from oracle import detector as odet
-    cfg = S.CONFIGS[name]
-    heads = S.HEAD_SETS[cfg['heads']]
-    H, W = cfg['H'], cfg['W']
-    # seeded random weights with the per-class heat-map calibration (scores spread, classes mixed, ~20-90 detections
-    # above the threshold) and 6-cell boxes so that consecutive frames associate: tests/golden/hm_calibration.json
-    sd = calibrated_state_dict(name, heads)
-    kw = dict(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'])
-    kw.update(optkw)
-    opt = default_opt(heads, **kw)
-    model = DLASegHIP(heads)
-    model.load_state_dict(sd)
-    det = StreamDetector(opt, model=model, num_streams=streams)
-    oopt = odet.default_opt(input_h=H, input_w=W, num_classes=heads['hm'], **kw)
-    oracles = [odet.Detector(oopt, sd, heads) for _ in range(streams)]
-    meta = make_meta(H, W, 2 * H, 2 * W)
-    px_per_cell = 2.0 * opt.down_ratio                       # image = 2x the network input; grid = input / 4
-    return cfg, opt, oopt, model, det, oracles, meta, px_per_cell
-
-
-def _run_config(name, streams, T, strict=False, min_tracks=5, seed0=317 + 7, **kw):
-    cfg, opt, oopt, model, det, oracles, meta, ppc = _setup(name, streams, **kw)
-    H, W = cfg['H'], cfg['W']
-    frames = [scrolled_stream(H, W, T, seed0 + 100 * s) for s in range(streams)]
-    checks = [StreamParity('%s stream %d' % (name, s), strict=strict) for s in range(streams)]
-    for t in range(T):
-        res = det.step(torch.cat([frames[s][t] for s in range(streams)], 0), [dict(meta) for _ in range(streams)])
-        gd = det.last_dets
-        for s in range(streams):
-            img = frames[s][t]
-            want = oracles[s].run(torch.cat((img, torch.flip(img, [3])), 0) if cfg['flip'] else img, dict(meta))
-            got = det.results_as_dicts(res[s], s, meta)
-            checks[s].check(t, gd, s, oracles[s].last_dets, got, want, oopt.out_thresh, ppc, min_dets=5,
-                            thresholds=(oopt.new_thresh, oopt.pre_thresh))
-    swaps = [c.finish(min_tracks=min_tracks) for c in checks]
+def _run_config(name, streams, T, **kw):
+    checks, swaps, _ = run_config(name, streams, T, **kw)
     return checks, swaps
 
 
