@@ -48,6 +48,7 @@ import torch  # noqa: E402
 
 PEAK_FP32_TFLOPS = 157.3      # MI355X_MICROARCH.md: fp32 MFMA = vector peak
 PEAK_HBM_GBS = 8000.0
+SWEEP_FRAMES = 5             # timed frames per thread count of the cpu_baseline sweep
 
 
 def parse():
@@ -66,7 +67,7 @@ def parse():
     ap.add_argument('--no-roofline', action='store_true')
     ap.add_argument('--no-resident', action='store_true', help='skip the extra resident-frames loop')
     ap.add_argument('--cpu-frames', type=int, default=20)
-    ap.add_argument('--cpu-threads', default='8,16,32,64', help='thread counts of the CPU-baseline sweep')
+    ap.add_argument('--cpu-threads', default='8,16,32', help='thread counts of the CPU-baseline sweep')
     ap.add_argument('--hm-gain', type=float, default=11.0)
     ap.add_argument('--raw-u8', action='store_true',
                     help='also report the rate with raw u8 1080p frames handed to step() (u8 H2D + device-side '
@@ -117,7 +118,7 @@ def kernel_pass(model, plan, reps=10):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        flops = flops_main = bytes_ = 0.0
+        flops = flops_main = bytes_ = bytes_up = 0.0
         nlayers = 0
         for l in launches:
             if l.fn == 'dcn_group':
@@ -130,6 +131,8 @@ def kernel_pass(model, plan, reps=10):
                     flops_main += 2.0 * 9 * d.Cin * d.Cout * hw
                     flops += 2.0 * 9 * d.Cin * d.Cout * hw + 2.0 * 9 * d.Cin * 27 * hw      # main + offset/mask conv
                     bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout + 9 * d.Cin * 27 + 27)
+                    if d.up_w:          # the IDAUp step the finishing launch of a `proj` layer carries (dla.py:543-545):
+                        bytes_up += 4.0 * 2 * d.Cout * hw * d.up_f * d.up_f        # skip tensor read + result written
             elif l.fn == 'heads':        # conv3x3 64 -> 256 + conv1x1 256 -> c of every fused head
                 d = l.args
                 hw = d.N * d.H * d.W
@@ -144,7 +147,8 @@ def kernel_pass(model, plan, reps=10):
                 flops += 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)
         if kind == 'dcn':
-            stats[kind] = dict(launches=len(launches), layers=nlayers, flops=flops, flops_main=flops_main, bytes=bytes_, ms=ms)
+            stats[kind] = dict(launches=len(launches), layers=nlayers, flops=flops, flops_main=flops_main, bytes=bytes_,
+                               bytes_idaup=bytes_up, ms=ms)
             continue
         stats[kind] = dict(launches=len(launches), flops=flops, flops_main=flops_main, bytes=bytes_, ms=ms)
     return stats
@@ -162,6 +166,51 @@ def pmc_traffic():
         return None, None
 
 
+def profiled_dcn():
+    """DCN device time per frame as the committed rocprofv3 kernel trace of this round saw it (profiles/dcn_profiled.json,
+    written by tools/dcn_profiled.py from the `--kernel-trace --stats` table of the same bench command): lets a reader
+    reproduce ``frac`` from profiles/ alone, next to the live HIP-event figure of this process."""
+    p = os.path.join(ROOT, 'profiles', 'dcn_profiled.json')
+    try:
+        with open(p) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
+def box_calibration(device):
+    """What class of box produced this line (the MI355X boxes of the pool differ by 5-15 % on memory-side kernels):
+    sustained fp32 MFMA rate of a pure v_mfma_f32_16x16x4_f32 loop (ct_calib_mfma, 2 workgroups per CU) and the
+    device-to-device copy bandwidth of a 1 GiB and a 16 MiB (L2 / MALL resident) buffer, HIP events on the launch stream."""
+    import ctypes
+    from centertrack_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream_ptr()
+    out = torch.zeros(1 << 20, device=device)
+
+    def timed(fn, reps=1):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps
+    iters, blocks = 50000, 512
+    ms = timed(lambda: lib.ct_calib_mfma(blocks, iters, ctypes.c_void_p(out.data_ptr()), st))
+    mfma = blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 4 / ms / 1e9
+    a = torch.empty(1 << 28, device=device)
+    b = torch.empty(1 << 28, device=device)
+    d2d = 2.0 * a.numel() * 4 / timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), a.numel() * 4, 0, st), 5) / 1e6
+    n = 1 << 22
+    d2d_small = 2.0 * n * 4 / timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), n * 4, 0, st), 50) / 1e6
+    del a, b
+    return {'device': torch.cuda.get_device_name(device), 'mfma_f32_tflops': round(mfma, 1),
+            'd2d_1GiB_GBps': round(d2d), 'd2d_16MiB_GBps': round(d2d_small)}
+
+
 def cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -174,7 +223,7 @@ def cpu_model():
 
 
 def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
-    """CPU oracle (port of the reference CPU path) on the same workload, bounded sample: a thread sweep (1 warm-up + 2
+    """CPU oracle (port of the reference CPU path) on the same workload, bounded sample: a thread sweep (1 warm-up + 5
     timed frames per thread count), then ``nframes`` frames after 3 warm-ups at the best count."""
     from oracle import detector as odet
     oopt = odet.default_opt(input_h=cfg['H'], input_w=cfg['W'], num_classes=heads['hm'], **opt_kw)
@@ -197,7 +246,7 @@ def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
             torch.set_num_threads(t)
             det.reset_tracking()
             run(1, 0)
-            per_thread[t] = round(2 / run(2, 1), 3)
+            per_thread[t] = round(SWEEP_FRAMES / run(SWEEP_FRAMES, 1), 3)
         best = max(per_thread, key=per_thread.get)
         torch.set_num_threads(best)
         det.reset_tracking()
@@ -207,9 +256,9 @@ def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
         torch.set_num_threads(saved)
     return dict(value=round(fps, 4), unit='frames/s', cores=best, kind='port', cpu=cpu_model(), host_cpus=ncpu,
                 thread_sweep_fps=per_thread,
-                sample='%d frames of the N=1 workload (1 stream, %dx%d) through oracle/detector.py after 3 warm-up '
-                       'frames at the best thread count of the sweep (1 warm-up + 2 timed frames per count); '
-                       'pure-PyTorch CPU restatement of the reference path incl. DCNv2' % (nframes, cfg['H'], cfg['W']))
+                sample='%d frames of the N=1 workload (1 stream, %dx%d) through oracle/detector.py after 3 warm-up ' % (nframes, cfg['H'], cfg['W']) +
+                       'frames at the best thread count of the sweep (1 warm-up + %d timed frames per count); ' % SWEEP_FRAMES +
+                       'pure-PyTorch CPU restatement of the reference path incl. DCNv2')
 
 
 def main():
@@ -262,21 +311,34 @@ def main():
     total_streams = B * world
     gatherer = None
     last = {}
+    K, F = det_rows_shape(det, cfg)
+    # every rank must replay the same fp32 summation orders: compare the plans before anything is timed
+    plan_hash = parallel.check_same_plan(DLASegHIP.plan_signature(det._ctx['plan']))
     if world > 1:
-        K, F = det_rows_shape(det, cfg)
-        gatherer = parallel.DetectionGatherer(total_streams, world, rank, K, F, device)
+        gatherer = parallel.DetectionGatherer(total_streams, world, rank, K, F, device, overlap=True)
+        score_col = [st for name, st, _ in det._ctx['decoder'].layout if name == 'scores'][0]
 
         def gather(rows):
+            # the block of the PREVIOUS frame is complete by now (its collective ran beside the host work of that
+            # frame): consume it -- count the detections of ALL streams -- then enqueue this frame's gather on the side
+            # stream; the returned event keeps the next graph launch from overwriting the rows too early
+            gatherer.consume(score_col, opt.out_thresh)
             last['rows'] = rows
-            last['all'] = gatherer(rows)
+            gatherer(rows)
+            return gatherer.rows_free
         det.gather_fn = gather
 
     def timed(frame_of, steps, first=0):
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
+        if gatherer is not None:
+            gatherer.consume(score_col, opt.out_thresh)      # (flush the block of the last untimed frame)
+            gatherer.consumed_steps = gatherer.consumed_detections = 0
         t0 = time.perf_counter()
         nfr, ndet = parallel.run_steps(det, frame_of, metas, steps, fps_step, first)
+        if gatherer is not None:
+            gatherer.consume(score_col, opt.out_thresh)      # the last frame's block (host-synchronous)
         torch.cuda.synchronize()
         parallel.barrier()
         torch.cuda.synchronize()
@@ -287,8 +349,14 @@ def main():
     dt, nfr, ndet = timed(host_frame, args.steps, args.warmup * fps_step)
     fps = total_streams * nfr / dt
     rccl_ranks = 1
+    gathered = None
     if gatherer is not None:                         # outside the timed region: prove what the collective moved
         rccl_ranks = gatherer.verify(last['rows'])
+        # the blocks consumed inside the timed loop carried every rank's detections: the count rank 0 made from them
+        # equals the sum of what the ranks' own trackers were handed (decode rows above out_thresh)
+        gathered = {'steps_consumed': gatherer.consumed_steps, 'detections_counted_from_blocks': gatherer.consumed_detections,
+                    'sum_of_rank_local_results': parallel.sum_over_ranks(ndet)}
+        gathered['equal'] = gathered['detections_counted_from_blocks'] == gathered['sum_of_rank_local_results']
 
     out = {
         'metric': 'frames/sec (DLA-34 + DCNv2 CenterTrack hot path: H2D of the frame + forward + decode + D2H + '
@@ -306,7 +374,10 @@ def main():
                    'mean_detections_per_frame': round(ndet / max(1, nfr * B), 1)},
         'fps_per_gpu': round(fps / world, 2), 'ms_per_frame_batch': round(1000.0 * dt / max(1, nfr), 4),
         'timed_region_s': round(dt, 3), 'h2d_in_timed_region': True, 'h2d_overlaps_previous_frame': True, 'rccl_ranks': rccl_ranks,
+        'plan_hash': plan_hash,
     }
+    if gathered is not None:
+        out['gathered'] = gathered
     if not args.no_resident:
         frames = [f.to(device) for f in frames_cpu]
         dt2, nfr2, _ = timed(lambda t: frames[t % T], args.steps)
@@ -327,6 +398,11 @@ def main():
         torch.cuda.synchronize()
         dev_ms = e0.elapsed_time(e1) / reps
         out['device_ms_per_frame_batch'] = round(dev_ms, 4)
+        out['host_gap_ms_per_frame_batch'] = round(1000.0 * dt / max(1, nfr) - dev_ms, 4)     # wall - device
+        try:
+            out['box_calibration'] = box_calibration(device)
+        except Exception as e:
+            out['box_calibration'] = {'error': repr(e)}
         out['launches_per_frame'] = len(ctx['plan']['launches'])
         if not args.no_roofline:
             st = kernel_pass(det.model, ctx['plan'])
@@ -345,7 +421,14 @@ def main():
                                'avg_launch_us': round(1000.0 * d['ms'] / nl, 2),
                                'hbm': {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': round(gbs / PEAK_HBM_GBS, 4),
-                                       'algorithmic_bytes_per_launch': round(d['bytes'] / nl)}}
+                                       'algorithmic_bytes_per_launch': round(d['bytes'] / nl),
+                                       # the finishing launches of the 8 `proj` layers also carry the IDAUp step
+                                       # (skip tensor read + result written, dla.py:543-545): what `traffic` has to
+                                       # be read against
+                                       'algorithmic_bytes_per_launch_with_idaup': round((d['bytes'] + d['bytes_idaup']) / nl)}}
+            prof = profiled_dcn()
+            if prof is not None and B == 1 and args.config == 'mot17_512' and not args.height and not args.width:
+                out['roofline']['profiled'] = prof
             c = st['conv']
             ctf = c['flops'] / (c['ms'] * 1e-3) / 1e12
             out['roofline_conv'] = {'kernel': 'conv_mfma / wino_conv kernels (%d dense conv launches incl. the fused heads)' % c['launches'], 'bound': 'mfma',
@@ -357,6 +440,8 @@ def main():
                 if tb is not None:
                     out['roofline']['traffic'] = round(tb)
                     out['roofline']['traffic_source'] = src
+                    out['roofline']['traffic_over_algorithmic'] = round(
+                        tb / out['roofline']['hbm']['algorithmic_bytes_per_launch_with_idaup'], 2)
         if args.raw_u8 and world == 1:
             # raw u8 1080p frames handed to step(): u8 H2D + warp / normalise on the device
             det2 = StreamDetector(opt, model=model, num_streams=B, use_graph=not args.no_graph)

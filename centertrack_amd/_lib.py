@@ -122,7 +122,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
            'ct_tracker_step_public', 'ct_tracker_step_dets', 'ct_transform_points',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
-           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_flip_merge', 'ct_flip_images']
+           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_flip_merge', 'ct_flip_images']
 
 _lib = None
 
@@ -209,6 +209,7 @@ def load():
     lib.ct_memcpy_async.argtypes = [p, p, sz, i, p]
     lib.ct_stream_synchronize.argtypes = [p]
     lib.ct_memset_async.argtypes = [p, i, sz, p]
+    lib.ct_calib_mfma.argtypes = [i, i, p, p]
     lib.ct_flip_merge.argtypes = [ctypes.POINTER(FlipHead), i, p, i, i, i, i, p]
     lib.ct_flip_images.argtypes = [p, p, sz, i, p]
     # CENTERTRACK_TUNE="key=value,key=value": launch-heuristic knobs of ct_set_tuning (A/B runs)

@@ -79,3 +79,30 @@ extern "C" int ct_stream_synchronize(void *stream)
     }
     return CT_OK;
 }
+
+// ---- box calibration: a pure MFMA loop (2 accumulator chains per wave, no memory traffic) ----
+__global__ __launch_bounds__(256) void calib_mfma_kernel(int iters, float *out)
+{
+    f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = acc0;
+    const f32x4 b = f32x4{1.f, 1.0001f, 0.9999f, 1.0002f};
+    const f32x4 a0 = f32x4{1.f, 2.f, 3.f, 4.f} * (1.0f + threadIdx.x * 1e-6f), a1 = a0 * 0.5f;
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(a0[e], b[e], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(a1[e], b[e], acc1, 0, 0, 0);
+            }
+    }
+    const f32x4 s = acc0 + acc1;
+    if (s[0] == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = s[1] + s[2] + s[3];
+}
+
+extern "C" int ct_calib_mfma(int blocks, int iters, float *out, void *stream)
+{
+    if (blocks <= 0 || iters <= 0 || !out) CT_FAIL_ARG("ct_calib_mfma: bad arguments");
+    hipLaunchKernelGGL(calib_mfma_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, iters, out);
+    CT_CHECK_LAUNCH("ct_calib_mfma");
+    return CT_OK;
+}

@@ -163,7 +163,12 @@ class StreamDetector(object):
         self._lut = torch.from_numpy(lut).to(self.device)
         self._raw_bufs = {}
         self._carried = {}         # per stream: extras (3D fields) of tracks kept alive without a detection
-        self.gather_fn = None      # optional hook: called with the packed device rows [B,K,F] (multi-GPU all-gather)
+        # optional hook: called with the packed device rows [B,K,F] right after the frame was launched (multi-GPU
+        # all-gather, parallel.DetectionGatherer).  It may return a CUDA event after which the rows have been read: the
+        # next frame's launch (which overwrites them) then waits for it on the device, so the hook is free to read the
+        # rows from a side stream
+        self.gather_fn = None
+        self._rows_free = None
         self._ctx = None
 
     # ---- per-shape device context (static buffers + captured graph) ----------------------
@@ -418,6 +423,9 @@ class StreamDetector(object):
             for s in range(B):
                 self.started[s] = True
         t1 = time.time()
+        if self._rows_free is not None:                        # (a side-stream reader of the previous frame's rows)
+            cur.wait_event(self._rows_free)
+            self._rows_free = None
         if ctx['raw']:
             ctx['graphs'][par].replay(sp)
         elif ctx['graphs'][par] is not None:
@@ -443,7 +451,8 @@ class StreamDetector(object):
             ev.record(cs)                                      #  recording was enqueued at the top of this step)
             self._prefetched = ((prefetch.data_ptr(), tuple(prefetch.shape)), ev)
         if self.gather_fn is not None:
-            self.gather_fn(ctx['decoder'].out)
+            ev = self.gather_fn(ctx['decoder'].out)
+            self._rows_free = ev if isinstance(ev, torch.cuda.Event) else None
         if ctx['raw']:                                         # (the D2H of the rows is the graph's last node)
             _lib.check(lib.ct_stream_synchronize(sp), 'ct_stream_synchronize')
         else:

@@ -632,6 +632,23 @@ class DLASegHIP(torch.nn.Module):
         autotune._save_file()
         return best[1], self._schedule_dcn(layers, produced0, N, dev, best[1])
 
+    @staticmethod
+    def plan_signature(plan):
+        """Everything of a plan that fixes the fp32 summation order, as one string: per launch its name, kernel choice
+        (algo) and split-K, the per-layer DCN tile / split / offset mode, the DCN schedule knobs.  Ranks of a multi-GPU
+        job compare its hash (parallel.check_same_plan) before they start."""
+        parts = ['dcn_knobs=%s' % (tuple(plan.get('dcn_knobs', ())),)]
+        for l in plan['launches']:
+            if l.fn == 'conv':
+                parts.append('%s:conv:%d:%d' % (l.name, int(l.args.algo), int(l.args.split_k)))
+            elif l.fn == 'dcn_group':
+                arr, n, phases = l.args
+                parts.append('%s:dcn:%d:%s' % (l.name, phases, ','.join(
+                    '%d/%d/%d' % (int(arr[j].algo), int(arr[j].split_k), int(arr[j].fuse_offset)) for j in range(n))))
+            else:
+                parts.append('%s:%s' % (l.name, l.fn))
+        return ';'.join(parts)
+
     def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False):
         key = (N, H, W, with_img, with_hm, fuse_sigmoid)
         if key not in self._plans:

@@ -6,7 +6,15 @@ shards by *stream*: rank r owns streams {s : s mod G == r}, holds a full weight 
 (79.8 MB) and its streams' tracker state.  There is no activation exchange; the only
 collective is ONE all-gather per step of the packed decode rows ([K, F] floats per
 stream, 4-10 KB) over RCCL/xGMI (torch.distributed backend "nccl"), latency-bound by
-construction.  On CPU the same code runs over gloo (tests, world_size 2)."""
+construction.  On CPU the same code runs over gloo (tests, world_size 2).
+
+Round 3 (multi-GPU readiness): ranks prove at start-up that they built IDENTICAL launch plans
+(``check_same_plan``: tile shapes, split-K and DCN schedule knobs fix the fp32 summation order, so a rank with a stale
+tuning cache would silently produce other last bits); the all-gather runs on a SIDE stream and lands in pinned host
+memory, so it overlaps the next frame's launch and host work instead of sitting between graph launch and stream sync;
+the gathered block is CONSUMED every step (``DetectionGatherer.consume``: detections of all streams counted on the host
+from the block of the previous step), and the count is cross-checked against the ranks' own counts after the loop."""
+import hashlib
 import os
 
 import torch
@@ -36,37 +44,128 @@ def shard_streams(num_streams, rank, world):
     return [s for s in range(num_streams) if s % world == rank]
 
 
+def check_same_plan(signature, what='launch plan'):
+    """Every rank hashes ``signature`` (a string that pins the fp32 summation order of its plan: per launch the tile
+    shape / algo / split-K, the DCN schedule knobs -- ``DLASegHIP.plan_signature``); the hashes are all-gathered and a
+    mismatch raises on EVERY rank, naming the ranks that differ from rank 0.  Returns the hex digest."""
+    digest = hashlib.sha256(signature.encode()).digest()
+    hexd = digest[:8].hex()
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return hexd
+    world = dist.get_world_size()
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    mine = torch.tensor([int.from_bytes(digest[0:7], 'little'), int.from_bytes(digest[7:14], 'little')],
+                        dtype=torch.int64, device=dev)
+    allh = torch.zeros(2 * world, dtype=torch.int64, device=dev)
+    dist.all_gather_into_tensor(allh, mine)
+    allh = allh.view(world, 2).tolist()
+    bad = [r for r in range(world) if allh[r] != allh[0]]
+    if bad:
+        raise RuntimeError('%s differs between ranks: rank(s) %s built another plan than rank 0 (stale '
+                           'CENTERTRACK_TUNE_CACHE / CENTERTRACK_DCN_KNOBS on that rank?); identical fp32 summation '
+                           'orders on every rank need identical plans' % (what, bad))
+    return hexd
+
+
 class DetectionGatherer(object):
     """The one exchange step of the sharded path: all-gather of the packed decode rows, with every buffer
     allocated ONCE (send [per,K,F], recv [world*per,K,F], the globally ordered result [num_streams,K,F]) so that a
     step enqueues exactly one copy-in, one ``all_gather_into_tensor`` and one reorder copy -- no allocation and no
     per-stream Python loop per frame.  Round-robin ownership (``shard_streams``) makes the reorder a transpose:
     global stream s = j*world + r is row j of rank r, i.e. ``out = recv.view(world, per, K, F).transpose(0, 1)``.
-    ``steps`` / ``last`` let the caller verify afterwards what was exchanged (``checksums``)."""
+    ``steps`` / ``last`` let the caller verify afterwards what was exchanged (``checksums``).
 
-    def __init__(self, num_streams, world, rank, K, F, device, dtype=torch.float32):
+    ``overlap`` (CUDA only): the three operations are enqueued on a side stream behind an event of the producing
+    stream, the reorder copy goes straight to PINNED HOST memory (two blocks, ping-pong), and ``__call__`` returns
+    immediately: the collective of frame t runs beside the host work and the launch of frame t+1.  The producer must
+    not overwrite ``local_rows`` before the copy-in ran: ``rows_free`` is the event to wait for (StreamDetector does,
+    before its next graph launch).  ``consume()`` hands out the block of the PREVIOUS call (complete by then) as a
+    numpy view."""
+
+    def __init__(self, num_streams, world, rank, K, F, device, dtype=torch.float32, overlap=False):
         self.num_streams, self.world, self.rank = num_streams, world, rank
         self.per = (num_streams + world - 1) // world
         self.n_local = len(shard_streams(num_streams, rank, world))
+        device = torch.device(device)
         self.send = torch.zeros((self.per, K, F), dtype=dtype, device=device)
         self.recv = torch.zeros((world * self.per, K, F), dtype=dtype, device=device)
         self.out = torch.zeros((world * self.per, K, F), dtype=dtype, device=device)
         self.steps = 0
+        self.overlap = bool(overlap) and device.type == 'cuda'
+        self.consumed_steps = 0
+        self.consumed_detections = 0
+        self._pending = None                      # index of the host block the last call is filling
+        if self.overlap:
+            self.side = torch.cuda.Stream(device=device)
+            self.host = [torch.zeros((world * self.per, K, F), dtype=dtype).pin_memory() for _ in range(2)]
+            self.done = [torch.cuda.Event(), torch.cuda.Event()]
+            self.rows_ready = torch.cuda.Event()
+            self.rows_free = torch.cuda.Event()
+        else:
+            self.host = [None, None]
+            self.rows_free = None
 
     def __call__(self, local_rows):
         """``local_rows``: [n_local, K, F] rows of this rank's streams (ascending global id).  Returns the
-        [num_streams, K, F] block ordered by global stream id (a view of a reused buffer)."""
+        [num_streams, K, F] block ordered by global stream id (a view of a reused buffer; with ``overlap`` the view is
+        only valid once ``wait()`` returned)."""
         if local_rows.shape[0] != self.n_local:
             raise ValueError('rank %d owns %d streams, got %d row blocks' % (self.rank, self.n_local, local_rows.shape[0]))
         self.steps += 1
-        if self.world == 1:
-            self.out[:self.n_local].copy_(local_rows)
-            return self.out[:self.num_streams]
-        self.send[:self.n_local].copy_(local_rows)
-        dist.all_gather_into_tensor(self.recv, self.send)
         K, F = self.send.shape[1:]
-        self.out.view(self.per, self.world, K, F).copy_(self.recv.view(self.world, self.per, K, F).transpose(0, 1))
+        if not self.overlap:
+            if self.world == 1:
+                self.out[:self.n_local].copy_(local_rows)
+            else:
+                self.send[:self.n_local].copy_(local_rows)
+                dist.all_gather_into_tensor(self.recv, self.send)
+                self.out.view(self.per, self.world, K, F).copy_(self.recv.view(self.world, self.per, K, F).transpose(0, 1))
+            self._pending = -1
+            return self.out[:self.num_streams]
+        cur = torch.cuda.current_stream()
+        self.rows_ready.record(cur)
+        slot = self.steps & 1
+        with torch.cuda.stream(self.side):
+            self.side.wait_event(self.rows_ready)
+            if self.world == 1:
+                self.out[:self.n_local].copy_(local_rows, non_blocking=True)
+                self.rows_free.record(self.side)
+            else:
+                self.send[:self.n_local].copy_(local_rows, non_blocking=True)
+                self.rows_free.record(self.side)
+                dist.all_gather_into_tensor(self.recv, self.send)
+                self.out.view(self.per, self.world, K, F).copy_(self.recv.view(self.world, self.per, K, F).transpose(0, 1))
+            self.host[slot].copy_(self.out, non_blocking=True)
+            self.done[slot].record(self.side)
+        self._pending = slot
         return self.out[:self.num_streams]
+
+    def wait(self):
+        """block the host until the last enqueued gather (and its host copy) finished"""
+        if self.overlap and self._pending is not None and self._pending >= 0:
+            self.done[self._pending].synchronize()
+
+    def host_block(self):
+        """the block of the last call as numpy [num_streams, K, F] (host-synchronous: waits for that call)"""
+        if self._pending is None:
+            return None
+        if self.overlap:
+            self.wait()
+            return self.host[self._pending].numpy()[:self.num_streams]
+        return self.out[:self.num_streams].cpu().numpy()
+
+    def consume(self, score_col=0, thresh=0.0):
+        """Use the block of the last call on the host: count the detections of ALL streams whose score exceeds
+        ``thresh`` (what a rank-0 result writer would keep).  Called right before the next step's gather is enqueued,
+        i.e. one step after its collective: the wait is a no-op in steady state.  Returns the count."""
+        blk = self.host_block()
+        if blk is None:
+            return 0
+        n = int((blk[:, :, score_col] > thresh).sum())
+        self.consumed_steps += 1
+        self.consumed_detections += n
+        self._pending = None
+        return n
 
     @staticmethod
     def _bits_sum(t, dims=None):
@@ -87,6 +186,9 @@ class DetectionGatherer(object):
         """After a step: every rank's block in the gathered result must carry the checksum that rank computed over
         its own rows (exchanged with one more small all-gather), and the reordered block must hold this rank's rows
         at its global stream ids.  Returns the number of ranks in the RCCL / gloo group; raises on a mismatch."""
+        self.wait()
+        if self.overlap:
+            torch.cuda.current_stream().wait_stream(self.side)
         mine, blocks = self.checksums(local_rows)
         ids = shard_streams(self.num_streams, self.rank, self.world)
         if ids and not torch.equal(self.out[ids], local_rows.to(self.out.dtype)):
@@ -133,6 +235,16 @@ def run_steps(det, frame_of, metas, steps, frames_per_step, first=0):
             ndet += sum(len(r) for r in res)
             t += 1
     return t - first, ndet
+
+
+def sum_over_ranks(value):
+    """sum of a python int over ranks"""
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(value)
+    dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def barrier():

@@ -340,6 +340,10 @@ void ct_graph_destroy(void *graph_exec);
 int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kind /*0 D2D, 1 H2D, 2 D2H*/, void *stream);
 int ct_memset_async(void *dst, int value, size_t bytes, void *stream);      /* DEVICE memory (zero_tracking) */
 int ct_stream_synchronize(void *stream);
+/* Box calibration (diagnostics; no reference equivalent): `blocks` workgroups of 4 waves each run `iters` rounds of 16
+ * independent-chain v_mfma_f32_16x16x4_f32 on registers -- the sustained fp32 MFMA rate of the box a bench line was
+ * measured on (bench.py's "box_calibration").  out: DEVICE float[>= blocks * 256] (never written in practice). */
+int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
 
 /* ---- image pre-processing (CPU, like the reference's: it runs in DataLoader worker processes) -----
  * Replaces the cv2.warpAffine + normalise + HWC->CHW (+ flipped copy) of Detector.pre_process

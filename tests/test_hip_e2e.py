@@ -312,3 +312,50 @@ def test_prefetched_frames_give_the_same_stream(device):
         assert len(ra) == len(rb) > 0
         for k in ('tracking_id', 'score', 'bbox', 'ct'):
             np.testing.assert_array_equal(ra[k], rb[k])
+
+
+def test_side_stream_gather_hook_consumes_every_frame(device):
+    """bench.py's multi-GPU hook at world size 1 on the device: the packed rows are read on a SIDE stream (copy-in,
+    all-gather stand-in, pinned host block), the next graph launch waits for ``rows_free``, and the block consumed one
+    step later holds exactly the detections the tracker was handed."""
+    import scenarios as S
+    from centertrack_amd import parallel
+    from centertrack_amd.detector import StreamDetector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    cfg = S.e2e_config()
+    sd = S.e2e_state_dict(cfg)
+    opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    frames = list(S.e2e_frames(cfg))
+    B = 2
+    plain = StreamDetector(opt, model=model, num_streams=B)
+    hooked = StreamDetector(opt, model=model, num_streams=B)
+    ctx = hooked._context(cfg['H'], cfg['W'])
+    K, F = ctx['decoder'].out.shape[1:]
+    g = parallel.DetectionGatherer(B, 1, 0, int(K), int(F), device, overlap=True)
+    assert g.overlap
+    score_col = [st for name, st, _ in ctx['decoder'].layout if name == 'scores'][0]
+    counts = []
+
+    def hook(rows):
+        if g.steps:
+            counts.append(g.consume(score_col, opt.out_thresh))
+        g(rows)
+        return g.rows_free
+    hooked.gather_fn = hook
+    want_counts = []
+    for t in range(len(frames)):
+        imgs = torch.cat([frames[t][0], frames[(t + 1) % len(frames)][0]], 0)
+        metas = [dict(frames[t][1]) for _ in range(B)]
+        a = plain.step(imgs, [dict(m) for m in metas])
+        b = hooked.step(imgs, metas)
+        for s in range(B):
+            np.testing.assert_array_equal(a[s]['tracking_id'], b[s]['tracking_id'])
+            np.testing.assert_array_equal(a[s]['score'], b[s]['score'])
+        want_counts.append(sum(len(r) for r in b))
+        np.testing.assert_array_equal(g.host_block(), hooked._ctx['host_rows'])       # the block IS this frame's rows
+    counts.append(g.consume(score_col, opt.out_thresh))
+    assert counts == want_counts and g.consumed_steps == len(frames)
+    assert g.verify(hooked._ctx['decoder'].out) == 1
+    assert len(parallel.check_same_plan(DLASegHIP.plan_signature(ctx['plan']))) == 16

@@ -169,3 +169,89 @@ def test_gatherer_single_rank_verifies_and_reuses_buffers():
         g.verify(x)                                        # the block now holds 2x: checksum mismatch
     with pytest.raises(ValueError):
         g(x[:2])
+
+
+# --------------------------------------------------------------------------------------------------
+# round 3: plan-consistency check across ranks, the gathered block consumed inside the loop
+def _plan_check_worker(rank, world, port, same, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from centertrack_amd import parallel
+    parallel.init_from_env(backend='gloo')
+    sig = 'dcn_knobs=(128, 4, 4, 1);level0:conv:104:1' if (same or rank == 0) else 'dcn_knobs=(0, 8, 2, 2);level0:conv:104:1'
+    try:
+        q.put((rank, 'ok', parallel.check_same_plan(sig)))
+    except RuntimeError as e:
+        q.put((rank, 'raised', str(e)))
+    parallel.barrier()
+    torch.distributed.destroy_process_group()
+
+
+@pytest.mark.parametrize('same', [True, False])
+def test_ranks_compare_their_launch_plans_before_they_start(same):
+    world = 2
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_plan_check_worker, args=(r, world, port, same, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if same:
+        assert [g[1] for g in got] == ['ok', 'ok'] and got[0][2] == got[1][2]
+    else:                                                  # EVERY rank raises, and names the rank that differs
+        assert [g[1] for g in got] == ['raised', 'raised']
+        assert all('rank(s) [1]' in g[2] for g in got)
+
+
+def test_plan_check_single_process_returns_a_digest():
+    from centertrack_amd import parallel
+    a, b = parallel.check_same_plan('x'), parallel.check_same_plan('y')
+    assert a != b and len(a) == 16
+
+
+def _consume_worker(rank, world, port, num_streams, K, F, q):
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR='127.0.0.1',
+                      MASTER_PORT=str(port))
+    from centertrack_amd import parallel
+    parallel.init_from_env(backend='gloo')
+    ids = parallel.shard_streams(num_streams, rank, world)
+    det = _FakeDetector(ids, K, F)
+    gatherer = parallel.DetectionGatherer(num_streams, world, rank, K, F, torch.device('cpu'), overlap=True)
+    assert not gatherer.overlap                            # (no side stream on a CPU device: same call sequence, inline)
+    thresh = 0.5
+
+    def gather(rows):                                      # exactly bench.py's round-3 hook
+        gatherer.consume(0, thresh)                        # the previous frame's block
+        gatherer(rows)
+        return gatherer.rows_free
+    det.gather_fn = gather
+    frames = [torch.full((len(ids), 3, 4, 4), 1.0) for _ in range(3)]
+    nfr, _ = parallel.run_steps(det, lambda t: frames[t % 3], [None] * len(ids), steps=2, frames_per_step=2)
+    gatherer.consume(0, thresh)                            # the last frame's
+    # what every rank must have counted: detections above the threshold of ALL streams over the 4 frames
+    want = sum(int((_FakeDetector.rows_of(s, t, K, F, 1.0)[:, 0] > thresh).sum()) for s in range(num_streams) for t in range(nfr))
+    local = sum(int((_FakeDetector.rows_of(s, t, K, F, 1.0)[:, 0] > thresh).sum()) for s in ids for t in range(nfr))
+    total = parallel.sum_over_ranks(local)
+    parallel.barrier()
+    q.put((rank, gatherer.consumed_steps, gatherer.consumed_detections, want, total))
+    torch.distributed.destroy_process_group()
+
+
+def test_gathered_block_is_consumed_every_step_and_counts_all_streams():
+    world, num_streams, K, F = 2, 5, 6, 8
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_consume_worker, args=(r, world, port, num_streams, K, F, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, steps, counted, want, total in got:
+        assert steps == 4 and counted == want == total
