@@ -311,7 +311,7 @@ def main():
     total_streams = B * world
     gatherer = None
     last = {}
-    K, F = det_rows_shape(det, cfg)
+    K, F = parallel.build_plans_consistently(lambda: det_rows_shape(det, cfg))
     # every rank must replay the same fp32 summation orders: compare the plans before anything is timed
     plan_hash = parallel.check_same_plan(DLASegHIP.plan_signature(det._ctx['plan']))
     if world > 1:

@@ -114,7 +114,7 @@ class Track(ctypes.Structure):
 
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
-           'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_offsets_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_stem_forward',
+           'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_offsets_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_dcn_v2_group_plan', 'ct_stem_forward',
            'ct_maxpool2x2', 'ct_upsample_add', 'ct_nchw_to_nhwc', 'ct_nhwc_to_nchw',
            'ct_decode_row_floats', 'ct_decode_workspace_bytes', 'ct_decode', 'ct_decode_pose_workspace_bytes',
            'ct_decode_pose', 'ct_render_pre_hm',
@@ -167,6 +167,7 @@ def load():
     lib.ct_dcn_v2_group.argtypes = [ctypes.POINTER(DcnDesc), i, i, p]
     lib.ct_dcn_v2_group_workspace_bytes.restype = sz
     lib.ct_dcn_v2_group_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
+    lib.ct_dcn_v2_group_plan.argtypes = [ctypes.POINTER(DcnDesc), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     lib.ct_stem_forward.argtypes = [p, p, p, i, i, i, p, p, p, p, p, p, i, p]
     lib.ct_maxpool2x2.argtypes = [p, i, i, i, i, i, p, i, p]
     lib.ct_upsample_add.argtypes = [p, i, i, i, i, i, p, i, p, i, p, i, p]

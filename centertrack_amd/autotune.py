@@ -22,6 +22,7 @@ import torch
 from . import _lib
 
 _CACHE = {}
+_PINNED = {}
 _LOADED = False
 _SCRATCH = {}
 _SHADOW = {}
@@ -54,28 +55,46 @@ def _load_file():
     the launch shapes of the BASELINE.json configurations, measured once on an MI355X and committed, so that every
     process -- every rank of a torchrun job -- replays IDENTICAL tile shapes, hence identical fp32 summation orders
     and identical last bits; ``CENTERTRACK_TUNE_PINNED=0`` ignores it), (2) the file named by
-    ``CENTERTRACK_TUNE_CACHE``, (3) live timing."""
+    ``CENTERTRACK_TUNE_CACHE`` -- for keys the pinned table does not hold: on a conflict the PINNED entry wins, so a
+    user cache written before the package shipped a re-tuned table cannot resurrect stale shapes -- (3) live timing."""
     global _LOADED
     if _LOADED:
         return
     _LOADED = True
-    if os.environ.get('CENTERTRACK_TUNE_PINNED', '1') != '0':
-        _CACHE.update(_read_table(PINNED_TABLE))
     p = _cache_path()
     if p:
         _CACHE.update(_read_table(p))
+    if os.environ.get('CENTERTRACK_TUNE_PINNED', '1') != '0':
+        _PINNED.update(_read_table(PINNED_TABLE))
+        _CACHE.update(_PINNED)
 
 
 def _save_file():
     """atomic (temp file + rename) and written by rank 0 only: under torchrun every rank tunes the same keys, and
-    concurrent rewrites of one path would interleave"""
+    concurrent rewrites of one path would interleave.  Only the keys the pinned table does NOT hold are written: the
+    file never carries a copy of pinned entries that could outlive a re-tuned table."""
     p = _cache_path()
     if not p or int(os.environ.get('RANK', '0')) != 0:
         return
     tmp = '%s.tmp.%d' % (p, os.getpid())
     with open(tmp, 'w') as f:
-        json.dump({k: list(v) for k, v in sorted(_CACHE.items())}, f, indent=0)
+        json.dump({k: list(v) for k, v in sorted(_CACHE.items()) if k not in _PINNED}, f, indent=0)
     os.replace(tmp, p)
+
+
+def share_from_rank0():
+    """torchrun jobs: a key missing from the pinned table / cache file is timed live, and two ranks timing the same
+    candidates may pick different winners (other fp32 summation orders).  Rank 0's choices are therefore broadcast and
+    adopted by every rank: call it after rank 0 built its plans and before the other ranks build theirs
+    (``parallel.build_plans_consistently``).  No-op without a process group."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return
+    _load_file()
+    box = [{k: list(v) for k, v in _CACHE.items()} if dist.get_rank() == 0 else None]
+    dist.broadcast_object_list(box, src=0)
+    if dist.get_rank() != 0:
+        _CACHE.update({k: tuple(v) for k, v in box[0].items()})
 
 
 def _scratch(nbytes, device):

@@ -803,6 +803,21 @@ extern "C" size_t ct_dcn_v2_group_workspace_bytes(const ct_dcn_desc *d)
     return ws_bytes(&t, p);
 }
 
+extern "C" int ct_dcn_v2_group_plan(const ct_dcn_desc *d, size_t *workspace_bytes, int *splits)
+{
+    if (!d) CT_FAIL_ARG("ct_dcn_v2_group_plan: null descriptor");
+    DcnPlan p;
+    ct_dcn_desc t = *d;
+    float dummy;
+    if (!t.workspace) t.workspace = &dummy;
+    if (!t.y) t.y = &dummy;
+    const int rc = make_plan(&t, &p, true);
+    if (rc != CT_OK) return rc;
+    if (workspace_bytes) *workspace_bytes = ws_bytes(&t, p);
+    if (splits) *splits = p.splits;
+    return CT_OK;
+}
+
 extern "C" int ct_dcn_v2(const ct_dcn_desc *d, void *stream)
 {
     return launch_group(d, 1, false, CT_DCN_OFFSETS | CT_DCN_MAIN | CT_DCN_FINISH, stream);

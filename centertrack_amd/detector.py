@@ -77,7 +77,9 @@ def render_pre_hm(tracks, meta, pre_thresh, out=None, with_hm=True):
 def imread_bgr(path):
     """``cv2.imread(path)`` (detector.py:66): the decoded image as uint8 [H,W,3] in BGR channel order.  cv2 is used
     when it is installed (bit-identical to the reference by construction); otherwise Pillow decodes the file -- lossless
-    formats (PNG, BMP, PPM) give the same pixels, JPEG decoders may differ in the last bit of a pixel."""
+    8-bit formats (PNG, BMP, PPM) give the same pixels, JPEG decoders may differ in the last bit of a pixel.  Like
+    cv2.imread's default flags the Pillow path applies the EXIF orientation and drops an alpha channel; 16-bit and
+    palette images go through Pillow's ``convert('RGB')``, whose rounding can differ from cv2's -- install cv2 for those."""
     try:
         import cv2
         img = cv2.imread(str(path))
@@ -90,7 +92,9 @@ def imread_bgr(path):
         from PIL import Image
     except ImportError:
         raise _lib.CTError('reading image files needs cv2 or Pillow; pass the decoded uint8 BGR array instead')
+    from PIL import ImageOps
     with Image.open(path) as im:
+        im = ImageOps.exif_transpose(im)                       # cv2.imread rotates by the EXIF orientation tag
         return np.ascontiguousarray(np.asarray(im.convert('RGB'))[:, :, ::-1])
 
 
@@ -154,7 +158,7 @@ class StreamDetector(object):
                                             public_det=getattr(opt, 'public_det', False))
                      for _ in range(self.B)] if self.native else None
         self._last_dets = None
-        self._prefetched = None    # ((host pointer, shape), event) of a frame uploaded ahead by step(prefetch=...)
+        self._prefetched = None    # (host tensor, its _version, event) of a frame uploaded ahead by step(prefetch=...)
         self.started = [False] * self.B
         # device-side pre-processing of raw u8 frames (ct_preprocess_device): normalisation table + staging buffers
         lut = np.empty((3, 256), np.float32)
@@ -357,6 +361,7 @@ class StreamDetector(object):
         # ---- the frame goes straight into the graph's frame buffer (images [0, B); the mirrored images [B, 2B) of
         #      flip_test are built on the device by the frame's first launch, detector.py:224-226) ----
         if raw_frames:
+            self._prefetched = None
             for s in range(B):
                 self._warp_frame(s, images[s], metas[s], fr, H, W)
         else:
@@ -365,12 +370,14 @@ class StreamDetector(object):
             if tuple(images.shape) != (B, 3, H, W):
                 raise _lib.CTError('step() expects [%d,3,%d,%d] frames, got %s' % (B, H, W, tuple(images.shape)))
             pf = self._prefetched
-            if pf is not None and pf[0] == (images.data_ptr(), tuple(images.shape)):
+            self._prefetched = None                            # (a frame uploaded ahead serves the very next call only)
+            # the SAME tensor object, unmodified since it was handed over (an in-place edit bumps ``_version``; a new
+            # tensor at a recycled address is another object)
+            if pf is not None and pf[0] is images and pf[1] == images._version:
                 # uploaded by the previous step's ``prefetch`` while that frame was computed: staging -> frame buffer
-                cur.wait_event(pf[1])
+                cur.wait_event(pf[2])
                 _lib.check(lib.ct_memcpy_async(fr.data_ptr(), ctx['stage'].data_ptr(), images.numel() * 4, 0, sp),
                            'frame copy')
-                self._prefetched = None
                 if ctx['stage_free'] is None:
                     ctx['stage_free'] = torch.cuda.Event()
                 ctx['stage_free'].record(cur)                  # the staging buffer may be refilled once this copy ran
@@ -449,7 +456,7 @@ class StreamDetector(object):
                                            ctx['copy_sp']), 'prefetch')
             ev = ctx['stage_ready']                            # (re-recorded every step; the waiter of the previous
             ev.record(cs)                                      #  recording was enqueued at the top of this step)
-            self._prefetched = ((prefetch.data_ptr(), tuple(prefetch.shape)), ev)
+            self._prefetched = (prefetch, prefetch._version, ev)
         if self.gather_fn is not None:
             ev = self.gather_fn(ctx['decoder'].out)
             self._rows_free = ev if isinstance(ev, torch.cuda.Event) else None
@@ -519,6 +526,7 @@ class StreamDetector(object):
                 self.fast[s].reset()
             self._carried.pop(s, None)
             self.started[s] = False
+        self._prefetched = None
 
     def results_as_dicts(self, results, stream=0, meta=None):
         """one stream's result of ``step`` as the reference's list of dicts (``meta``: the frame's meta, whose

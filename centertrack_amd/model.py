@@ -166,7 +166,10 @@ class DLASegHIP(torch.nn.Module):
                 P['%s.up_%d' % (p, k)] = ops.upsample_weight(sd['%s.up_%d.weight' % (p, k)])
         # heads with <= 8 output channels: ONE launch for conv3x3 + ReLU + conv1x1 of all of them (ct_heads_fused)
         hc = self.head_conv
-        small = [h for h, c in self.heads.items() if c <= 8] if (FUSE_HEADS and WINOGRAD and hc == 256) else []
+        # ('hm_hp' stays out whatever its width: ct_heads_fused has ONE sigmoid range, taken by 'hm'; the per-head 1x1
+        # tail applies hm_hp's sigmoid, detector.py:300-304)
+        small = ([h for h, c in self.heads.items() if c <= 8 and h != 'hm_hp']
+                 if (FUSE_HEADS and WINOGRAD and hc == 256) else [])
         small = small[:_lib.CT_MAX_FUSED_HEADS]
         P['heads_small'] = small
         if small:
@@ -455,7 +458,7 @@ class DLASegHIP(torch.nn.Module):
                 _lib.check(rc, l.name)
 
     # --- the 16 DeformConv nodes of DLAUp / IDAUp as grouped launches -------------------------------------
-    def _schedule_dcn(self, layers, produced0, N, dev, knobs):
+    def _schedule_dcn(self, layers, produced0, N, dev, knobs, tune=True):
         """Launch list of the 16 DCN nodes for one choice of ``knobs``.
 
         Dataflow (dla.py:539-574): a `proj` node only reads a finished level; the IDAUp step behind it needs the
@@ -499,7 +502,7 @@ class DLASegHIP(torch.nn.Module):
                 omv = ops.new_view(N, ly.x.H, ly.x.W, 32, dev)
                 part = omv.buf
                 d = ops.make_conv_desc(ly.x, pk['w_off'], 27, 3, 1, out=omv, w_wino=pk['w_off_wino'])
-                if autotune.enabled():
+                if tune:
                     autotune.tune_conv(d, dev)
                 convs.setdefault(ly.main, []).append(
                     _Launch(ly.name + '.offset', 'conv', d, (ly.x, omv, pk),
@@ -510,7 +513,7 @@ class DLASegHIP(torch.nn.Module):
             elif not ly.fused:
                 om = ops.new_view(N, ly.x.H, ly.x.W, 32, dev)
                 d = ops.make_conv_desc(ly.x, pk['w_off'], 27, 3, 1, shift=pk['b_off'], out=om, sig=(18, 27))
-                if autotune.enabled():
+                if tune:
                     autotune.tune_conv(d, dev)
                 convs.setdefault(ly.main, []).append(
                     _Launch(ly.name + '.offset', 'conv', d, (ly.x, om, pk),
@@ -519,7 +522,9 @@ class DLASegHIP(torch.nn.Module):
             dd = ops.make_dcn_desc(ly.x, om, pk['w'], ly.cout, pk['scale'], pk['shift'], True, ly.out, up=ly.up,
                                    split_k=ly.splits, algo=3264, om_partial=part, raw_offsets=raw,
                                    w_off=pk['w_off'] if own else None, b_off=pk['b_off'] if own else None)
-            need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(dd))
+            need_c = ctypes.c_size_t(0)
+            _lib.check(lib.ct_dcn_v2_group_plan(ctypes.byref(dd), ctypes.byref(need_c), None), 'DCN layer ' + ly.name)
+            need = need_c.value
             ly.use_ws = need > 0
             keep = [ly.x, om, part, ly.out, pk, ly.up]
             if need:
@@ -602,10 +607,10 @@ class DLASegHIP(torch.nn.Module):
         env = os.environ.get('CENTERTRACK_DCN_KNOBS', '')
         if env:
             knobs = tuple(int(v) for v in env.split(','))
-            return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
+            return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs, tune)
         default = (128, 4, 2, 1)
         if not tune:
-            return default, self._schedule_dcn(layers, produced0, N, dev, default)
+            return default, self._schedule_dcn(layers, produced0, N, dev, default, tune)
         key = 'dcnplan3:%d,%d,%d' % (N, H, W)
         autotune._load_file()
         if key in autotune._CACHE:

@@ -67,6 +67,21 @@ def check_same_plan(signature, what='launch plan'):
     return hexd
 
 
+def build_plans_consistently(build_fn):
+    """Run ``build_fn`` (whatever builds this rank's launch plans, e.g. ``det._context(H, W)``) so that every rank ends
+    up with rank 0's launch-shape choices: rank 0 builds first (timing whatever the pinned table does not hold), its
+    tuning cache is broadcast, then the other ranks build from it without timing anything.  Returns build_fn()'s
+    result.  ``check_same_plan`` afterwards proves the outcome."""
+    from . import autotune
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return build_fn()
+    out = build_fn() if dist.get_rank() == 0 else None
+    autotune.share_from_rank0()
+    if dist.get_rank() != 0:
+        out = build_fn()
+    return out
+
+
 class DetectionGatherer(object):
     """The one exchange step of the sharded path: all-gather of the packed decode rows, with every buffer
     allocated ONCE (send [per,K,F], recv [world*per,K,F], the globally ordered result [num_streams,K,F]) so that a

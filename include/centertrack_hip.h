@@ -171,6 +171,11 @@ enum { CT_DCN_MAIN = 1,      /* the gather + contraction launch (results or spli
                                 must precede CT_DCN_MAIN of the same layers */ };
 int ct_dcn_v2_group(const ct_dcn_desc *descs, int n, int phases, void *stream);
 size_t ct_dcn_v2_group_workspace_bytes(const ct_dcn_desc *d);
+/* The same query with an error code: ct_dcn_v2_group_workspace_bytes returns 0 both for "no workspace needed" and for
+ * a descriptor the launch would reject; this one validates the descriptor as a member of a group launch (workspace /
+ * output pointers may still be NULL) and returns CT_OK with *workspace_bytes (0 = the layer finishes in its MAIN
+ * launch) and *splits (K splits the launch will use), or the launch's error code (see ct_last_error). */
+int ct_dcn_v2_group_plan(const ct_dcn_desc *d, size_t *workspace_bytes, int *splits);
 
 /* ---- the three 7x7 stems, fused --------------------------------------------------
  * Replaces DLA.forward's base_layer / pre_img_layer / pre_hm_layer and their sum

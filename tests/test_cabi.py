@@ -126,6 +126,57 @@ def test_dcn_argument_validation_without_gpu(lib):
     assert l.ct_dcn_v2_group(ctypes.byref(d), 5, _lib.CT_DCN_MAIN, None) == _lib.CT_ERR_ARG
 
 
+def test_group_plan_query_reports_errors_instead_of_zero(lib):
+    """ct_dcn_v2_group_workspace_bytes answers 0 for "none needed" AND for a rejected descriptor; ct_dcn_v2_group_plan
+    tells them apart"""
+    from centertrack_amd import _lib
+    l = _lib.load()
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    d = _lib.DcnDesc()
+    d.x = d.w_packed = d.om = p
+    d.N, d.H, d.W, d.Cin, d.Cout, d.ldx, d.ldy, d.ldom = 1, 8, 8, 256, 64, 256, 64, 32
+    d.algo, d.split_k = 3264, 2
+    need, splits = ctypes.c_size_t(7), ctypes.c_int(0)
+    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), ctypes.byref(splits)) == 0
+    assert splits.value == 2 and need.value == 2 * 8 * 8 * 64 * 4 == l.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d))
+    d.split_k = 1
+    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == 0 and need.value == 0
+    d.Cin = 48                                                 # rejected: the size query says 0, the plan query says why
+    assert l.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d)) == 0
+    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == _lib.CT_ERR_ARG
+    assert b'Cin' in l.ct_last_error()
+
+
+def test_pinned_table_wins_over_a_user_cache_and_is_never_copied_into_it(tmp_path, monkeypatch):
+    """a CENTERTRACK_TUNE_CACHE file written before the package shipped a re-tuned pinned table must not
+    resurrect stale shapes, and the file only ever holds keys the pinned table does not"""
+    import json
+    from centertrack_amd import autotune
+    with open(autotune.PINNED_TABLE) as f:
+        pinned = json.load(f)
+    key = 'dcnplan3:1,512,512'
+    stale = {key: [0, 2, 2, 1, 999.0], 'conv:user-only-key': [3, 1, 5.0]}
+    cache = tmp_path / 'cache.json'
+    cache.write_text(json.dumps(stale))
+    monkeypatch.setenv('CENTERTRACK_TUNE_CACHE', str(cache))
+    monkeypatch.delenv('RANK', raising=False)
+    saved = (dict(autotune._CACHE), dict(autotune._PINNED), autotune._LOADED)
+    try:
+        autotune._CACHE.clear(); autotune._PINNED.clear(); autotune._LOADED = False
+        autotune._load_file()
+        assert list(autotune._CACHE[key]) == pinned[key]                  # the pinned entry won
+        assert list(autotune._CACHE['conv:user-only-key']) == [3, 1, 5.0]   # other keys of the file are honoured
+        autotune._CACHE['conv:live-tuned'] = (2, 1, 7.5)
+        autotune._save_file()
+        written = json.loads(cache.read_text())
+        assert set(written) == {'conv:user-only-key', 'conv:live-tuned'}
+    finally:
+        autotune._CACHE.clear(); autotune._CACHE.update(saved[0])
+        autotune._PINNED.clear(); autotune._PINNED.update(saved[1])
+        autotune._LOADED = saved[2]
+
+
 def test_pinned_tune_table_is_well_formed():
     """centertrack_amd/tune_table.json: conv entries (algo, split_k, us), DCN schedule entries `dcnplan3:N,H,W` ->
     (fuse_max_cin, chunks_per_split, nkk, offset mode, us) with values the scheduler understands; no stale keys"""
