@@ -90,7 +90,10 @@ class PoseDesc(ctypes.Structure):
                 ('hps_batch_stride', ctypes.c_size_t), ('hm_hp_batch_stride', ctypes.c_size_t),
                 ('hp_offset_batch_stride', ctypes.c_size_t),
                 ('out', ctypes.c_void_p), ('out_stride', ctypes.c_int),
-                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t)]
+                ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
+                ('box_wh', ctypes.c_void_p), ('box_reg', ctypes.c_void_p), ('box_ltrb', ctypes.c_void_p),
+                ('box_wh_batch_stride', ctypes.c_size_t), ('box_reg_batch_stride', ctypes.c_size_t),
+                ('box_ltrb_batch_stride', ctypes.c_size_t)]
 
 
 class FlipHead(ctypes.Structure):

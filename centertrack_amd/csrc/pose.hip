@@ -8,7 +8,9 @@
 //      offset, peaks <= 0.2 dropped) sit in LDS; thread k regresses joint j of detection k
 //      (hps[b, 2j..2j+1, ind_k] + centre), scans the peaks for the nearest one (fp32 sqrt(dx^2+dy^2),
 //      contraction off, first minimum like torch.min) and keeps the regressed joint when that peak is weak
-//      or outside the detection's box;
+//      or outside the detection's box -- the wh / ltrb box from the packed row, or rebuilt from the heads when the
+//      row carries the ltrb_amodal box instead, or (no box head: decode.py:60-71) the extent of the detection's
+//      regressed joints widened by 25 %;
 //   3. pose_score_kernel: kps_score[b,k] = score * mean_j(peak score or, where not snapped, score)
 //      (joints summed in order, then / J, like torch.mean over a strided dim).
 // Integer / compare work with B*J*K*K distance evaluations (1.7e5 per image): latency-bound, no MFMA.
@@ -31,6 +33,8 @@ struct PoseArgs {
     float *out;               // [B,K,2J+1]
     size_t hps_bs, off_bs;
     int B, K, J, F, HW, box_col, OW;
+    const float *bwh, *breg, *bltrb;   // box_col < 0: gate box from the heads (all null: box-less variant)
+    size_t bwh_bs, breg_bs, bltrb_bs;
 };
 
 __global__ __launch_bounds__(128) void pose_match_kernel(PoseArgs a)
@@ -70,8 +74,38 @@ __global__ __launch_bounds__(128) void pose_match_kernel(PoseArgs a)
             if (d < best) { best = d; bi = c; }
         }
         const float hs = ps[bi], hx = px[bi], hy = py[bi];
-        const bool keep_reg = hs < POSE_THRESH || hx < row[a.box_col] || hx > row[a.box_col + 2] ||
-                              hy < row[a.box_col + 1] || hy > row[a.box_col + 3];
+        float bl, bt, br, bb;
+        if (a.box_col >= 0) {
+            bl = row[a.box_col]; bt = row[a.box_col + 1]; br = row[a.box_col + 2]; bb = row[a.box_col + 3];
+        } else if (a.bltrb) {                                         // decode.py:131-139
+            const float *q = a.bltrb + (size_t)b * a.bltrb_bs + ind;
+            bl = row[2] + q[0]; bt = row[3] + q[(size_t)a.HW]; br = row[2] + q[(size_t)2 * a.HW]; bb = row[3] + q[(size_t)3 * a.HW];
+        } else if (a.bwh) {                                           // decode.py:102-128
+            float xs = row[2] + 0.5f, ys = row[3] + 0.5f;
+            if (a.breg) {
+                xs = row[2] + a.breg[(size_t)b * a.breg_bs + ind];
+                ys = row[3] + a.breg[(size_t)b * a.breg_bs + a.HW + ind];
+            }
+            float ww = a.bwh[(size_t)b * a.bwh_bs + ind], hh = a.bwh[(size_t)b * a.bwh_bs + a.HW + ind];
+            if (ww < 0.f) ww = 0.f;
+            if (hh < 0.f) hh = 0.f;
+            bl = xs - ww / 2; bt = ys - hh / 2; br = xs + ww / 2; bb = ys + hh / 2;
+        } else {                                                      // decode.py:60-71: extent of the regressed joints
+            bl = bt = __builtin_inff();
+            br = bb = -__builtin_inff();
+            for (int q = 0; q < a.J; ++q) {
+                const float qx = a.hps[(size_t)b * a.hps_bs + (size_t)(2 * q) * a.HW + ind] + row[2];
+                const float qy = a.hps[(size_t)b * a.hps_bs + (size_t)(2 * q + 1) * a.HW + ind] + row[3];
+                bl = fminf(bl, qx); br = fmaxf(br, qx);
+                bt = fminf(bt, qy); bb = fmaxf(bb, qy);
+            }
+            const float margin = 0.25f;
+            bl = bl - (br - bl) * margin;
+            br = br + (br - bl) * margin;                             // (from the widened l, like the reference)
+            bt = bt - (bb - bt) * margin;
+            bb = bb + (bb - bt) * margin;
+        }
+        const bool keep_reg = hs < POSE_THRESH || hx < bl || hx > br || hy < bt || hy > bb;
         float *o = a.out + ((size_t)b * a.K + k) * OW;
         o[2 * j] = keep_reg ? rx : hx;
         o[2 * j + 1] = keep_reg ? ry : hy;
@@ -102,9 +136,10 @@ int check(const ct_pose_desc *d, const char *who)
 {
     if (!d || !d->rows || !d->inds || !d->hps || !d->hm_hp) CT_FAIL_ARG("%s: null pointer", who);
     if (d->B <= 0 || d->h <= 0 || d->w <= 0 || d->K <= 0 || d->num_joints <= 0) CT_FAIL_ARG("%s: bad shape", who);
-    if (d->box_col < 4 || d->box_col + 4 > d->row_floats)
-        CT_FAIL_ARG("%s: the pose branch needs the wh / ltrb box in the packed rows (box_col=%d, row_floats=%d)", who,
+    if (d->box_col != -1 && (d->box_col < 4 || d->box_col + 4 > d->row_floats))
+        CT_FAIL_ARG("%s: box_col=%d is neither -1 (box from the heads / box-less) nor a box column of a %d-float row", who,
                     d->box_col, d->row_floats);
+    if (d->box_col == -1 && d->box_reg && !d->box_wh) CT_FAIL_ARG("%s: box_reg given without box_wh", who);
     if (d->hm_hp_batch_stride && d->hm_hp_batch_stride != (size_t)d->num_joints * d->h * d->w)
         CT_FAIL_ARG("%s: hm_hp must be densely packed [B,J,h,w]", who);
     return CT_OK;
@@ -153,6 +188,12 @@ extern "C" int ct_decode_pose(const ct_pose_desc *d, void *stream)
     a.hps_bs = d->hps_batch_stride ? d->hps_batch_stride : (size_t)2 * d->num_joints * HW;
     a.off_bs = d->hp_offset_batch_stride ? d->hp_offset_batch_stride : (size_t)2 * HW;
     a.B = d->B; a.K = d->K; a.J = d->num_joints; a.F = d->row_floats; a.HW = HW; a.box_col = d->box_col;
+    a.bwh = d->box_col < 0 ? d->box_wh : nullptr;
+    a.breg = d->box_col < 0 ? d->box_reg : nullptr;
+    a.bltrb = d->box_col < 0 ? d->box_ltrb : nullptr;
+    a.bwh_bs = d->box_wh_batch_stride ? d->box_wh_batch_stride : (size_t)2 * HW;
+    a.breg_bs = d->box_reg_batch_stride ? d->box_reg_batch_stride : (size_t)2 * HW;
+    a.bltrb_bs = d->box_ltrb_batch_stride ? d->box_ltrb_batch_stride : (size_t)4 * HW;
     a.OW = d->out_stride ? d->out_stride : 2 * d->num_joints + 1;
     if (a.OW < 2 * d->num_joints + 1) CT_FAIL_ARG("ct_decode_pose: out_stride %d too small", d->out_stride);
     hipStream_t s = (hipStream_t)stream;

@@ -264,9 +264,6 @@ class Decoder(object):
         if 'hps' in heads:                                 # pose branch, decode.py:161-171
             J = heads['hps'].shape[1] // 2
             if 'hm_hp' in heads:
-                if 'ltrb_amodal' in heads or not ({'wh', 'ltrb'} & set(heads)):
-                    raise _lib.CTError('the pose branch needs the wh / ltrb box (decode.py:45-57); box-less and '
-                                       'ltrb_amodal variants are not implemented')
                 self.layout = self.layout + [('hps', F0, 2 * J), ('kps_score', F0 + 2 * J, 1)]
                 self.F = F0 + 2 * J + 1
             else:                                          # decode.py:80-81: no refinement, kps_score = kps
@@ -286,7 +283,20 @@ class Decoder(object):
             off = heads.get('hp_offset', heads.get('reg'))
             assert planes_ok(hps) and hm_hp.is_contiguous() and hm_hp.shape[1] == J and (off is None or planes_ok(off))
             pd = _lib.PoseDesc()
-            pd.rows, pd.row_floats, pd.box_col, pd.inds = self.out.data_ptr(), self.F, 4, self.inds.data_ptr()
+            pd.rows, pd.row_floats, pd.inds = self.out.data_ptr(), self.F, self.inds.data_ptr()
+            # the gate box of _update_kps_with_hm is generic_decode's local `bboxes`: wh, overridden by ltrb -- never the
+            # ltrb_amodal box that replaces ret['bboxes'] in the packed row (decode.py:123,137 vs 159)
+            if 'ltrb_amodal' in heads or not ({'wh', 'ltrb'} & set(heads)):
+                pd.box_col = -1
+                for name, fld in (('wh', 'box_wh'), ('ltrb', 'box_ltrb')):
+                    if name in heads:
+                        assert planes_ok(heads[name])
+                        setattr(pd, fld, heads[name].data_ptr())
+                        setattr(pd, fld + '_batch_stride', heads[name].stride(0))
+                if 'wh' in heads and 'reg' in heads:
+                    pd.box_reg, pd.box_reg_batch_stride = heads['reg'].data_ptr(), heads['reg'].stride(0)
+            else:
+                pd.box_col = 4
             pd.B, pd.h, pd.w, pd.K, pd.num_joints = B, h, w, K, J
             pd.hps, pd.hm_hp, pd.hp_offset = hps.data_ptr(), hm_hp.data_ptr(), _p(off)
             pd.hps_batch_stride = hps.stride(0)

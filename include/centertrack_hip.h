@@ -230,10 +230,17 @@ int ct_decode(const ct_decode_desc *d, void *stream);
 
 /* ---- pose branch of the decode ------------------------------------
  * Replaces the `'hps' in output` branch of generic_decode (src/lib/model/decode.py:161-171) with
- * _update_kps_with_hm (decode.py:11-81, the `bboxes is not None` case) and _topk_channel
- * (src/lib/model/utils.py:60-69).  Runs after ct_decode on the same frame: rows / inds are ct_decode's
- * outputs (row pitch row_floats); box_col = column of the wh / ltrb box in a packed row (4 when present; a row that carries the
- * ltrb_amodal box there instead is not accepted by the caller).  hps: NCHW [B,2J,h,w]; hm_hp: NCHW
+ * _update_kps_with_hm (decode.py:11-81) and _topk_channel (src/lib/model/utils.py:60-69).  Runs after ct_decode on
+ * the same frame: rows / inds are ct_decode's outputs (row pitch row_floats).  The box a snapped joint must lie in
+ * (decode.py:45-57) is generic_decode's LOCAL `bboxes` -- the wh box, overridden by the ltrb box (decode.py:123,137),
+ * never the ltrb_amodal box (that one only replaces ret['bboxes'], decode.py:159):
+ *   box_col >= 4  column of that box in a packed row (rows of a model without an ltrb_amodal head);
+ *   box_col == -1 the rows do not hold it (their box columns carry the amodal box, or there is none): it is rebuilt
+ *                 from the heads box_ltrb [B,4,h,w], else box_wh [B,2,h,w] (+ box_reg [B,2,h,w], NULL = +0.5), with
+ *                 ct_decode's own expressions; all three NULL = the box-less variant (decode.py:60-71): the box is the
+ *                 extent of the detection's regressed joints widened by 25 % per side (r and b grow from the already
+ *                 widened l and t, as in the reference).
+ * hps: NCHW [B,2J,h,w]; hm_hp: NCHW
  * [B,J,h,w] post-sigmoid, densely packed; hp_offset: NCHW [B,2,h,w] (the hp_offset head, else the reg
  * head, else NULL = +0.5).  out: [B,K,2J+1] = refined key points (x0,y0,x1,y1,...) then kps_score
  * (with out_stride it may point into the packed rows themselves: one buffer, one D2H).
@@ -246,6 +253,8 @@ typedef struct ct_pose_desc {
     size_t hps_batch_stride, hm_hp_batch_stride, hp_offset_batch_stride;   /* floats between images; 0 = dense */
     float *out; int out_stride;            /* floats between consecutive rows of out; 0 = 2J+1 */
     void *workspace; size_t workspace_bytes;
+    const float *box_wh, *box_reg, *box_ltrb;                              /* box_col == -1, see above */
+    size_t box_wh_batch_stride, box_reg_batch_stride, box_ltrb_batch_stride;   /* floats between images; 0 = dense */
 } ct_pose_desc;
 size_t ct_decode_pose_workspace_bytes(const ct_pose_desc *d);
 int ct_decode_pose(const ct_pose_desc *d, void *stream);

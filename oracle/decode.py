@@ -59,11 +59,13 @@ POSE_THRESH = 0.2          # decode.py:16
 
 
 def refine_keypoints(kps, output, K, bboxes, scores):
-    """decode.py:11-81 (_update_kps_with_hm), the ``bboxes is not None`` case: every regressed joint
+    """decode.py:11-81 (_update_kps_with_hm): every regressed joint
     (kps [B,K,2J], centre + hps offset) snaps to the nearest peak of its joint heat-map ``hm_hp`` (top-K
     peaks per joint, + hp_offset / reg sub-pixel offset, peaks <= 0.2 discarded) unless that peak is weak or
     falls outside the detection's box; kps_score = score * mean_j(peak score or, where not snapped, score).
-    Written per (image, joint) instead of the reference's 5-D broadcast; same fp32 operations."""
+    ``bboxes`` None (no wh / ltrb head, decode.py:60-71): the box is the extent of the detection's regressed joints
+    widened by 25 % per side -- r and b are widened from the ALREADY widened l and t, as the reference's in-place
+    sequence does.  Written per (image, joint) instead of the reference's 5-D broadcast; same fp32 operations."""
     batch, J = kps.shape[0], kps.shape[2] // 2
     heat = nms(output['hm_hp'])
     p_score, p_inds, p_ys, p_xs = topk_channel(heat, K=K)                      # [B,J,K]
@@ -80,7 +82,17 @@ def refine_keypoints(kps, output, K, bboxes, scores):
     new_kps = kps.clone()
     joint_score = torch.empty((batch, J, K), dtype=kps.dtype)
     for b in range(batch):
-        l, t, r, bt = bboxes[b, :, 0], bboxes[b, :, 1], bboxes[b, :, 2], bboxes[b, :, 3]
+        if bboxes is not None:
+            l, t, r, bt = bboxes[b, :, 0], bboxes[b, :, 1], bboxes[b, :, 2], bboxes[b, :, 3]
+        else:                                                                    # decode.py:60-71
+            xs_, ys_ = kps[b, :, 0::2], kps[b, :, 1::2]                          # [K, J]
+            l, r = xs_.min(dim=1)[0], xs_.max(dim=1)[0]
+            t, bt = ys_.min(dim=1)[0], ys_.max(dim=1)[0]
+            margin = 0.25
+            l = l - (r - l) * margin
+            r = r + (r - l) * margin
+            t = t - (bt - t) * margin
+            bt = bt + (bt - t) * margin
         for j in range(J):
             rx, ry = kps[b, :, 2 * j], kps[b, :, 2 * j + 1]                      # regressed joint of every detection
             dx = rx[:, None] - p_xs[b, j][None, :]
@@ -148,8 +160,6 @@ def generic_decode(output, K=100, zero_tracking=False, return_inds=False):
         kps[..., 0::2] += xs0.view(batch, K, 1)
         kps[..., 1::2] += ys0.view(batch, K, 1)
         if 'hm_hp' in output:
-            if bboxes is None:
-                raise NotImplementedError('pose refinement without a box head (decode.py:60-71) is not restated')
             ret['hps'], ret['kps_score'] = refine_keypoints(kps, output, K, bboxes, scores)
         else:
             ret['hps'], ret['kps_score'] = kps, kps                           # decode.py:80-81

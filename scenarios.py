@@ -30,6 +30,12 @@ def decode_cases():
         dict(name='nusc_28x50', heads=W.NUSC_HEADS, B=3, h=28, w=50, K=64, seed=4),
         dict(name='mot_128x128', heads=W.MOT_HEADS, B=1, h=128, w=128, K=100, seed=5),
         dict(name='pose_32x48', heads=W.POSE_HEADS, B=1, h=32, w=48, K=100, seed=6),   # (the reference's pose branch only runs at batch 1)
+        # pose without any box head (decode.py:60-71: joints gated by the extent of the regressed key points) and with
+        # an ltrb_amodal head next to wh (the gate stays the wh box, ret['bboxes'] is the amodal one, decode.py:159)
+        dict(name='pose_nobox_24x32', heads=OrderedDict([(k, v) for k, v in W.POSE_HEADS.items() if k != 'wh']),
+             B=1, h=24, w=32, K=60, seed=7, hps_std=1.0),
+        dict(name='pose_amodal_24x32', heads=OrderedDict(list(W.POSE_HEADS.items()) + [('ltrb_amodal', 4)]),
+             B=1, h=24, w=32, K=60, seed=8),
     ]
 
 
@@ -50,7 +56,7 @@ def make_head_maps(case):
         elif name == 'wh':
             out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 4 + 3).float()
         elif name == 'hps':
-            out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * 3).float()
+            out[name] = (torch.randn((B, c, h, w), generator=g, dtype=torch.float64) * case.get('hps_std', 3.0)).float()
         elif name == 'dep':
             out[name] = (torch.rand((B, c, h, w), generator=g, dtype=torch.float64) * 60 + 1).float()
         else:

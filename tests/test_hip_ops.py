@@ -547,42 +547,54 @@ def test_decode_matches_oracle_and_golden(device, golden_dir):
             np.testing.assert_array_equal(got[k], g['%s.%s' % (case['name'], k)], err_msg='golden %s.%s' % (case['name'], k))
 
 
-@pytest.mark.parametrize('B,h,w,K,offset', [(2, 24, 40, 100, 'hp_offset'), (3, 32, 32, 40, 'reg'), (1, 16, 24, 20, None)])
-def test_decode_pose_branch_variants(device, B, h, w, K, offset):
+@pytest.mark.parametrize('B,h,w,K,offset,box', [(2, 24, 40, 100, 'hp_offset', 'wh'), (3, 32, 32, 40, 'reg', 'wh'),
+                                                  (1, 16, 24, 20, None, 'wh'), (2, 24, 40, 60, 'hp_offset', 'none'),
+                                                  (2, 24, 40, 60, 'reg', 'wh+amodal'), (2, 24, 32, 50, None, 'ltrb'),
+                                                  (2, 24, 32, 50, 'reg', 'wh+ltrb+amodal')])
+def test_decode_pose_branch_variants(device, B, h, w, K, offset, box):
     """pose branch beyond the reference's batch-1 golden case: batches (the reference's expand() only works at
     batch 1; the oracle's per-image form extends it), the reg head as sub-pixel offset when there is no hp_offset
-    head, no offset head at all (+0.5), other K.  Key points exact (they are selections), kps_score to 1e-5."""
+    head, no offset head at all (+0.5), other K; and every source of the gate box (decode.py:45-71): wh, ltrb
+    (overrides wh), wh with an ltrb_amodal head beside it (the packed row then carries the amodal box and the gate box is
+    rebuilt from the heads), no box head at all (extent of the regressed joints + 25 %).  Key points exact (they are
+    selections), kps_score to 1e-5."""
     from collections import OrderedDict
     import scenarios as S
     from oracle import decode as odecode
-    heads = OrderedDict([('hm', 1), ('wh', 2), ('hps', 34), ('hm_hp', 17)])
+    heads = OrderedDict([('hm', 1), ('hps', 34), ('hm_hp', 17)])
+    for name, c in (('wh', 2), ('ltrb', 4), ('amodal', 4)):
+        if name in box.split('+'):
+            heads['ltrb_amodal' if name == 'amodal' else name] = c
     if offset == 'hp_offset':
         heads['reg'] = 2
         heads['hp_offset'] = 2
     elif offset == 'reg':
         heads['reg'] = 2
-    case = dict(name='pose_var', heads=heads, B=B, h=h, w=w, K=K, seed=40 + B)
+    case = dict(name='pose_var', heads=heads, B=B, h=h, w=w, K=K, seed=40 + B, hps_std=1.0 if box == 'none' else 3.0)
     maps = S.make_head_maps(case)
+    if 'ltrb' in heads:                               # a proper box around the centre (random N(0,2) sides would be inside-out)
+        maps['ltrb'] = maps['ltrb'].abs() * torch.tensor([-3.0, -3.0, 3.0, 3.0]).view(1, 4, 1, 1)
     maps['hm_hp'][:, 3] *= 0.15                       # a joint whose peaks are all weak: regressed joints kept
     dec, got, inds = _decode_case(device, case, maps)
     want = odecode.generic_decode({k: v.clone() for k, v in maps.items()}, K=K, return_inds=True)
     np.testing.assert_array_equal(inds, want['inds'].numpy())
     np.testing.assert_array_equal(got['hps'], want['hps'].numpy())
-    np.testing.assert_array_equal(got['bboxes'], want['bboxes'].numpy())
+    if box != 'none':
+        np.testing.assert_array_equal(got['bboxes'], want['bboxes'].numpy())
     np.testing.assert_allclose(got['kps_score'], want['kps_score'].numpy(), rtol=1e-5, atol=1e-7)
     kps = odecode.transpose_and_gather_feat(maps['hps'], want['inds']).view(B, K, 34).clone()
     kps[..., 0::2] += want['xs'].view(B, K, 1)
     kps[..., 1::2] += want['ys'].view(B, K, 1)
     snapped = (kps.numpy() != got['hps'])
     assert snapped.any() and not snapped[..., 6:8].any()      # joint 3 never snaps (all its peaks <= 0.2)
+    others = np.delete(snapped[..., 0::2], 3, axis=-1)
+    assert 0.05 < others.mean() < 0.98, 'the gate box must decide both ways (%.2f snapped)' % others.mean()
 
 
 def test_decode_pose_rejects_what_it_does_not_implement(device):
     from centertrack_amd import _lib, ops
     hm = torch.rand((1, 1, 16, 16), device=device)
     hps, hm_hp = torch.randn((1, 34, 16, 16), device=device), torch.rand((1, 17, 16, 16), device=device)
-    with pytest.raises(_lib.CTError):                                  # no box head
-        ops.Decoder(hm, {'hps': hps, 'hm_hp': hm_hp}, 20)
     with pytest.raises(_lib.CTError):                                  # no joint heat-map
         ops.Decoder(hm, {'hps': hps, 'wh': torch.rand((1, 2, 16, 16), device=device)}, 20)
 

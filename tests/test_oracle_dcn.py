@@ -123,3 +123,22 @@ def test_gridsample_formulation_passes_the_kats_and_the_module_forward():
     w_off, b_off = _rand(27, 4, 3, 3, seed=10).double() * 0.3, _rand(27, seed=11).double()
     np.testing.assert_allclose(gs.dcn_forward(x, w, b, w_off, b_off).numpy(),
                                odcn.dcn_forward(x, w, b, w_off, b_off).numpy(), atol=1e-9)
+
+
+def test_restatements_match_the_upstream_build():
+    """The pin of SURVEY row a6: the reference's OWN compiled DCNv2 CPU forward (oracle/_ref/libdcn_v2_ref.so, built by
+    `make -C oracle ref` from upstream's src/cpu sources behind oracle/ref_shim.cpp) against the three restatements,
+    on offsets from sub-pixel to far outside the image and exact border hits.  Skipped while the un-vendored submodule
+    is absent -- DCNv2 parity then stays 'unpinned'."""
+    from oracle import dcn_v2_upstream as up
+    if not up.available():
+        pytest.skip('oracle/_ref/libdcn_v2_ref.so not built: upstream DCNv2 sources are absent from /root/reference')
+    for seed, (B, Ci, Co, H, W), scale in ((31, (2, 8, 6, 9, 11), 0.7), (32, (1, 16, 27, 12, 10), 4.0), (33, (1, 4, 4, 5, 7), 15.0)):
+        x, w, b = _rand(B, Ci, H, W, seed=seed), _rand(Co, Ci, 3, 3, seed=seed + 100), _rand(Co, seed=seed + 200)
+        off = _rand(B, 18, H, W, seed=seed + 300, scale=scale)
+        off[:, :, 0, 0] = torch.round(off[:, :, 0, 0])           # exact integer hits incl. the border rows / columns
+        mask = torch.sigmoid(_rand(B, 9, H, W, seed=seed + 400))
+        want = up.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy())
+        np.testing.assert_allclose(odcn.dcn_v2_conv(x, off, mask, w, b).numpy(), want, atol=2e-5, rtol=1e-5)
+        np.testing.assert_allclose(dcn_v2_c.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy()), want,
+                                   atol=2e-5, rtol=1e-5)
