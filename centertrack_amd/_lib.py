@@ -115,6 +115,30 @@ class Track(ctypes.Structure):
                 ('row', ctypes.c_int)]
 
 
+class FrameLoopDesc(ctypes.Structure):
+    _fields_ = [('B', ctypes.c_int), ('K', ctypes.c_int), ('F', ctypes.c_int),
+                ('trackers', ctypes.POINTER(ctypes.c_void_p)),
+                ('layout', RowLayout),
+                ('out_thresh', ctypes.c_float), ('pre_thresh', ctypes.c_float),
+                ('inp_w', ctypes.c_int), ('inp_h', ctypes.c_int),
+                ('host_rows', ctypes.c_void_p), ('rows_keep', ctypes.c_void_p),
+                ('blob_params', ctypes.c_void_p), ('blob_counts', ctypes.c_void_p), ('blob_cap', ctypes.c_int),
+                ('nslots', ctypes.c_int),
+                ('graphs', ctypes.c_void_p * 3), ('frames', ctypes.c_void_p * 3),
+                ('frame_bytes', ctypes.c_size_t),
+                ('stream', ctypes.c_void_p),
+                ('results', ctypes.c_void_p), ('results_cap', ctypes.c_int)]
+
+
+class FrameStepArgs(ctypes.Structure):
+    _fields_ = [('slot', ctypes.c_int), ('frame_kind', ctypes.c_int),
+                ('frame', ctypes.c_void_p), ('next_frame', ctypes.c_void_p),
+                ('trans_input', ctypes.c_void_p), ('trans_inv', ctypes.c_void_p)]
+
+
+CT_FRAME_DEVICE, CT_FRAME_HOST, CT_FRAME_IN_PLACE, CT_FRAME_UPLOADED = range(4)
+
+
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
            'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_offsets_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_dcn_v2_group_plan', 'ct_stem_forward',
@@ -125,7 +149,10 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
            'ct_tracker_step_public', 'ct_tracker_step_dets', 'ct_transform_points',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
-           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_flip_merge', 'ct_flip_images']
+           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_flip_merge', 'ct_flip_images',
+           'ct_frame_loop_create', 'ct_frame_loop_destroy', 'ct_frame_loop_submit', 'ct_frame_loop_wait', 'ct_frame_loop_finish',
+           'ct_frame_loop_finish_submit', 'ct_frame_loop_upload', 'ct_frame_loop_pending_slot', 'ct_frame_loop_in_flight',
+           'ct_frame_loop_forget_upload']
 
 _lib = None
 
@@ -216,6 +243,19 @@ def load():
     lib.ct_calib_mfma.argtypes = [i, i, p, p]
     lib.ct_flip_merge.argtypes = [ctypes.POINTER(FlipHead), i, p, i, i, i, i, p]
     lib.ct_flip_images.argtypes = [p, p, sz, i, p]
+    lib.ct_frame_loop_create.restype = p
+    lib.ct_frame_loop_create.argtypes = [ctypes.POINTER(FrameLoopDesc)]
+    lib.ct_frame_loop_destroy.restype = None
+    lib.ct_frame_loop_destroy.argtypes = [p]
+    lib.ct_frame_loop_submit.argtypes = [p, ctypes.POINTER(FrameStepArgs)]
+    lib.ct_frame_loop_wait.argtypes = [p]
+    lib.ct_frame_loop_finish.argtypes = [p, ctypes.POINTER(FrameStepArgs), p]
+    lib.ct_frame_loop_finish_submit.argtypes = [p, ctypes.POINTER(FrameStepArgs), p, ctypes.POINTER(FrameStepArgs)]
+    lib.ct_frame_loop_upload.argtypes = [p, i, p]
+    lib.ct_frame_loop_pending_slot.argtypes = [p]
+    lib.ct_frame_loop_in_flight.argtypes = [p]
+    lib.ct_frame_loop_forget_upload.restype = None
+    lib.ct_frame_loop_forget_upload.argtypes = [p]
     # CENTERTRACK_TUNE="key=value,key=value": launch-heuristic knobs of ct_set_tuning (A/B runs)
     for kv in filter(None, os.environ.get('CENTERTRACK_TUNE', '').split(',')):
         k, _, v = kv.partition('=')

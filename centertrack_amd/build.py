@@ -8,7 +8,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(PKG)
 CSRC = os.path.join(PKG, 'csrc')
 LIB = os.path.join(PKG, 'libcentertrack_hip.so')
-SOURCES = ['api.cpp', 'runtime.hip', 'conv_mfma.hip', 'wino_mfma.hip', 'dcn_mfma.hip', 'stem.hip', 'elementwise.hip', 'decode.hip', 'pose.hip', 'host_track.cpp', 'host_preprocess.cpp', 'preprocess.hip', 'flip.hip']
+SOURCES = ['api.cpp', 'runtime.hip', 'conv_mfma.hip', 'wino_mfma.hip', 'dcn_mfma.hip', 'stem.hip', 'elementwise.hip', 'decode.hip', 'pose.hip', 'host_track.cpp', 'host_preprocess.cpp', 'preprocess.hip', 'flip.hip', 'frame_loop.hip']
 FLAGS = ['--offload-arch=gfx950', '-O3', '-std=c++17', '-fPIC', '-I' + os.path.join(ROOT, 'include'), '-I' + CSRC,
          '-Wno-unused-result']
 

@@ -10,9 +10,16 @@
 //            segment (+1 halo row each side) -> LDS, NMS from LDS, the strictly positive
 //            survivors (~10 % of the pixels) are compacted with wave ballots into an LDS
 //            list; if more than K survive, rank counting keeps the segment's top K.
-//   stage 2  one workgroup per image: exact radix select (wave-aggregated LDS histogram
-//            atomics) of the K-th key over all candidates, bitonic sort of the K winners,
-//            gathers + box arithmetic, packed row store.  If an image has fewer than K
+//   stage 2a (round 3; only when an image is expected to hold more candidates than stage 2 sorts in LDS) several
+//            workgroups per image: each sorts one slice of <= SLICE slots in LDS (bitonic) and keeps its K
+//            best -- the union of the slices' top K contains the image's top K -- so that stage 2 reads
+//            G x K keys instead of C x nseg x K with ONE workgroup (COCO x 4 streams: 128 000 slots per
+//            image on 4 workgroups = 92.9 us; r02_g_kstats_coco_512_b4.txt).
+//   stage 2  one workgroup per image: all non-empty candidates are compacted into LDS and sorted (bitonic,
+//            <= FCAP keys: one scan + ~66 compare-exchange rounds instead of two scans and two rank-counting
+//            loops); the K best are gathered: all head values + box arithmetic, packed row store.  More than
+//            FCAP candidates: threshold from the per-thread maxima + rank counting, or the exact radix select
+//            (wave-aggregated LDS histogram atomics) for adversarial layouts.  If an image has fewer than K
 //            strictly positive survivors (near-empty maps) the K winners are instead selected
 //            over ALL pixels with the NMS recomputed from HBM (slow, exact, rare).
 // Byte/index work: HBM/L2-bound, no matrix cores.
@@ -197,6 +204,8 @@ struct Stage2Args {
     float *out;
     long long *inds;
     int B, C, h, w, K, nseg, F;
+    int M2;                          // candidate slots per image
+    int keys_final;                  // the slots already hold (score : ~(class*HW + pixel)) keys (written by stage 2a)
 };
 
 // NMS'd score key of flat index f = cls*HW + p, straight from HBM (slow path only)
@@ -241,7 +250,53 @@ __device__ __forceinline__ void scan_cands(const unsigned long long *cand, int M
     }
 }
 
-constexpr int FCAP = 2048;        // capacity of the stage-2 filtered candidate list
+constexpr int FCAP = 4096;        // capacity of the stage-2 candidate list held (and sorted) in LDS
+constexpr int SLICE = 4096;       // slots per stage-2a workgroup
+
+// descending bitonic sort of n (a power of two) 64-bit keys in LDS by all threads of the workgroup
+__device__ __forceinline__ void bitonic_desc(unsigned long long *v, int n, int tid, int NT)
+{
+    for (int size = 2; size <= n; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int i = tid; i < (n >> 1); i += NT) {
+                const int lo = 2 * i - (i & (stride - 1));
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long x = v[lo], y = v[hi];
+                if ((x < y) == desc) { v[lo] = y; v[hi] = x; }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+struct Stage2aArgs {
+    const unsigned long long *cand;   // [B][M2] stage-1 keys (score : ~pixel), class = slot / per_class
+    unsigned long long *cand2;        // [B][G][K] final-form keys, sorted, unused slots = 0
+    int M2, G, K, per_class, HW;
+};
+
+__global__ __launch_bounds__(1024) void decode_stage2a_kernel(Stage2aArgs a)
+{
+    __shared__ unsigned long long v[SLICE];
+    const int b = blockIdx.x / a.G, g = blockIdx.x - b * a.G;
+    const int tid = threadIdx.x, NT = blockDim.x;
+    const int lo = g * SLICE, n = min(SLICE, a.M2 - lo);
+    const unsigned long long *cand = a.cand + (size_t)b * a.M2 + lo;
+    for (int i = tid; i < SLICE; i += NT) {
+        unsigned long long k = (i < n) ? cand[i] : 0ull;
+        if (k != 0ull) {
+            const unsigned cls = (unsigned)((lo + i) / a.per_class);
+            const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            k = (k & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (cls * (unsigned)a.HW + p));
+        }
+        v[i] = k;
+    }
+    __syncthreads();
+    bitonic_desc(v, SLICE, tid, NT);
+    unsigned long long *out = a.cand2 + ((size_t)b * a.G + g) * a.K;
+    for (int i = tid; i < a.K; i += NT) out[i] = v[i];
+}
 
 __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
 {
@@ -255,13 +310,13 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     const int b = blockIdx.x;
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int HW = a.h * a.w;
-    const int M2 = a.C * a.nseg * a.K;
+    const int M2 = a.M2;
     const unsigned long long *cand = a.cand + (size_t)b * M2;
     const int per_class = a.nseg * a.K;
 
     // key2 = score bits : ~(class*HW + pixel); empty slots (key 0) stay 0
     auto key2 = [&](int i, unsigned long long k) -> unsigned long long {
-        if (k == 0ull) return 0ull;
+        if (k == 0ull || a.keys_final) return k;
         const unsigned cls = (unsigned)(i / per_class);
         const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
         return (k & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (cls * (unsigned)HW + p));
@@ -272,22 +327,44 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     for (int i = tid; i < KP; i += NT) win[i] = 0ull;
     if (tid == 0) { slot = 0; total = 0; nf = 0; Lsh = 1ull; }
     __syncthreads();
-    // ---- pass 1: every thread's largest candidate + the number of candidates --------------------
-    {
-        unsigned long long mx = 0ull;
-        int cnt = 0;
-        scan_cands(cand, M2, tid, NT, [&](int i, unsigned long long raw) {
-            const unsigned long long k = key2(i, raw);
-            cnt += (k != 0ull) ? 1 : 0;
-            mx = (k > mx) ? k : mx;
-        });
-        lmax[tid] = mx;
-        for (int o = 32; o > 0; o >>= 1) cnt += __shfl_down(cnt, o);
-        if (lane == 0 && cnt) atomicAdd(&total, cnt);
-    }
+    // ---- pass 0: every non-empty candidate into LDS (ballot compaction), counted ------------------
+    scan_cands(cand, M2, tid, NT, [&](int i, unsigned long long raw) {
+        const unsigned long long k = key2(i, raw);
+        const bool hit = k != 0ull;
+        const unsigned long long mask = __ballot(hit);
+        int base = 0;
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(&total, (int)__popcll(mask));
+            base = __shfl(base, leader);
+        }
+        if (hit) {
+            const int sl = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+            if (sl < FCAP) filt[sl] = k;
+        }
+    });
     __syncthreads();
     bool need_sort = true;
-    if (total >= a.K) {
+    if (total >= a.K && total <= FCAP) {
+        // the common case: sort them all, the K best come out in order
+        int NP = KP;
+        while (NP < total) NP <<= 1;
+        for (int i = total + tid; i < NP; i += NT) filt[i] = 0ull;
+        __syncthreads();
+        bitonic_desc(filt, NP, tid, NT);
+        for (int i = tid; i < a.K; i += NT) win[i] = filt[i];
+        need_sort = false;
+    } else if (total >= a.K) {
+        // ---- more candidates than the LDS list holds: every thread's largest candidate first ----------
+        {
+            unsigned long long mx = 0ull;
+            scan_cands(cand, M2, tid, NT, [&](int i, unsigned long long raw) {
+                const unsigned long long k = key2(i, raw);
+                mx = (k > mx) ? k : mx;
+            });
+            lmax[tid] = mx;
+        }
+        __syncthreads();
         // L = K-th largest of the per-thread maxima (distinct keys): a lower bound of the K-th largest
         // candidate, so {k >= L} contains the top K and, for randomly spread scores, little more
         // (ranked among the first 256 threads' maxima only: ranking all 1024 costs more than the
@@ -353,20 +430,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         }
     }
     __syncthreads();
-    if (need_sort) {          // (block-uniform) bitonic sort, descending
-        for (int size = 2; size <= KP; size <<= 1) {
-            for (int stride = size >> 1; stride > 0; stride >>= 1) {
-                for (int i = tid; i < KP / 2; i += NT) {
-                    const int lo = 2 * i - (i & (stride - 1));
-                    const int hi = lo + stride;
-                    const bool desc = ((lo & size) == 0);
-                    const unsigned long long x = win[lo], y = win[hi];
-                    if ((x < y) == desc) { win[lo] = y; win[hi] = x; }
-                }
-                __syncthreads();
-            }
-        }
-    }
+    if (need_sort) bitonic_desc(win, KP, tid, NT);          // (block-uniform)
     for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
         const unsigned long long k = win[r];
         const float score = ord2f((unsigned)(k >> 32));
@@ -461,11 +525,24 @@ static int pick_seg(const ct_decode_desc *d)
     return seg;
 }
 
+// stage 2a groups per image (0 = stage 2 reads the stage-1 candidates itself): used when the expected number of
+// candidates -- ~1/9 of a segment's pixels survive the 3x3 NMS, at most K per segment are kept -- would overflow the
+// list stage 2 sorts in LDS (many classes, or segments of >= 1024 pixels)
+static int pick_groups(const ct_decode_desc *d, int seg, int nseg)
+{
+    const long M2 = (long)d->C * nseg * d->K;
+    const long per_seg = seg / 9 + 1 < d->K ? seg / 9 + 1 : d->K;
+    const long expected = (long)d->C * nseg * per_seg;
+    return (M2 > FCAP && expected > FCAP * 3 / 4) ? (int)((M2 + SLICE - 1) / SLICE) : 0;
+}
+
 extern "C" size_t ct_decode_workspace_bytes(const ct_decode_desc *d)
 {
     if (check(d, "ct_decode_workspace_bytes") != CT_OK) return 0;
-    const int nseg = ct_cdiv(d->h * d->w, pick_seg(d));
-    return (size_t)d->B * d->C * nseg * d->K * sizeof(unsigned long long);
+    const int seg = pick_seg(d);
+    const int nseg = ct_cdiv(d->h * d->w, seg);
+    const long M2 = (long)d->C * nseg * d->K;
+    return ((size_t)d->B * M2 + (size_t)d->B * pick_groups(d, seg, nseg) * d->K) * sizeof(unsigned long long);
 }
 
 extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
@@ -475,7 +552,9 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     if (!d->out) CT_FAIL_ARG("ct_decode: null output");
     const int seg = pick_seg(d);
     const int nseg = ct_cdiv(d->h * d->w, seg);
-    const size_t need = (size_t)d->B * d->C * nseg * d->K * sizeof(unsigned long long);
+    const long M2 = (long)d->C * nseg * d->K;
+    const int G = pick_groups(d, seg, nseg);
+    const size_t need = ((size_t)d->B * M2 + (size_t)d->B * G * d->K) * sizeof(unsigned long long);
     if (!d->workspace || d->workspace_bytes < need) {
         ct_set_error("ct_decode: needs %zu workspace bytes, got %zu", need, d->workspace_bytes);
         return CT_ERR_WORKSPACE;
@@ -509,8 +588,16 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     a2.B = d->B; a2.C = d->C; a2.h = d->h; a2.w = d->w; a2.K = d->K; a2.nseg = nseg;
     a2.F = d->out_stride ? d->out_stride : ct_decode_row_floats(d);   // floats between consecutive rows
     if (a2.F < ct_decode_row_floats(d)) CT_FAIL_ARG("ct_decode: out_stride %d < row floats", d->out_stride);
-    const long M2 = (long)d->C * nseg * d->K;
-    hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(M2 <= 2048 ? 256 : 1024), 0, s, a2);
+    a2.M2 = (int)M2; a2.keys_final = 0;
+    if (G > 0) {
+        Stage2aArgs aa;
+        aa.cand = a1.cand; aa.cand2 = a1.cand + (size_t)d->B * M2;
+        aa.M2 = (int)M2; aa.G = G; aa.K = d->K; aa.per_class = nseg * d->K; aa.HW = d->h * d->w;
+        hipLaunchKernelGGL(decode_stage2a_kernel, dim3((unsigned)(d->B * G)), dim3(1024), 0, s, aa);
+        CT_CHECK_LAUNCH("ct_decode(stage 2a)");
+        a2.cand = aa.cand2; a2.M2 = G * d->K; a2.keys_final = 1;
+    }
+    hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(a2.M2 <= 2048 ? 256 : 1024), 0, s, a2);
     CT_CHECK_LAUNCH("ct_decode(stage 2)");
     return CT_OK;
 }

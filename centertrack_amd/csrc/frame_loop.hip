@@ -1,0 +1,200 @@
+// Native host loop of one frame of B streams (round 3; VERDICT r2 item 3: "take the frame loop out of Python").
+//
+// Replaces, for the steady state of the native tracking path, the Python body of StreamDetector.step
+// (reference: src/lib/detector.py:139-165 -- process -> post_process -> merge_outputs -> tracker.step ->
+// pre_images = images -- and _get_additional_inputs, detector.py:254-290, at the top of the next run):
+//   submit  prior-heat-map blobs of every stream from its tracker (ct_tracker_prehm_params) into the pinned
+//           block the frame graph uploads, the frame into its rotation slot (or a device-side wait for the
+//           upload the previous call started), the frame graph, the upload of the NEXT frame into the next
+//           slot on the copy stream;
+//   finish  wait for the graph's last node (the D2H of the packed rows), then post-process + association of
+//           every stream (ct_tracker_step) into the caller's result buffers;
+//   finish + submit of the next frame in ONE call when the next frame is the one already being uploaded: the
+//           GPU idles for the association only, not for the trip back through the interpreter.
+// Frame buffers rotate over `nslots` slots (3 with a pre_img input): frame t sits in slot t % nslots and is
+// read as pre_img from there at t+1, so `self.pre_images = images` costs no copy, and frame t+1 can be
+// uploaded straight into its own slot while the graph of frame t still reads slots t and t-1 (no staging
+// buffer, no device-to-device copy on the critical path).
+#include <string.h>
+
+#include "ct_common.h"
+
+namespace {
+
+struct Loop {
+    ct_frame_loop_desc d;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t frame_ready = nullptr;     // the upload into the next slot finished (recorded on copy_stream)
+    int uploaded_slot = -1;               // slot the pending upload targets (-1: none)
+    bool in_flight = false;               // a graph was launched and not yet waited for
+    int flight_slot = -1;
+};
+
+int fail(const char *what, hipError_t e)
+{
+    ct_set_error("%s: %s", what, hipGetErrorString(e));
+    return CT_ERR_LAUNCH;
+}
+
+}  // namespace
+
+extern "C" void *ct_frame_loop_create(const ct_frame_loop_desc *d)
+{
+    if (!d || d->B <= 0 || d->K <= 0 || d->F <= 0 || !d->trackers || !d->host_rows || !d->results || d->results_cap <= 0 ||
+        d->nslots < 1 || d->nslots > 3 || d->frame_bytes == 0) {
+        ct_set_error("ct_frame_loop_create: bad descriptor");
+        return nullptr;
+    }
+    for (int i = 0; i < d->nslots; ++i)
+        if (!d->graphs[i] || !d->frames[i]) {
+            ct_set_error("ct_frame_loop_create: slot %d has no graph / frame buffer", i);
+            return nullptr;
+        }
+    if (d->blob_params && (!d->blob_counts || d->blob_cap <= 0)) {
+        ct_set_error("ct_frame_loop_create: blob_params without counts / capacity");
+        return nullptr;
+    }
+    Loop *L = new Loop();
+    L->d = *d;
+    hipError_t e = hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&L->frame_ready, hipEventDisableTiming);
+    if (e != hipSuccess) {
+        ct_set_error("ct_frame_loop_create: %s", hipGetErrorString(e));
+        if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
+        delete L;
+        return nullptr;
+    }
+    return L;
+}
+
+extern "C" void ct_frame_loop_destroy(void *loop)
+{
+    Loop *L = (Loop *)loop;
+    if (!L) return;
+    if (L->copy_stream) { (void)hipStreamSynchronize(L->copy_stream); (void)hipStreamDestroy(L->copy_stream); }
+    if (L->frame_ready) (void)hipEventDestroy(L->frame_ready);
+    delete L;
+}
+
+extern "C" int ct_frame_loop_pending_slot(void *loop) { return loop ? ((Loop *)loop)->uploaded_slot : -1; }
+
+extern "C" int ct_frame_loop_in_flight(void *loop) { return (loop && ((Loop *)loop)->in_flight) ? ((Loop *)loop)->flight_slot : -1; }
+
+extern "C" void ct_frame_loop_forget_upload(void *loop)
+{
+    Loop *L = (Loop *)loop;
+    if (!L) return;
+    if (L->uploaded_slot >= 0) (void)hipStreamSynchronize(L->copy_stream);     // (the slot may be rewritten by the caller)
+    L->uploaded_slot = -1;
+}
+
+extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
+{
+    Loop *L = (Loop *)loop;
+    if (!L || !a) CT_FAIL_ARG("ct_frame_loop_submit: null argument");
+    const ct_frame_loop_desc &d = L->d;
+    if (L->in_flight) CT_FAIL_ARG("ct_frame_loop_submit: the previous frame was not finished");
+    if (a->slot < 0 || a->slot >= d.nslots) CT_FAIL_ARG("ct_frame_loop_submit: slot %d of %d", a->slot, d.nslots);
+    hipStream_t s = (hipStream_t)d.stream;
+    // 1. prior heat-map blobs of every stream from its tracker state (detector.py:254-290, per-track part)
+    if (d.blob_params) {
+        if (!a->trans_input) CT_FAIL_ARG("ct_frame_loop_submit: trans_input missing");
+        for (int b = 0; b < d.B; ++b) {
+            const int n = ct_tracker_prehm_params(d.trackers[b], d.pre_thresh, a->trans_input + 6 * b, d.inp_w, d.inp_h,
+                                                  d.blob_params + (size_t)b * d.blob_cap * 3, d.blob_cap);
+            if (n < 0) return CT_ERR_ARG;
+            d.blob_counts[b] = n;
+        }
+    }
+    // 2. the frame into its slot
+    hipError_t e = hipSuccess;
+    if (a->frame_kind == CT_FRAME_UPLOADED) {
+        if (L->uploaded_slot != a->slot) CT_FAIL_ARG("ct_frame_loop_submit: no upload pending for slot %d (pending: %d)", a->slot, L->uploaded_slot);
+        e = hipStreamWaitEvent(s, L->frame_ready, 0);
+        if (e != hipSuccess) return fail("ct_frame_loop_submit(wait for the uploaded frame)", e);
+    } else if (a->frame_kind == CT_FRAME_DEVICE || a->frame_kind == CT_FRAME_HOST) {
+        if (!a->frame) CT_FAIL_ARG("ct_frame_loop_submit: null frame");
+        if (L->uploaded_slot == a->slot) {     // an upload nobody will use targets this slot: let it finish first
+            e = hipStreamWaitEvent(s, L->frame_ready, 0);
+            if (e != hipSuccess) return fail("ct_frame_loop_submit(wait for a stale upload)", e);
+        }
+        e = hipMemcpyAsync(d.frames[a->slot], a->frame, d.frame_bytes,
+                           a->frame_kind == CT_FRAME_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, s);
+        if (e != hipSuccess) return fail("ct_frame_loop_submit(frame copy)", e);
+    } else if (a->frame_kind != CT_FRAME_IN_PLACE) {
+        CT_FAIL_ARG("ct_frame_loop_submit: frame_kind %d", a->frame_kind);
+    }
+    L->uploaded_slot = -1;
+    // 3. the frame: one graph launch
+    e = hipGraphLaunch((hipGraphExec_t)d.graphs[a->slot], s);
+    if (e != hipSuccess) return fail("ct_frame_loop_submit(graph launch)", e);
+    L->in_flight = true;
+    L->flight_slot = a->slot;
+    // 4. upload of the next frame into the next slot (last read by the graph of the PREVIOUS frame, which the host
+    //    has already waited for)
+    if (a->next_frame) {
+        if (d.nslots < 2) CT_FAIL_ARG("ct_frame_loop_submit: uploading ahead needs >= 2 slots");
+        const int ns = (a->slot + 1) % d.nslots;
+        e = hipMemcpyAsync(d.frames[ns], a->next_frame, d.frame_bytes, hipMemcpyHostToDevice, L->copy_stream);
+        if (e == hipSuccess) e = hipEventRecord(L->frame_ready, L->copy_stream);
+        if (e != hipSuccess) return fail("ct_frame_loop_submit(upload of the next frame)", e);
+        L->uploaded_slot = ns;
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_frame_loop_upload(void *loop, int slot, const float *frame)
+{
+    Loop *L = (Loop *)loop;
+    if (!L || !frame) CT_FAIL_ARG("ct_frame_loop_upload: null argument");
+    const ct_frame_loop_desc &d = L->d;
+    if (slot < 0 || slot >= d.nslots) CT_FAIL_ARG("ct_frame_loop_upload: slot %d of %d", slot, d.nslots);
+    if (L->in_flight && (slot == L->flight_slot || (d.nslots == 3 && slot == (L->flight_slot + 2) % 3)))
+        CT_FAIL_ARG("ct_frame_loop_upload: slot %d is read by the frame in flight", slot);
+    hipError_t e = hipMemcpyAsync(d.frames[slot], frame, d.frame_bytes, hipMemcpyHostToDevice, L->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(L->frame_ready, L->copy_stream);
+    if (e != hipSuccess) return fail("ct_frame_loop_upload", e);
+    L->uploaded_slot = slot;
+    return CT_OK;
+}
+
+extern "C" int ct_frame_loop_wait(void *loop)
+{
+    Loop *L = (Loop *)loop;
+    if (!L) CT_FAIL_ARG("ct_frame_loop_wait: null loop");
+    if (!L->in_flight) return CT_OK;
+    hipError_t e = hipStreamSynchronize((hipStream_t)L->d.stream);
+    if (e != hipSuccess) return fail("ct_frame_loop_wait", e);
+    L->in_flight = false;
+    return CT_OK;
+}
+
+extern "C" int ct_frame_loop_finish(void *loop, const ct_frame_step_args *a, int *counts)
+{
+    Loop *L = (Loop *)loop;
+    if (!L || !a || !counts) CT_FAIL_ARG("ct_frame_loop_finish: null argument");
+    const ct_frame_loop_desc &d = L->d;
+    if (!a->trans_inv) CT_FAIL_ARG("ct_frame_loop_finish: trans_inv missing");
+    int rc = ct_frame_loop_wait(loop);
+    if (rc != CT_OK) return rc;
+    const float *rows = d.host_rows;
+    if (d.rows_keep) {
+        memcpy(d.rows_keep, d.host_rows, sizeof(float) * (size_t)d.B * d.K * d.F);
+        rows = d.rows_keep;
+    }
+    // post-process + association of every stream (post_process.py:21-91, detector.py:371-377, tracker.py:28-138)
+    for (int b = 0; b < d.B; ++b) {
+        const int n = ct_tracker_step(d.trackers[b], rows + (size_t)b * d.K * d.F, d.K, d.F, &d.layout, d.out_thresh,
+                                      a->trans_inv + 6 * b, d.results + (size_t)b * d.results_cap, d.results_cap);
+        if (n < 0) return CT_ERR_ARG;
+        counts[b] = n;
+    }
+    return CT_OK;
+}
+
+extern "C" int ct_frame_loop_finish_submit(void *loop, const ct_frame_step_args *cur, int *counts, const ct_frame_step_args *next)
+{
+    int rc = ct_frame_loop_finish(loop, cur, counts);
+    if (rc != CT_OK) return rc;
+    return ct_frame_loop_submit(loop, next);
+}

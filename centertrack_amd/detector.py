@@ -24,6 +24,7 @@ import numpy as np
 import torch
 
 from . import _lib, fast_track, ops
+NATIVE_LOOP = os.environ.get('CENTERTRACK_NATIVE_LOOP', '1') != '0'   # (A/B switch: 0 = the Python frame loop)
 from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, get_affine_transform, make_meta)
 from .model import create_model, load_model
 from .post_process import generic_post_process
@@ -230,19 +231,26 @@ class StreamDetector(object):
         if self.native:
             ctx['row_layout'] = fast_track.row_layout(ctx['decoder'].layout)
         # Frame buffers owned by THIS detector (the plan's activation buffers are shared by every detector of
-        # the model).  Two of them ping-pong: the frame of step t is written into buffer t & 1 and read as
-        # `pre_img` from there at step t+1, so the reference's `self.pre_images = images` (detector.py:148)
-        # costs no copy; one captured graph per parity.
-        ctx['frames'] = [torch.zeros_like(x_in), torch.zeros_like(x_in) if img_in is not None else None]
-        ctx['parity'] = 0
-        ctx['graphs'] = [None, None]
+        # the model).  They ROTATE: the frame of step t is written into slot t % nslots and read as `pre_img` from
+        # there at step t+1, so the reference's `self.pre_images = images` (detector.py:148) costs no copy; with three
+        # slots the frame of step t+1 can be uploaded straight into ITS slot while the graph of step t still reads
+        # slots t and t-1 (round 3: no staging buffer, no device-to-device copy between upload and launch); one
+        # captured graph per slot.
+        nslots = 3 if img_in is not None else 2
+        ctx['nslots'] = nslots
+        ctx['frames'] = [torch.zeros_like(x_in) for _ in range(nslots)]
+        ctx['slot'] = 0                    # slot of the NEXT frame
+        ctx['graphs'] = [None] * nslots
         ctx['raw'] = False
+        ctx['loop'] = None
+        ctx['launched'] = None             # (frame tensor, version, metas) of a frame the native loop launched ahead
+        ctx['copy_stream'] = None
 
-        def device_frame(parity=0, with_copies=False):
+        def device_frame(slot=0, with_copies=False):
             """all device work of one frame; ``with_copies``: also the H2D of the prior-heat-map blobs and the D2H
             of the packed detections (fixed pinned buffers), so that a captured frame is ONE graph launch"""
-            cur = ctx['frames'][parity if img_in is not None else 0]
-            prev = ctx['frames'][parity ^ 1] if img_in is not None else None
+            cur = ctx['frames'][slot]
+            prev = ctx['frames'][(slot - 1) % nslots] if img_in is not None else None
             if with_copies and render:
                 _lib.check(_lib.load().ct_memcpy_async(ctx['pc_dev'].data_ptr(), ctx['pc_host'].data_ptr(),
                                                        ctx['pc_host'].numel() * 4, 1, _lib.stream_ptr()), 'H2D')
@@ -282,14 +290,14 @@ class StreamDetector(object):
                 # only C-ABI launches inside device_frame (no torch op, flip_test included): capture / replay
                 # straight through HIP
                 raw = os.environ.get('CENTERTRACK_RAW_GRAPH', '1') != '0'
-                for par in ((0, 1) if img_in is not None else (0,)):
+                for sl in range(nslots):
                     if raw:
-                        g = _HipGraph(lambda: device_frame(par, True))
+                        g = _HipGraph(lambda: device_frame(sl, True))
                     else:
                         g = torch.cuda.CUDAGraph()
                         with torch.cuda.graph(g):
-                            device_frame(par)
-                    ctx['graphs'][par] = g
+                            device_frame(sl)
+                    ctx['graphs'][sl] = g
                 ctx['raw'] = raw
             except Exception as e:
                 # never degrade silently: the eager launches are the same kernels at a fraction of the frame rate
@@ -298,11 +306,52 @@ class StreamDetector(object):
                                        'CENTERTRACK_GRAPH_FALLBACK=1 to run eager launches' % (e,))
                 import warnings
                 warnings.warn('centertrack_amd: HIP graph capture failed (%s); using eager launches' % (e,))
-                ctx['graphs'] = [None, None]
+                ctx['graphs'] = [None] * nslots
                 torch.cuda.synchronize()
         ctx['graph'] = ctx['graphs'][0]
+        if ctx['raw'] and self.native and NATIVE_LOOP:
+            self._make_loop(ctx, H, W, render)
         self._ctx = ctx
         return ctx
+
+    def _make_loop(self, ctx, H, W, render):
+        """the native frame loop (ct_frame_loop_*, csrc/frame_loop.hip) over this context's graphs / buffers / trackers"""
+        lib = _lib.load()
+        B, K, F = ctx['decoder'].out.shape
+        d = _lib.FrameLoopDesc()
+        d.B, d.K, d.F = int(B), int(K), int(F)
+        ctx['loop_trackers'] = (ctypes.c_void_p * self.B)(*[f.h for f in self.fast])
+        d.trackers = ctypes.cast(ctx['loop_trackers'], ctypes.POINTER(ctypes.c_void_p))
+        d.layout = ctx['row_layout']
+        d.out_thresh, d.pre_thresh = float(self.opt.out_thresh), float(self.opt.pre_thresh)
+        d.inp_w, d.inp_h = int(W), int(H)
+        d.host_rows = ctx['host_out'].data_ptr()
+        ctx['rows_keep'] = np.zeros(tuple(ctx['decoder'].out.shape), np.float32)
+        d.rows_keep = ctx['rows_keep'].ctypes.data
+        if render:
+            d.blob_params, d.blob_counts = ctx['prm_host'].data_ptr(), ctx['cnt_host'].data_ptr()
+            d.blob_cap = ctx['max_blobs']
+        d.nslots = ctx['nslots']
+        for i in range(ctx['nslots']):
+            d.graphs[i] = ctx['graphs'][i].exec
+            d.frames[i] = ctx['frames'][i].data_ptr()
+        d.frame_bytes = self.B * 3 * H * W * 4
+        ctx['loop_stream'] = torch.cuda.current_stream()
+        d.stream = ctx['loop_stream'].cuda_stream
+        ctx['res_cap'] = self.fast[0].cap
+        ctx['res_buf'] = np.zeros((self.B, ctx['res_cap']), fast_track.TRACK_DTYPE)
+        d.results, d.results_cap = ctx['res_buf'].ctypes.data, ctx['res_cap']
+        h = lib.ct_frame_loop_create(ctypes.byref(d))
+        if not h:
+            raise _lib.CTError('ct_frame_loop_create: %s' % lib.ct_last_error().decode())
+        ctx['loop'] = ctypes.c_void_p(h)
+        ctx['loop_desc'] = d
+        ctx['counts'] = np.zeros(self.B, np.int32)
+        ctx['tin'] = np.zeros((self.B, 6), np.float64)
+        ctx['tinv'] = np.zeros((self.B, 6), np.float32)
+        ctx['args'] = [_lib.FrameStepArgs(), _lib.FrameStepArgs()]
+        for a in ctx['args']:
+            a.trans_input, a.trans_inv = ctx['tin'].ctypes.data, ctx['tinv'].ctypes.data
 
     def _warp_frame(self, s, image, meta, frames, H, W):
         """upload the raw u8 frame of stream ``s`` and warp / normalise it into ``frames[s]`` (and the mirrored copy
@@ -330,7 +379,120 @@ class StreamDetector(object):
                    'ct_preprocess_device')
 
     # ---- one frame for every stream -------------------------------------------------------
-    def step(self, images, metas, timers=None, prefetch=None):
+    def _meta_transforms(self, m):
+        """float64 [6] network-input affine and float32 [6] inverse output affine (post_process.py:30) of a frame's
+        meta, cached in the dict, keyed on the VALUES of c / s (an in-place edit or a recycled object id must not
+        resurrect a stale transform)"""
+        cached = m.get('_trans_inv')
+        c_, s_ = m['c'], m['s']
+        ident = (float(c_[0]), float(c_[1]), float(s_) if np.ndim(s_) == 0 else tuple(np.ravel(s_).tolist()),
+                 m['out_width'], m['out_height'])
+        if cached is None or cached[0] != ident:
+            tinv = np.ascontiguousarray(get_affine_transform(
+                m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1).astype(np.float32))
+            m['_trans_inv'] = cached = (ident, tinv)
+        return cached[1]
+
+    def _drop_launched(self, ctx):
+        """a frame the native loop launched ahead will not be used (other frame handed over, reset): wait for it and
+        give its slot back -- the trackers never saw it"""
+        if ctx.get('loop') is not None and ctx['launched'] is not None:
+            _lib.check(_lib.load().ct_frame_loop_wait(ctx['loop']), 'ct_frame_loop_wait')
+            ctx['slot'] = (ctx['slot'] - 1) % ctx['nslots']
+            ctx['launched'] = None
+
+    def _step_native(self, ctx, images, metas, timers, prefetch, prefetch_metas):
+        """steady state of the native tracking path: the frame loop of csrc/frame_loop.hip.  With ``prefetch`` AND
+        ``prefetch_metas`` the next frame is launched by the same native call that finishes this one."""
+        lib = _lib.load()
+        t0 = time.time()
+        B, n = self.B, ctx['nslots']
+        loop = ctx['loop']
+        launched = ctx['launched']
+        ahead = launched is not None and launched[0] is images and launched[1] == images._version
+        if launched is not None and not ahead:
+            self._drop_launched(ctx)
+        cur, nxt = ctx['args']
+        if ahead:
+            # this frame is already in flight; its prior heat-map was built with the metas promised last step
+            if any(a is not b for a, b in zip(launched[2], metas)) and [self._meta_transforms(m).tobytes() for m in metas] != launched[3]:
+                raise _lib.CTError('step(): the metas of this frame differ from the prefetch_metas promised for it')
+            ctx['launched'] = None
+            slot = (ctx['slot'] - 1) % n
+        else:
+            slot = ctx['slot']
+            tin, tinv = ctx['tin'], ctx['tinv']
+            for s_ in range(B):
+                tinv[s_] = self._meta_transforms(metas[s_]).reshape(-1)
+                tin[s_] = np.asarray(metas[s_]['trans_input'], np.float64).reshape(-1)
+            pf = self._prefetched
+            self._prefetched = None
+            cur.slot, cur.frame, cur.next_frame = slot, None, None
+            if pf is not None and pf[0] is images and pf[1] == images._version and pf[2] == slot:
+                cur.frame_kind = _lib.CT_FRAME_UPLOADED
+            elif images.dtype == torch.float32 and images.is_contiguous():
+                cur.frame_kind = _lib.CT_FRAME_DEVICE if images.device.type == 'cuda' else _lib.CT_FRAME_HOST
+                cur.frame = images.data_ptr()
+            else:
+                ctx['frames'][slot][:B].copy_(images)
+                cur.frame_kind = _lib.CT_FRAME_IN_PLACE
+            if pf is not None and cur.frame_kind != _lib.CT_FRAME_UPLOADED:
+                lib.ct_frame_loop_forget_upload(loop)
+        can_prefetch = (prefetch is not None and torch.is_tensor(prefetch) and prefetch.device.type == 'cpu'
+                        and prefetch.dtype == torch.float32 and prefetch.is_contiguous()
+                        and tuple(prefetch.shape) == tuple(images.shape))
+        t1 = time.time()
+        if ahead:
+            if can_prefetch:            # the frame after the one in flight: its slot was last read by the finished frame
+                _lib.check(lib.ct_frame_loop_upload(loop, (slot + 1) % n, prefetch.data_ptr()), 'ct_frame_loop_upload')
+        else:
+            if can_prefetch:
+                cur.next_frame = prefetch.data_ptr()
+            if self._rows_free is not None:                    # (left by a step of the Python path)
+                ctx['loop_stream'].wait_event(self._rows_free)
+                self._rows_free = None
+            _lib.check(lib.ct_frame_loop_submit(loop, ctypes.byref(cur)), 'ct_frame_loop_submit')
+            ctx['slot'] = (slot + 1) % n
+        if can_prefetch:
+            self._prefetched = (prefetch, prefetch._version, (slot + 1) % n)
+        if self.gather_fn is not None:
+            # (the hook enqueues its reader of the device rows behind this frame's graph; the event it returns is waited
+            # for ON THE STREAM right here, i.e. between this graph and the next one, whoever launches that)
+            ev = self.gather_fn(ctx['decoder'].out)
+            if isinstance(ev, torch.cuda.Event):
+                ctx['loop_stream'].wait_event(ev)
+        counts = ctx['counts']
+        early = (can_prefetch and prefetch_metas is not None
+                 and all(a is b for a, b in zip(prefetch_metas, metas)))
+        if early:
+            # finish this frame and launch the next one in ONE native call: the GPU idles for the association only
+            nxt.slot, nxt.frame_kind, nxt.frame, nxt.next_frame = (slot + 1) % n, _lib.CT_FRAME_UPLOADED, None, None
+            _lib.check(lib.ct_frame_loop_finish_submit(loop, ctypes.byref(cur), counts.ctypes.data, ctypes.byref(nxt)),
+                       'ct_frame_loop_finish_submit')
+            ctx['slot'] = (slot + 2) % n
+            ctx['launched'] = (prefetch, prefetch._version, list(metas),
+                               [self._meta_transforms(m).tobytes() for m in metas])
+            self._prefetched = None
+        else:
+            _lib.check(lib.ct_frame_loop_finish(loop, ctypes.byref(cur), counts.ctypes.data), 'ct_frame_loop_finish')
+        t2 = time.time()
+        self._last_dets = None
+        res, cap = ctx['res_buf'], ctx['res_cap']
+        out = []
+        for s_ in range(B):
+            k = int(counts[s_])
+            if k > cap:                                        # (max_age > 0 lets the track list grow: re-read it)
+                tmp = np.zeros(k, fast_track.TRACK_DTYPE)
+                got = lib.ct_tracker_get_tracks(self.fast[s_].h, tmp.ctypes.data, k)
+                out.append(tmp[:min(got, k)])
+            else:
+                out.append(res[s_, :k].copy())
+        if timers is not None:
+            timers.update({'pre': t1 - t0, 'net': t2 - t1, 'dec': 0.0, 'post': 0.0, 'merge': 0.0,
+                           'track': time.time() - t2})
+        return out
+
+    def step(self, images, metas, timers=None, prefetch=None, prefetch_metas=None):
         """images: float32 [B,3,H,W] (already normalised, like PrefetchDataset hands over), or a list of B raw
         uint8 HxWx3 frames, which are uploaded as bytes and warped / normalised on the device
         (``ct_preprocess_device``, bit-identical to ``Detector.pre_process``);
@@ -338,8 +500,9 @@ class StreamDetector(object):
         ``prefetch``: the float32 host tensor the NEXT call will pass as ``images`` (optional): its H2D copy is enqueued
         on a second HIP stream as soon as this frame's graph is launched and overlaps with it -- what the reference's
         ``DataLoader(pin_memory=True)`` + ``images.to(device, non_blocking=True)`` (test.py:74-76, detector.py:93-94) is
-        for; the next call then finds the frame in HBM (a staging buffer: the previous frame must stay intact as
-        ``pre_img`` while this one runs)."""
+        for; the copy lands in the NEXT frame's own rotation slot, so the next call launches without any device copy.
+        ``prefetch_metas``: the metas the next call will pass (the same objects as ``metas`` for a video whose frames
+        share one size): with them the native loop launches the next frame in the call that finishes this one."""
         opt = self.opt
         t0 = time.time()
         B = self.B
@@ -352,16 +515,23 @@ class StreamDetector(object):
         ctx = self._context(H, W)
         x_in, img_in, hm_in = ctx['plan']['inputs']
         lib = _lib.load()
+        if (ctx['loop'] is not None and not raw_frames and all(self.started) and tuple(images.shape) == (B, 3, H, W)
+                and not getattr(opt, 'public_det', False) and not getattr(opt, 'zero_tracking', False)):
+            return self._step_native(ctx, images, metas, timers, prefetch, prefetch_metas)
+        self._drop_launched(ctx)
         # (torch.cuda.current_stream() costs ~5 us of host time per call and the GPU idles while the host prepares a
         # frame: looked up once per step)
         cur = torch.cuda.current_stream()
         sp = ctypes.c_void_p(cur.cuda_stream)
-        par = ctx['parity'] if img_in is not None else 0
-        fr = ctx['frames'][par]
-        # ---- the frame goes straight into the graph's frame buffer (images [0, B); the mirrored images [B, 2B) of
+        n = ctx['nslots']
+        slot = ctx['slot']
+        fr = ctx['frames'][slot]
+        pf = self._prefetched
+        self._prefetched = None                                # (a frame uploaded ahead serves the very next call only)
+        # ---- the frame goes straight into its rotation slot (images [0, B); the mirrored images [B, 2B) of
         #      flip_test are built on the device by the frame's first launch, detector.py:224-226) ----
         if raw_frames:
-            self._prefetched = None
+            self._forget_upload(ctx, pf)
             for s in range(B):
                 self._warp_frame(s, images[s], metas[s], fr, H, W)
         else:
@@ -369,26 +539,23 @@ class StreamDetector(object):
                 images = images[:B]                            # (a pre-flipped batch: the copy is rebuilt on device)
             if tuple(images.shape) != (B, 3, H, W):
                 raise _lib.CTError('step() expects [%d,3,%d,%d] frames, got %s' % (B, H, W, tuple(images.shape)))
-            pf = self._prefetched
-            self._prefetched = None                            # (a frame uploaded ahead serves the very next call only)
             # the SAME tensor object, unmodified since it was handed over (an in-place edit bumps ``_version``; a new
-            # tensor at a recycled address is another object)
-            if pf is not None and pf[0] is images and pf[1] == images._version:
-                # uploaded by the previous step's ``prefetch`` while that frame was computed: staging -> frame buffer
-                cur.wait_event(pf[2])
-                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), ctx['stage'].data_ptr(), images.numel() * 4, 0, sp),
-                           'frame copy')
-                if ctx['stage_free'] is None:
-                    ctx['stage_free'] = torch.cuda.Event()
-                ctx['stage_free'].record(cur)                  # the staging buffer may be refilled once this copy ran
-            elif images.dtype == torch.float32 and images.is_contiguous():
-                # one DMA from wherever the caller keeps the frame: H2D for a host tensor (detector.py:93-94 -- pinned
-                # memory makes it asynchronous), D2D for a resident one
-                kind = 0 if images.device.type == 'cuda' else 1
-                _lib.check(lib.ct_memcpy_async(fr.data_ptr(), images.data_ptr(), images.numel() * 4, kind, sp),
-                           'frame copy')
+            # tensor at a recycled address is another object), uploaded into THIS slot
+            if pf is not None and pf[0] is images and pf[1] == images._version and pf[2] == slot:
+                if ctx['loop'] is not None:
+                    self._forget_upload(ctx, pf)                   # (uploaded by the native loop's copy stream: wait on the host; rare path)
+                else:
+                    cur.wait_event(ctx['frame_ready'])             # uploaded by the previous step's ``prefetch``
             else:
-                fr[:B].copy_(images)
+                self._forget_upload(ctx, pf)
+                if images.dtype == torch.float32 and images.is_contiguous():
+                    # one DMA from wherever the caller keeps the frame: H2D for a host tensor (detector.py:93-94 -- pinned
+                    # memory makes it asynchronous), D2D for a resident one
+                    kind = 0 if images.device.type == 'cuda' else 1
+                    _lib.check(lib.ct_memcpy_async(fr.data_ptr(), images.data_ptr(), images.numel() * 4, kind, sp),
+                               'frame copy')
+                else:
+                    fr[:B].copy_(images)
         tracking = bool(getattr(opt, 'tracking', False))
         if tracking:
             for s in range(B):
@@ -400,7 +567,7 @@ class StreamDetector(object):
                         self.trackers[s].init_track(pre_dets)
             if img_in is not None:
                 # first frame of a stream: pre_images = images (detector.py:99-103)
-                prev = ctx['frames'][par ^ 1]
+                prev = ctx['frames'][(slot - 1) % n]
                 fresh = [s for s in range(B) if not self.started[s]]
                 if fresh and self.flip:
                     _lib.check(lib.ct_flip_images(fr.data_ptr(), fr[B:].data_ptr(), B * 3 * H, W, sp), 'ct_flip_images')
@@ -434,29 +601,28 @@ class StreamDetector(object):
             cur.wait_event(self._rows_free)
             self._rows_free = None
         if ctx['raw']:
-            ctx['graphs'][par].replay(sp)
-        elif ctx['graphs'][par] is not None:
-            ctx['graphs'][par].replay()
+            ctx['graphs'][slot].replay(sp)
+        elif ctx['graphs'][slot] is not None:
+            ctx['graphs'][slot].replay()
         else:
-            ctx['device_frame'](par)
-        if img_in is not None:
-            ctx['parity'] ^= 1                                 # this frame is the next step's pre_img
+            ctx['device_frame'](slot)
+        ctx['slot'] = (slot + 1) % n                           # this frame is the next step's pre_img
         if (prefetch is not None and torch.is_tensor(prefetch) and prefetch.device.type == 'cpu'
                 and prefetch.dtype == torch.float32 and prefetch.is_contiguous() and tuple(prefetch.shape) == (B, 3, H, W)):
-            if 'stage' not in ctx:
-                ctx['stage'] = torch.empty((B, 3, H, W), dtype=torch.float32, device=self.device)
-                ctx['copy_stream'] = torch.cuda.Stream(device=self.device)
-                ctx['stage_free'] = None
-                ctx['stage_ready'] = torch.cuda.Event()
-                ctx['copy_sp'] = ctypes.c_void_p(ctx['copy_stream'].cuda_stream)
-            cs = ctx['copy_stream']
-            if ctx['stage_free'] is not None:                  # (the staging buffer was read by the D2D of this step)
-                cs.wait_event(ctx['stage_free'])
-            _lib.check(lib.ct_memcpy_async(ctx['stage'].data_ptr(), prefetch.data_ptr(), prefetch.numel() * 4, 1,
-                                           ctx['copy_sp']), 'prefetch')
-            ev = ctx['stage_ready']                            # (re-recorded every step; the waiter of the previous
-            ev.record(cs)                                      #  recording was enqueued at the top of this step)
-            self._prefetched = (prefetch, prefetch._version, ev)
+            # straight into the NEXT frame's slot: it was last read (as pre_img) by the previous frame's graph, which the
+            # host has waited for -- the graph just launched reads this slot and the one before it only
+            ns = (slot + 1) % n
+            if ctx['loop'] is not None:                        # (the next step may be the native loop's: its copy stream)
+                _lib.check(lib.ct_frame_loop_upload(ctx['loop'], ns, prefetch.data_ptr()), 'ct_frame_loop_upload')
+            else:
+                if ctx['copy_stream'] is None:
+                    ctx['copy_stream'] = torch.cuda.Stream(device=self.device)
+                    ctx['frame_ready'] = torch.cuda.Event()
+                    ctx['copy_sp'] = ctypes.c_void_p(ctx['copy_stream'].cuda_stream)
+                _lib.check(lib.ct_memcpy_async(ctx['frames'][ns].data_ptr(), prefetch.data_ptr(), prefetch.numel() * 4, 1,
+                                               ctx['copy_sp']), 'prefetch')
+                ctx['frame_ready'].record(ctx['copy_stream'])
+            self._prefetched = (prefetch, prefetch._version, ns)
         if self.gather_fn is not None:
             ev = self.gather_fn(ctx['decoder'].out)
             self._rows_free = ev if isinstance(ev, torch.cuda.Event) else None
@@ -467,6 +633,8 @@ class StreamDetector(object):
             cur.synchronize()
         t2 = time.time()
         rows = ctx['host_rows']
+        if ctx.get('rows_keep') is not None:
+            ctx['rows_keep'][...] = rows                       # (last_dets reads the kept copy when a native loop exists)
         self._last_dets = None                                 # unpacked on demand (last_dets)
         all_results = []
         t_post = t_track = 0.0
@@ -474,18 +642,7 @@ class StreamDetector(object):
             ta = time.time()
             for s in range(B):
                 m = metas[s]
-                # float32 inverse output affine (post_process.py:30), cached in the meta dict, keyed on the VALUES
-                # of c / s (an in-place edit or a recycled object id must not resurrect a stale transform)
-                cached = m.get('_trans_inv')
-                c_, s_ = m['c'], m['s']
-                ident = (float(c_[0]), float(c_[1]), float(s_) if np.ndim(s_) == 0 else tuple(np.ravel(s_).tolist()),
-                         m['out_width'], m['out_height'])
-                if cached is None or cached[0] != ident:
-                    tinv = np.ascontiguousarray(get_affine_transform(
-                        m['c'], m['s'], 0, (m['out_width'], m['out_height']), inv=1).astype(np.float32))
-                    m['_trans_inv'] = (ident, tinv)
-                else:
-                    tinv = cached[1]
+                tinv = self._meta_transforms(m)
                 pub = m['cur_dets'] if getattr(opt, 'public_det', False) else None       # detector.py:141-142
                 all_results.append(self.fast[s].step(rows[s], ctx['row_layout'], opt.out_thresh, tinv, pub).copy())
             t_track = time.time() - ta
@@ -510,16 +667,29 @@ class StreamDetector(object):
                            'track': t_track})
         return all_results
 
+    def _forget_upload(self, ctx, pf):
+        """a frame uploaded ahead is not the one handed over now: make sure its copy is not still writing a slot"""
+        if pf is None:
+            return
+        if ctx['loop'] is not None:
+            _lib.load().ct_frame_loop_forget_upload(ctx['loop'])
+        if ctx['copy_stream'] is not None:
+            ctx['copy_stream'].synchronize()
+
     @property
     def last_dets(self):
         """the reference's ``dets`` dict (decode.py:99-180) of the last step: numpy views of a per-frame COPY of the
         packed rows -- the pinned D2H buffer is overwritten by the next step, while the reference's
         ``.cpu().numpy()`` arrays (detector.py:349-350) stay valid for as long as a caller keeps the results"""
         if self._last_dets is None and self._ctx is not None:
-            self._last_dets = self._ctx['decoder'].unpack(self._ctx['host_rows'].copy())
+            keep = self._ctx.get('rows_keep')          # (the native loop may already be writing the next frame's rows)
+            self._last_dets = self._ctx['decoder'].unpack((keep if keep is not None else self._ctx['host_rows']).copy())
         return self._last_dets
 
     def reset_tracking(self, stream=None):
+        if self._ctx is not None:
+            self._drop_launched(self._ctx)
+            self._forget_upload(self._ctx, self._prefetched)
         for s in (range(self.B) if stream is None else [stream]):
             self.trackers[s].reset()
             if self.fast is not None:

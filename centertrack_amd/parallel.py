@@ -244,7 +244,9 @@ def run_steps(det, frame_of, metas, steps, frames_per_step, first=0):
     for _ in range(steps):
         for _ in range(frames_per_step):
             if ahead:
-                res = det.step(frame_of(t), metas, prefetch=frame_of(t + 1) if t < last else None)
+                # (frames of one video share their meta: the promise lets the native loop launch frame t+1 in the call
+                # that finishes frame t)
+                res = det.step(frame_of(t), metas, prefetch=frame_of(t + 1) if t < last else None, prefetch_metas=metas)
             else:
                 res = det.step(frame_of(t), metas)
             ndet += sum(len(r) for r in res)

@@ -359,6 +359,66 @@ int ct_stream_synchronize(void *stream);
  * measured on (bench.py's "box_calibration").  out: DEVICE float[>= blocks * 256] (never written in practice). */
 int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
 
+/* ---- the host loop of one frame of B streams, natively (round 3) ----------------------------------------------
+ * Replaces, for the steady state of the tracking path, the per-frame host work of Detector.run
+ * (src/lib/detector.py:139-165: process -> post_process -> merge_outputs -> tracker.step -> pre_images = images, and
+ * the per-track part of _get_additional_inputs, detector.py:254-290, of the NEXT run): no interpreter between the end
+ * of frame t and the launch of frame t+1.  The caller (centertrack_amd/detector.py) describes the loop once:
+ * B trackers, the packed-row layout, the pinned host blocks the frame graph's copy nodes use (host_rows: destination
+ * of its last node; blob_params / blob_counts: source of its first node, NULL without a prior heat-map), one
+ * executable graph (ct_graph_end) and one DEVICE frame buffer per rotation slot -- frame t lives in slot t % nslots
+ * and is read as pre_img from there by the graph of slot (t+1) % nslots -- and the result buffers.
+ *   ct_frame_loop_submit   prior-heat-map blobs from the trackers, the frame into slot `slot` (frame_kind: copy from
+ *                          DEVICE / pinned HOST memory, already IN_PLACE, or UPLOADED = wait on the device for the upload
+ *                          the previous submit started), graph launch, upload of `next_frame` (pinned HOST) into the
+ *                          next slot on a copy stream;
+ *   ct_frame_loop_wait     block until the frame in flight finished (rows are in host_rows);
+ *   ct_frame_loop_finish   wait + post-process / association of every stream: counts[b] tracks in
+ *                          results[b * results_cap ..] (n > results_cap: grow and read ct_tracker_get_tracks);
+ *   ct_frame_loop_finish_submit   both, back to back (frame t+1 = the frame uploaded ahead);
+ *   ct_frame_loop_upload   the upload alone (when the frame in flight was launched by a finish_submit and the caller
+ *                          only now learns the frame after it).
+ * trans_input: float64 [B][2][3] network-input affine of each stream's frame (prior heat-map); trans_inv: float32
+ * [B][2][3] output-grid -> image affine (post-process).  One frame in flight at a time. */
+enum { CT_FRAME_DEVICE = 0, CT_FRAME_HOST = 1, CT_FRAME_IN_PLACE = 2, CT_FRAME_UPLOADED = 3 };
+typedef struct ct_frame_loop_desc {
+    int B, K, F;
+    void *const *trackers;                 /* [B] ct_tracker_create handles */
+    ct_row_layout layout;
+    float out_thresh, pre_thresh;
+    int inp_w, inp_h;
+    const float *host_rows;                /* pinned HOST [B,K,F] */
+    float *rows_keep;                      /* HOST [B,K,F] or NULL: finish copies the rows here first and works on the copy,
+                                              so that results / the decode dict of frame t stay valid while the graph of
+                                              frame t+1 (launched by the same call) overwrites host_rows */
+    int *blob_params, *blob_counts;        /* pinned HOST [B][blob_cap][3], [B]; NULL = no prior heat-map */
+    int blob_cap;
+    int nslots;                            /* 1 .. 3 */
+    void *graphs[3];
+    float *frames[3];
+    size_t frame_bytes;                    /* bytes of one frame batch as the caller hands it over ([B,3,H,W] fp32) */
+    void *stream;
+    ct_track *results; int results_cap;    /* HOST [B][results_cap] */
+} ct_frame_loop_desc;
+typedef struct ct_frame_step_args {
+    int slot, frame_kind;
+    const float *frame;                    /* DEVICE / HOST source (frame_kind 0 / 1), else ignored */
+    const float *next_frame;               /* pinned HOST frame to upload for the next call, or NULL */
+    const double *trans_input;
+    const float *trans_inv;
+} ct_frame_step_args;
+void *ct_frame_loop_create(const ct_frame_loop_desc *d);      /* NULL on error */
+void ct_frame_loop_destroy(void *loop);
+int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a);
+int ct_frame_loop_wait(void *loop);
+int ct_frame_loop_finish(void *loop, const ct_frame_step_args *a, int *counts);
+int ct_frame_loop_finish_submit(void *loop, const ct_frame_step_args *cur, int *counts, const ct_frame_step_args *next);
+int ct_frame_loop_upload(void *loop, int slot, const float *frame);   /* upload a pinned HOST frame into `slot` on the copy stream
+                                                                         (the frame a later submit names with CT_FRAME_UPLOADED) */
+int ct_frame_loop_pending_slot(void *loop);      /* slot an upload is pending for, or -1 */
+int ct_frame_loop_in_flight(void *loop);         /* slot of the frame in flight, or -1 */
+void ct_frame_loop_forget_upload(void *loop);    /* drop a pending upload (waits for the copy) */
+
 /* ---- image pre-processing (CPU, like the reference's: it runs in DataLoader worker processes) -----
  * Replaces the cv2.warpAffine + normalise + HWC->CHW (+ flipped copy) of Detector.pre_process
  * (src/lib/detector.py:207-239).  img: HOST u8 [h, w, channels] (row pitch `stride` bytes); trans: float64

@@ -81,7 +81,17 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
         pytest.skip('no gcc')
     checks = {'ct_dcn_desc': (_lib.DcnDesc, ['x', 'om', 'w_packed', 'workspace', 'fuse_offset', 'w_off_packed', 'up_w',
                                              'up_ldy', 'om_partial', 'om_partial_bytes']),
-              'ct_conv_desc': (_lib.ConvDesc, ['x', 'split_k', 'algo', 'w_winograd'])}
+              'ct_conv_desc': (_lib.ConvDesc, ['x', 'split_k', 'algo', 'w_winograd']),
+              'ct_pose_desc': (_lib.PoseDesc, ['rows', 'box_col', 'hp_offset', 'out', 'workspace_bytes', 'box_wh', 'box_ltrb',
+                                               'box_ltrb_batch_stride']),
+              'ct_decode_desc': (_lib.DecodeDesc, ['hm', 'heads', 'out', 'hm_batch_stride', 'out_stride']),
+              'ct_heads_desc': (_lib.HeadsDesc, ['x', 'w0_winograd', 'cout', 'out', 'depth_scale']),
+              'ct_frame_loop_desc': (_lib.FrameLoopDesc, ['B', 'trackers', 'layout', 'out_thresh', 'host_rows', 'rows_keep',
+                                                          'blob_params', 'blob_cap', 'nslots', 'graphs', 'frames',
+                                                          'frame_bytes', 'stream', 'results', 'results_cap']),
+              'ct_frame_step_args': (_lib.FrameStepArgs, ['slot', 'frame_kind', 'frame', 'next_frame', 'trans_input',
+                                                          'trans_inv']),
+              'ct_track': (_lib.Track, ['score', 'ct', 'bbox', 'tracking_id', 'row'])}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "centertrack_hip.h"', 'int main(void) {']
     for cname, (_, fields) in checks.items():
         lines.append('printf("%s %%zu\\n", sizeof(%s));' % (cname, cname))

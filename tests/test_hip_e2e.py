@@ -144,7 +144,7 @@ def test_run_on_raw_uint8_frames(device):
         want_img = oimage.pre_process_image(frame, meta['trans_input'], cfg['W'], cfg['H'], MEAN, STD)
         np.testing.assert_array_equal(images.numpy(), want_img)
         ctx = det.impl._ctx
-        np.testing.assert_array_equal(ctx['frames'][ctx['parity'] ^ 1].cpu().numpy(), want_img)   # device warp
+        np.testing.assert_array_equal(ctx['frames'][(ctx['slot'] - 1) % ctx['nslots']].cpu().numpy(), want_img)   # device warp
         want = oracle.run(torch.from_numpy(want_img), dict(meta))
         assert len(want) > 0
         _check_frame(ret['results'], want, t, 'raw frames')
@@ -177,7 +177,7 @@ def test_raw_frame_streams_with_flip_equal_host_preprocessed_streams(device):
         got = dev_det.step(frames, [dict(m) for m in metas])
         want = host_det.step(torch.cat([p[0][0:1] for p in pre], 0), metas)
         cd, ch = dev_det._ctx, host_det._ctx
-        assert torch.equal(cd['frames'][cd['parity'] ^ 1], ch['frames'][ch['parity'] ^ 1])
+        assert torch.equal(cd['frames'][(cd['slot'] - 1) % cd['nslots']], ch['frames'][(ch['slot'] - 1) % ch['nslots']])
         for s in range(B):
             assert [(int(r['tracking_id']), float(r['score'])) + tuple(map(float, r['bbox'])) for r in got[s]] == \
                    [(int(r['tracking_id']), float(r['score'])) + tuple(map(float, r['bbox'])) for r in want[s]]
@@ -359,3 +359,87 @@ def test_side_stream_gather_hook_consumes_every_frame(device):
     assert counts == want_counts and g.consumed_steps == len(frames)
     assert g.verify(hooked._ctx['decoder'].out) == 1
     assert len(parallel.check_same_plan(DLASegHIP.plan_signature(ctx['plan']))) == 16
+
+
+def _stream_setup(B):
+    import scenarios as S
+    from centertrack_amd.detector import default_opt
+    from centertrack_amd.model import DLASegHIP
+    cfg = dict(S.e2e_config(), T=8)
+    sd = S.e2e_state_dict(cfg)
+    opt = default_opt(cfg['heads'], track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'])
+    model = DLASegHIP(cfg['heads'])
+    model.load_state_dict(sd)
+    frames = list(S.e2e_frames(cfg))
+    meta = frames[0][1]
+    # B streams: stream s sees the sequence shifted by s frames (pinned host tensors, like a DataLoader's)
+    T = len(frames) - B + 1
+    batches = [torch.cat([frames[t + s][0] for s in range(B)], 0).pin_memory() for t in range(T)]
+    return opt, model, batches, meta
+
+
+@pytest.mark.parametrize('B', [1, 2])
+def test_native_frame_loop_equals_python_loop(device, monkeypatch, B):
+    """round 3: the native frame loop (ct_frame_loop_*: blobs from the trackers, frame into its rotation slot, graph
+    launch, upload of the next frame into ITS slot, wait, association -- and the next frame launched by the call that
+    finishes this one) gives bit-identical results, decode rows and ids to the Python loop, with and without
+    prefetching, and when a promised frame is replaced by another one."""
+    from centertrack_amd import detector as D
+    opt, model, batches, meta = _stream_setup(B)
+    T = len(batches)
+    metas = [dict(meta) for _ in range(B)]
+
+    def run(native, mode):
+        monkeypatch.setattr(D, 'NATIVE_LOOP', native)
+        det = D.StreamDetector(opt, model=model, num_streams=B)
+        out = []
+        for t in range(T):
+            kw = {}
+            if mode in ('prefetch', 'early', 'broken') and t + 1 < T:
+                kw['prefetch'] = batches[t + 1]
+            if mode in ('early', 'broken') and t + 1 < T:
+                kw['prefetch_metas'] = metas
+            img = batches[t]
+            if mode == 'broken' and t == 3:
+                img = batches[t].clone()               # NOT the tensor that was promised (and launched ahead)
+            res = det.step(img, metas, **kw)
+            rows = {k: np.array(v) for k, v in det.last_dets.items()}
+            out.append(([r.copy() for r in res], rows))
+        assert (det._ctx['loop'] is not None) == native
+        return out
+    ref = run(False, 'plain')
+    for native, mode in ((False, 'prefetch'), (True, 'plain'), (True, 'prefetch'), (True, 'early'), (True, 'broken')):
+        got = run(native, mode)
+        for t in range(T):
+            for s in range(B):
+                a, b = ref[t][0][s], got[t][0][s]
+                assert len(a) == len(b) and len(a) > 0, (native, mode, t, s)
+                for f in ('tracking_id', 'score', 'bbox', 'ct', 'tracking', 'class', 'age', 'active', 'row'):
+                    np.testing.assert_array_equal(a[f], b[f], err_msg='%s %s frame %d stream %d %s' % (native, mode, t, s, f))
+            for k in ref[t][1]:
+                np.testing.assert_array_equal(ref[t][1][k], got[t][1][k], err_msg='%s %s frame %d rows %s' % (native, mode, t, k))
+
+
+def test_native_loop_reset_tracking_and_single_detector_run(device):
+    """Detector.run (no prefetch) goes through the native loop from the second frame on; reset_tracking() in the middle
+    of a prefetched stream drops the frame launched ahead and starts over: the second pass equals the first."""
+    from centertrack_amd import detector as D
+    opt, model, batches, meta = _stream_setup(1)
+    det = D.StreamDetector(opt, model=model, num_streams=1)
+    metas = [dict(meta)]
+
+    def play(n):
+        out = []
+        for t in range(n):
+            res = det.step(batches[t], metas, prefetch=batches[t + 1] if t + 1 < len(batches) else None,
+                           prefetch_metas=metas)
+            out.append(res[0].copy())
+        return out
+    first = play(4)                                    # (frame 4 has been launched ahead by now)
+    assert det._ctx['launched'] is not None
+    det.reset_tracking()
+    assert det._ctx['launched'] is None
+    second = play(4)
+    for a, b in zip(first, second):
+        for f in ('tracking_id', 'score', 'bbox'):
+            np.testing.assert_array_equal(a[f], b[f])

@@ -599,6 +599,38 @@ def test_decode_pose_rejects_what_it_does_not_implement(device):
         ops.Decoder(hm, {'hps': hps, 'wh': torch.rand((1, 2, 16, 16), device=device)}, 20)
 
 
+@pytest.mark.parametrize('name,C,h,w,B,K,dense', [
+    ('coco_x2', 80, 128, 128, 2, 100, False),          # 128 000 slots per image: stage 2a (32 slices) + stage 2
+    ('kitti_x4', 3, 96, 320, 4, 100, False),           # 1024-pixel segments, every one full: stage 2a (3 slices)
+    ('nusc_x1', 10, 112, 200, 1, 100, False),          # 44 000 slots, stage 2a
+    ('mot_x1', 1, 128, 128, 1, 100, False),            # ~1800 candidates: compacted and sorted in LDS by stage 2 alone
+    ('dense_160', 1, 160, 160, 1, 100, True),          # 6400 peaks (> the LDS list): threshold + rank-counting path
+    ('dense_k512', 2, 160, 160, 1, 512, True),         # the same with the largest K
+])
+def test_decode_selection_paths_full_size(device, name, C, h, w, B, K, dense):
+    """every selection path of stage 2 / 2a (round 3) against the oracle's generic_decode: indices, classes, scores
+    and boxes bit-exact"""
+    from collections import OrderedDict
+    from centertrack_amd import ops
+    from oracle import decode as odecode
+    g = torch.Generator().manual_seed(len(name) * 131 + C)
+    hm = (torch.rand((B, C, h, w), generator=g, dtype=torch.float64) ** 2 * 0.98 + 0.001).float()
+    if dense:                                          # a peak on every other pixel in both directions
+        peaks = torch.zeros_like(hm)
+        peaks[:, :, 0::2, 0::2] = 0.5 + 0.45 * torch.rand((B, C, (h + 1) // 2, (w + 1) // 2), generator=g)
+        hm = torch.maximum(hm * 0.3, peaks)
+    maps = OrderedDict([('hm', hm), ('reg', torch.rand((B, 2, h, w), generator=g)), ('wh', torch.rand((B, 2, h, w), generator=g) * 9),
+                        ('tracking', torch.randn((B, 2, h, w), generator=g))])
+    dev = {k: v.to(device).contiguous() for k, v in maps.items()}
+    dec = ops.Decoder(dev['hm'], {k: v for k, v in dev.items() if k != 'hm'}, K)
+    got = dec.unpack(dec.run().cpu().numpy())
+    inds = dec.inds.cpu().numpy()
+    want = odecode.generic_decode({k: v.clone() for k, v in maps.items()}, K=K, return_inds=True)
+    np.testing.assert_array_equal(inds, want['inds'].numpy(), err_msg=name + ' inds')
+    for k in ('scores', 'clses', 'xs', 'ys', 'bboxes', 'tracking'):
+        np.testing.assert_array_equal(got[k], want[k].numpy(), err_msg='%s.%s' % (name, k))
+
+
 def test_decode_nms_plateau_and_ties(device):
     """KAT-5: equal neighbours are both kept by the 3x3 NMS; exact ties order by lower
     class, then lower pixel (documented tie rule; torch leaves it unspecified)."""
