@@ -672,7 +672,9 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         DcnPlan &p = plans[i];
         int rc = make_plan(d, &p, grouped);
         if (rc != CT_OK) return rc;
-        if (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK)
+        // (one MAIN launch = one kernel instantiation; the OFFSETS / FINISH launches do not depend on the tile shape, so
+        //  layers whose MAIN launches differ -- e.g. in channels per step -- may share them)
+        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK))
             CT_FAIL_ARG("ct_dcn_v2_group: layer %d resolves to another tile shape than layer 0", i);
         const size_t need = ws_bytes(d, p);
         if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {

@@ -20,6 +20,7 @@ from .ops import View
 from .weights import CHANNELS, LEVELS, dla34_param_shapes
 
 BN_EPS = 1e-5
+SMALL_SLOT_WGS = 600      # a MAIN slot with fewer workgroups than this (of 768 resident ones) may split K finer
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
@@ -44,7 +45,7 @@ class _Launch(object):
 class _DcnLayer(object):
     """One DeformConv node of the IDAUp tree (dla.py:506-518) waiting to be scheduled: input view, output view, the
     fused IDAUp step ``up`` = (weight, f, skip view, output view) of a `proj` node."""
-    __slots__ = ('name', 'x', 'cout', 'out', 'up', 'main', 'finish', 'desc', 'fused', 'splits', 'use_ws')
+    __slots__ = ('name', 'x', 'cout', 'out', 'up', 'main', 'finish', 'desc', 'fused', 'splits', 'use_ws', 'nkk')
 
     def __init__(self, name, x, cout, out, up):
         self.name, self.x, self.cout, self.out, self.up = name, x, cout, out, up
@@ -474,11 +475,21 @@ class DLASegHIP(torch.nn.Module):
         over 64-channel chunks in ONE CT_DCN_OFFSETS launch for all layers of the slot (split_offsets = 1, one
         workgroup per 32-pixel tile and chunk whatever Cin) or by one conv launch per layer (0); every workgroup
         contracts chunks_per_split 32-channel chunks, in steps of 16 * nkk channels (nkk = 2 / 4: 16 / 32 MFMAs per
-        wave between barriers)."""
+        wave between barriers).  knobs[4] (round 3) = chunks per split of the SMALL slots: at one stream the three `proj`
+        slots hold 256 .. 384 workgroups of 18 (chunk, tap) steps each on 768 workgroup slots -- one wave per SIMD,
+        nothing to hide the gather latency behind -- while their layers go through the workspace anyway (IDAUp step in
+        the finishing launch); splitting K twice as fine fills the chip and halves every workgroup's loop.  0 = off,
+        2 = two chunks per split, 1 = one chunk per split (then in 32-channel steps)."""
         lib = _lib.load()
         P = self._prepared
         fuse_max_cin, cps, nkk = knobs[:3]
         split_offsets = knobs[3] if len(knobs) > 3 else 1
+        cps_small = knobs[4] if len(knobs) > 4 else 0
+        slot_cps = {}
+        if cps_small and cps_small < cps:
+            for t, wgs in self._dcn_slot_sizes(layers, produced0, N, cps).items():
+                if wgs < SMALL_SLOT_WGS:
+                    slot_cps[t] = cps_small
         time_of = dict(produced0)                    # buffer id -> time after which it is readable
 
         def t_of(view):
@@ -491,8 +502,10 @@ class DLASegHIP(torch.nn.Module):
             pk = P[ly.name]
             ly.fused = ly.x.C % 64 == 0 and ly.x.C <= fuse_max_cin and FUSE_OFFSET
             nchunks = ly.x.C // 32
-            ly.splits = max(1, nchunks // cps)
             ly.main = t_of(ly.x) // 2 + 1
+            c = slot_cps.get(ly.main, cps)
+            ly.nkk = 2 if (c == 1 or ly.x.C % 64) else nkk
+            ly.splits = max(1, nchunks // c)
             om = part = None
             raw = False
             if not ly.fused and split_offsets == 2 and ly.x.C % 64 == 0 and pk['w_off_wino'] is not None:
@@ -551,7 +564,7 @@ class DLASegHIP(torch.nn.Module):
                 keep = []
                 for j, ly in enumerate(part):
                     ctypes.memmove(ctypes.byref(arr[j]), ctypes.byref(ly.desc[0]), ctypes.sizeof(_lib.DcnDesc))
-                    arr[j].algo = 43264 if nkk == 4 else 3264
+                    arr[j].algo = 43264 if ly.nkk == 4 else 3264
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
@@ -566,6 +579,27 @@ class DLASegHIP(torch.nn.Module):
             if slots[t]['finish']:
                 group(slots[t]['finish'], _lib.CT_DCN_FINISH, 'dcn.finish')
         return out
+
+    @staticmethod
+    def _dcn_slot_sizes(layers, produced0, N, cps):
+        """{MAIN slot: workgroups} of the schedule with ``cps`` chunks per split everywhere (the slot of a layer does
+        not depend on how finely it is split: a split layer is readable one time step later, which rounds to the same
+        next slot)"""
+        time_of = dict(produced0)
+        sizes = {}
+        for ly in layers:
+            main = time_of.get(id(ly.x.buf), 0) // 2 + 1
+            splits = max(1, (ly.x.C // 32) // cps)
+            use_ws = splits > 1 or ly.up is not None
+            if use_ws:
+                fin = max(main, (time_of.get(id(ly.up[2].buf), 0) + 1) // 2) if ly.up is not None else main
+                done = 2 * fin + 1
+            else:
+                done = 2 * main
+            time_of[id((ly.up[3] if ly.up is not None else ly.out).buf)] = done
+            tiles = N * ((ly.x.H + 1) // 2) * ((ly.x.W + 15) // 16) * ((ly.cout + 63) // 64)
+            sizes[main] = sizes.get(main, 0) + tiles * splits
+        return sizes
 
     def _time_launches(self, launches, reps=10):
         """device time (us) of a launch list, by graph replay on a side stream"""
@@ -608,13 +642,17 @@ class DLASegHIP(torch.nn.Module):
         if env:
             knobs = tuple(int(v) for v in env.split(','))
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs, tune)
-        default = (128, 4, 2, 1)
+        default = (128, 4, 2, 1, 0)
         if not tune:
             return default, self._schedule_dcn(layers, produced0, N, dev, default, tune)
-        key = 'dcnplan3:%d,%d,%d' % (N, H, W)
+        key = 'dcnplan4:%d,%d,%d' % (N, H, W)
+        key3 = 'dcnplan3:%d,%d,%d' % (N, H, W)          # (round-2 tables: four knobs, no fine-split slots)
         autotune._load_file()
         if key in autotune._CACHE:
-            knobs = tuple(int(v) for v in autotune._CACHE[key][:4])
+            knobs = tuple(int(v) for v in autotune._CACHE[key][:5])
+            return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
+        if key3 in autotune._CACHE and os.environ.get('CENTERTRACK_DCN_RETUNE', '0') != '1':
+            knobs = tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0,)
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         best = None
         # (split_offsets = 0 -- one conv launch per un-fused layer -- never won in round 2's sweeps: 368 against 336 us
@@ -625,14 +663,16 @@ class DLASegHIP(torch.nn.Module):
             for cps in (2, 4, 8):
                 for nkk in (2, 4):
                     for so in ((1, 2) if fuse_max < 256 else (1,)):
-                        knobs = (fuse_max, cps, nkk, so)
-                        launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
-                        us = self._time_launches(launches)
-                        if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
-                            print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us' % (N, H, W, knobs, len(launches), us))
-                        if best is None or us < best[0]:
-                            best = (us, knobs)
-                        del launches
+                        small = [t for t, w in self._dcn_slot_sizes(layers, produced0, N, cps).items() if w < SMALL_SLOT_WGS]
+                        for cs in ((0,) + tuple(c for c in (2, 1) if c < cps) if small else (0,)):
+                            knobs = (fuse_max, cps, nkk, so, cs)
+                            launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
+                            us = self._time_launches(launches)
+                            if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
+                                print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us' % (N, H, W, knobs, len(launches), us))
+                            if best is None or us < best[0]:
+                                best = (us, knobs)
+                            del launches
         autotune._CACHE[key] = tuple(best[1]) + (round(best[0], 1),)
         autotune._save_file()
         return best[1], self._schedule_dcn(layers, produced0, N, dev, best[1])

@@ -165,7 +165,7 @@ def test_pinned_table_wins_over_a_user_cache_and_is_never_copied_into_it(tmp_pat
     from centertrack_amd import autotune
     with open(autotune.PINNED_TABLE) as f:
         pinned = json.load(f)
-    key = 'dcnplan3:1,512,512'
+    key = sorted(k for k in pinned if k.startswith('dcnplan'))[0]
     stale = {key: [0, 2, 2, 1, 999.0], 'conv:user-only-key': [3, 1, 5.0]}
     cache = tmp_path / 'cache.json'
     cache.write_text(json.dumps(stale))
@@ -195,17 +195,19 @@ def test_pinned_tune_table_is_well_formed():
     with open(autotune.PINNED_TABLE) as f:
         t = json.load(f)
     plans = {k: v for k, v in t.items() if k.startswith('dcnplan')}
-    assert len(plans) >= 20 and all(k.startswith('dcnplan3:') for k in plans)
+    assert len(plans) >= 20 and all(k.startswith(('dcnplan3:', 'dcnplan4:')) for k in plans)
     for k, v in plans.items():
         n, h, w = (int(x) for x in k.split(':')[1].split(','))
         assert n >= 1 and h % 32 == 0 and w % 32 == 0
-        assert len(v) == 5 and v[0] in (0, 64, 128, 256) and v[1] in (2, 4, 8) and v[2] in (2, 4) and v[3] in (1, 2), (k, v)
-        assert v[4] > 0
+        nk = 4 if k.startswith('dcnplan3:') else 5             # (round 3 added the fine-split knob of the small slots)
+        assert len(v) == nk + 1 and v[0] in (0, 64, 128, 256) and v[1] in (2, 4, 8) and v[2] in (2, 4) and v[3] in (1, 2), (k, v)
+        assert nk == 4 or v[4] in (0, 1, 2), (k, v)
+        assert v[nk] > 0
     for k, v in t.items():
         if k.startswith('conv'):
             assert len(v) == 3 and v[2] > 0, (k, v)
-    for must in ('dcnplan3:1,512,512', 'dcnplan3:8,384,1280', 'dcnplan3:4,512,512', 'dcnplan3:4,448,800'):
-        assert must in t, must                                 # BASELINE configs 2 / 3 / 4 / 5
+    for must in ('1,512,512', '8,384,1280', '4,512,512', '4,448,800'):
+        assert 'dcnplan3:' + must in t or 'dcnplan4:' + must in t, must          # BASELINE configs 2 / 3 / 4 / 5
 
 
 def test_tools_compile():

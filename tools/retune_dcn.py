@@ -1,7 +1,7 @@
 #!/usr/bin/env python
-"""Re-measure the DCN schedule knobs (`dcnplan3:N,H,W`) for every (streams, size) the pinned table holds and write the
+"""Re-measure the DCN schedule knobs (`dcnplan4:N,H,W`, five knobs since round 3) for every (streams, size) the pinned table holds and write the
 merged table: run on the GPU box with CENTERTRACK_TUNE_CACHE=<out.json>; the conv entries of the pinned table are
-kept, stale `dcnplan2:*` entries dropped.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
+kept, `dcnplan2:*` / `dcnplan3:*` entries dropped.  Optional further arguments: N,H,W shapes to restrict the run to.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
 import json
 import os
 import sys
@@ -19,6 +19,8 @@ from centertrack_amd.model import DLASegHIP  # noqa: E402
 table = autotune._read_table(autotune.PINNED_TABLE)
 shapes = sorted({tuple(int(v) for v in k.split(':')[1].split(',')) for k in table if k.startswith('dcnplan')},
                 key=lambda t: t[0] * t[1] * t[2])
+if len(sys.argv) > 2:
+    shapes = [tuple(int(v) for v in a.split(',')) for a in sys.argv[2:]]
 autotune._load_file()
 for k in [k for k in autotune._CACHE if k.startswith('dcnplan')]:      # (measured again below)
     del autotune._CACHE[k]
@@ -29,10 +31,13 @@ for (N, H, Wd) in shapes:
     model.load_state_dict(sd)
     model = model.to('cuda')
     plan = model.get_plan(N, H, Wd, True, True, True)
-    print('dcnplan3:%d,%d,%d -> %s' % (N, H, Wd, (plan['dcn_knobs'],)), flush=True)
+    print('dcnplan4:%d,%d,%d -> %s' % (N, H, Wd, (plan['dcn_knobs'],)), flush=True)
     del plan, model
     torch.cuda.empty_cache()
-merged = {k: list(v) for k, v in autotune._CACHE.items() if not k.startswith('dcnplan2:')}
+merged = {k: list(v) for k, v in table.items() if not k.startswith('dcnplan')}       # (the cache file holds un-pinned keys only)
+merged.update({k: list(v) for k, v in autotune._CACHE.items() if not k.startswith(('dcnplan2:', 'dcnplan3:'))})
+if len(sys.argv) > 2:       # partial run: keep the round-2 schedules of the other shapes
+    merged.update({k: list(v) for k, v in table.items() if k.startswith('dcnplan3:') and k.replace('dcnplan3', 'dcnplan4') not in merged})
 with open(out, 'w') as f:
     json.dump(dict(sorted(merged.items())), f, indent=0)
 print('%d keys -> %s' % (len(merged), out))
