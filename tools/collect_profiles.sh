@@ -4,7 +4,7 @@
 #   as MI355X_MICROARCH.md prescribes) of the SAME bench command, summarised into gpurun_out/profiles_new/.
 # usage (from the repo root on the GPU box):  bash tools/collect_profiles.sh <tag>     e.g. r02_a
 set -u
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
@@ -25,5 +25,6 @@ python tools/pmc_stats.py $(ls /tmp/pmcA/*counter_collection.csv /tmp/pmcA/*/*co
 python tools/pmc_stats.py $(ls /tmp/pmcB/*counter_collection.csv /tmp/pmcB/*/*counter_collection.csv 2>/dev/null | head -1) 30 > $OUT/${TAG}_pmc_fetch_size.txt
 python tools/pmc_stats.py $(ls /tmp/pmcC/*counter_collection.csv /tmp/pmcC/*/*counter_collection.csv 2>/dev/null | head -1) 30 > $OUT/${TAG}_pmc_write_size.txt
 python tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_size.txt $OUT/${TAG}_pmc_write_size.txt $TAG > $OUT/pmc_traffic.json
+python tools/dcn_profiled.py $OUT/${TAG}_rocprofv3_kernel_stats_bench_steps3.txt | sed "s#$OUT/#profiles/#" > $OUT/dcn_profiled.json
 cat $OUT/${TAG}_bench_n1.json
 tail -12 $OUT/pmc_traffic.json
