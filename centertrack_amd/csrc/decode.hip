@@ -251,7 +251,7 @@ __device__ __forceinline__ void scan_cands(const unsigned long long *cand, int M
 }
 
 constexpr int FCAP = 4096;        // capacity of the stage-2 candidate list held (and sorted) in LDS
-constexpr int SLICE = 4096;       // slots per stage-2a workgroup
+constexpr int SLICE = 8192;       // slots per stage-2a workgroup (8 per thread, kept in registers)
 
 // descending bitonic sort of n (a power of two) 64-bit keys in LDS by all threads of the workgroup
 __device__ __forceinline__ void bitonic_desc(unsigned long long *v, int n, int tid, int NT)
@@ -270,6 +270,123 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long *v, int n, int t
     }
 }
 
+
+// ---- top-K of <= 8 keys per thread (1024 threads: <= 8192 keys) by a linear score histogram ------------------
+// The keys sit in REGISTERS (one global round trip, no second scan, no sort of the whole set): 1024 bins over the
+// score range (0, 1) -- heat maps are post-sigmoid -- are filled with wave-aggregated LDS atomics, one suffix scan
+// finds the bin b* that holds the K-th largest key, every key in a higher bin is a winner, the keys of b* itself
+// (a handful) are ranked by counting and the best `need` of them complete the set.  Exact for any input; a boundary
+// bin with more than TIECAP keys (scores clustered in < 1/1024 of the range) reports overflow and the caller falls
+// back to the general path.
+constexpr int SEL_U = 8;          // keys per thread
+constexpr int SEL_BINS = 1024;
+constexpr int TIECAP = 1024;
+
+struct SelShared {
+    unsigned hist[SEL_BINS];
+    int wsum[16];
+    unsigned long long tie[TIECAP];
+    int bstar, need, total, nwin, ntie;
+};
+
+__device__ __forceinline__ int sel_bin(unsigned long long k)
+{
+    const float sc = ord2f((unsigned)(k >> 32));
+    const int b = (int)(sc * (float)SEL_BINS);
+    return b < 0 ? 0 : (b > SEL_BINS - 1 ? SEL_BINS - 1 : b);
+}
+
+// keys[u]: 0 = empty.  On return: -1 = fewer than K keys in total (sh.total holds their number; with `keep_all` they
+// are all in win[0 .. total)), -2 = boundary bin overflow (nothing written), else K: win[0 .. K) hold the K largest
+// keys, unsorted.  blockDim.x must be 1024.  win must hold >= K slots.
+__device__ __forceinline__ int select_topk_regs(const unsigned long long (&keys)[SEL_U], int K, SelShared &sh,
+                                                unsigned long long *win, bool keep_all)
+{
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    sh.hist[tid] = 0u;
+    if (tid == 0) { sh.bstar = -1; sh.need = 0; sh.total = 0; sh.nwin = 0; sh.ntie = 0; }
+    __syncthreads();
+    int bins[SEL_U];
+#pragma unroll
+    for (int u = 0; u < SEL_U; ++u) {
+        bins[u] = sel_bin(keys[u]);
+        hist_add(sh.hist, (unsigned)bins[u], keys[u] != 0ull);
+    }
+    __syncthreads();
+    // suffix sums over the 1024 bins: thread t owns bin t
+    const int c = (int)sh.hist[tid];
+    int suf = c;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_down(suf, o);
+        if (lane + o < 64) suf += t;
+    }
+    if (lane == 0) sh.wsum[wave] = suf;
+    __syncthreads();
+    int hi = 0;
+    for (int w = wave + 1; w < 16; ++w) hi += sh.wsum[w];
+    const int incl = suf + hi, above = incl - c;          // keys in bins >= t / > t
+    if (tid == 0) sh.total = incl;
+    if (above < K && incl >= K) { sh.bstar = tid; sh.need = K - above; }
+    __syncthreads();
+    const int total = sh.total;
+    if (total < K) {
+        if (keep_all) {
+#pragma unroll
+            for (int u = 0; u < SEL_U; ++u) {
+                const bool hit = keys[u] != 0ull;
+                const unsigned long long mask = __ballot(hit);
+                int base = 0;
+                if (mask) {
+                    const int leader = __ffsll((long long)mask) - 1;
+                    if (lane == leader) base = atomicAdd(&sh.nwin, (int)__popcll(mask));
+                    base = __shfl(base, leader);
+                }
+                if (hit) win[base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = keys[u];
+            }
+            __syncthreads();
+        }
+        return -1;
+    }
+    const int bstar = sh.bstar, need = sh.need;
+#pragma unroll
+    for (int u = 0; u < SEL_U; ++u) {
+        const bool live = keys[u] != 0ull;
+        const bool hit = live && bins[u] > bstar;
+        const bool tied = live && bins[u] == bstar;
+        unsigned long long mask = __ballot(hit);
+        int base = 0;
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(&sh.nwin, (int)__popcll(mask));
+            base = __shfl(base, leader);
+        }
+        if (hit) win[base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = keys[u];
+        mask = __ballot(tied);
+        if (mask) {
+            const int leader = __ffsll((long long)mask) - 1;
+            if (lane == leader) base = atomicAdd(&sh.ntie, (int)__popcll(mask));
+            base = __shfl(base, leader);
+        }
+        if (tied) {
+            const int sl = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
+            if (sl < TIECAP) sh.tie[sl] = keys[u];
+        }
+    }
+    __syncthreads();
+    const int m = sh.ntie;
+    if (m > TIECAP) return -2;
+    const int first = K - need;                            // = number of keys above the boundary bin
+    for (int i = tid; i < m; i += 1024) {
+        const unsigned long long k = sh.tie[i];
+        int r = 0;
+        for (int j = 0; j < m; ++j) r += (sh.tie[j] > k) ? 1 : 0;
+        if (r < need) win[first + r] = k;
+    }
+    __syncthreads();
+    return K;
+}
+
 struct Stage2aArgs {
     const unsigned long long *cand;   // [B][M2] stage-1 keys (score : ~pixel), class = slot / per_class
     unsigned long long *cand2;        // [B][G][K] final-form keys, sorted, unused slots = 0
@@ -278,24 +395,54 @@ struct Stage2aArgs {
 
 __global__ __launch_bounds__(1024) void decode_stage2a_kernel(Stage2aArgs a)
 {
-    __shared__ unsigned long long v[SLICE];
+    __shared__ SelShared sh;
+    __shared__ unsigned long long win[MAXK];
+    __shared__ unsigned rhist[256];
+    __shared__ unsigned long long rbcast[2];
+    __shared__ int rslot;
     const int b = blockIdx.x / a.G, g = blockIdx.x - b * a.G;
     const int tid = threadIdx.x, NT = blockDim.x;
     const int lo = g * SLICE, n = min(SLICE, a.M2 - lo);
     const unsigned long long *cand = a.cand + (size_t)b * a.M2 + lo;
-    for (int i = tid; i < SLICE; i += NT) {
+    unsigned long long keys[SEL_U];
+#pragma unroll
+    for (int u = 0; u < SEL_U; ++u) {
+        const int i = tid + u * NT;
         unsigned long long k = (i < n) ? cand[i] : 0ull;
         if (k != 0ull) {
             const unsigned cls = (unsigned)((lo + i) / a.per_class);
             const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
             k = (k & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (cls * (unsigned)a.HW + p));
         }
-        v[i] = k;
+        keys[u] = k;
     }
+    for (int i = tid; i < a.K; i += NT) win[i] = 0ull;
     __syncthreads();
-    bitonic_desc(v, SLICE, tid, NT);
     unsigned long long *out = a.cand2 + ((size_t)b * a.G + g) * a.K;
-    for (int i = tid; i < a.K; i += NT) out[i] = v[i];
+    const int rc = select_topk_regs(keys, a.K, sh, win, true);
+    if (rc != -2) {
+        for (int i = tid; i < a.K; i += NT) out[i] = win[i];
+        return;
+    }
+    // scores clustered inside one histogram bin: exact radix select over the slice (>= K keys exist)
+    auto get = [&](int i) -> unsigned long long {
+        unsigned long long k = cand[i];
+        if (k != 0ull) {
+            const unsigned cls = (unsigned)((lo + i) / a.per_class);
+            const unsigned p = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            k = (k & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (cls * (unsigned)a.HW + p));
+        }
+        return k;
+    };
+    if (tid == 0) rslot = 0;
+    __syncthreads();
+    const unsigned long long T = radix_select_kth(get, n, a.K, rhist, rbcast);
+#pragma unroll
+    for (int u = 0; u < SEL_U; ++u)
+        if (keys[u] >= T && keys[u] != 0ull) {
+            const int sl = atomicAdd(&rslot, 1);
+            if (sl < a.K) out[sl] = keys[u];
+        }
 }
 
 __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
@@ -305,6 +452,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     __shared__ unsigned long long win[MAXK];
     __shared__ unsigned long long lmax[1024];
     __shared__ unsigned long long filt[FCAP];
+    __shared__ SelShared sel;
     __shared__ unsigned long long Lsh;
     __shared__ int slot, total, nf;
     const int b = blockIdx.x;
@@ -327,6 +475,34 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     for (int i = tid; i < KP; i += NT) win[i] = 0ull;
     if (tid == 0) { slot = 0; total = 0; nf = 0; Lsh = 1ull; }
     __syncthreads();
+    bool need_sort = true;
+    bool selected = false;
+    if (M2 <= SEL_U * 1024 && NT == 1024) {
+        // ---- the common case (round 3): <= 8 candidates per thread, kept in registers; histogram select ----
+        unsigned long long keys[SEL_U];
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const int i = tid + u * NT;
+            keys[u] = (i < M2) ? key2(i, cand[i]) : 0ull;
+        }
+        const int rc = select_topk_regs(keys, a.K, sel, filt, false);
+        if (rc == a.K) {
+            // sort the K winners by counting (distinct keys)
+            for (int i = tid; i < a.K; i += NT) {
+                const unsigned long long k = filt[i];
+                int r = 0;
+                for (int j = 0; j < a.K; ++j) r += (filt[j] > k) ? 1 : 0;
+                win[r] = k;
+            }
+            need_sort = false;
+            selected = true;
+        } else if (rc == -1) {
+            if (tid == 0) total = sel.total;              // fewer than K candidates: the exact slow path below
+            selected = true;
+        }
+        __syncthreads();
+    }
+    if (!selected) {
     // ---- pass 0: every non-empty candidate into LDS (ballot compaction), counted ------------------
     scan_cands(cand, M2, tid, NT, [&](int i, unsigned long long raw) {
         const unsigned long long k = key2(i, raw);
@@ -344,9 +520,11 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         }
     });
     __syncthreads();
-    bool need_sort = true;
-    if (total >= a.K && total <= FCAP) {
-        // the common case: sort them all, the K best come out in order
+    }
+    if (selected && need_sort == false) {
+        // (winners already in win[])
+    } else if (!selected && total >= a.K && total <= FCAP) {
+        // sort them all, the K best come out in order
         int NP = KP;
         while (NP < total) NP <<= 1;
         for (int i = total + tid; i < NP; i += NT) filt[i] = 0ull;
@@ -354,7 +532,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         bitonic_desc(filt, NP, tid, NT);
         for (int i = tid; i < a.K; i += NT) win[i] = filt[i];
         need_sort = false;
-    } else if (total >= a.K) {
+    } else if (!selected && total >= a.K) {
         // ---- more candidates than the LDS list holds: every thread's largest candidate first ----------
         {
             unsigned long long mx = 0ull;
@@ -525,15 +703,14 @@ static int pick_seg(const ct_decode_desc *d)
     return seg;
 }
 
-// stage 2a groups per image (0 = stage 2 reads the stage-1 candidates itself): used when the expected number of
-// candidates -- ~1/9 of a segment's pixels survive the 3x3 NMS, at most K per segment are kept -- would overflow the
-// list stage 2 sorts in LDS (many classes, or segments of >= 1024 pixels)
+// stage 2a groups per image (0 = stage 2 reads the stage-1 candidates itself): one group per 8192 candidate slots
 static int pick_groups(const ct_decode_desc *d, int seg, int nseg)
 {
     const long M2 = (long)d->C * nseg * d->K;
-    const long per_seg = seg / 9 + 1 < d->K ? seg / 9 + 1 : d->K;
-    const long expected = (long)d->C * nseg * per_seg;
-    return (M2 > FCAP && expected > FCAP * 3 / 4) ? (int)((M2 + SLICE - 1) / SLICE) : 0;
+    (void)seg;
+    if (M2 <= SLICE) return 0;                            // stage 2 holds them all in registers
+    const long G = (M2 + SLICE - 1) / SLICE;
+    return (int)G;
 }
 
 extern "C" size_t ct_decode_workspace_bytes(const ct_decode_desc *d)
@@ -597,7 +774,7 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
         CT_CHECK_LAUNCH("ct_decode(stage 2a)");
         a2.cand = aa.cand2; a2.M2 = G * d->K; a2.keys_final = 1;
     }
-    hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(a2.M2 <= 2048 ? 256 : 1024), 0, s, a2);
+    hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(1024), 0, s, a2);
     CT_CHECK_LAUNCH("ct_decode(stage 2)");
     return CT_OK;
 }

@@ -604,21 +604,35 @@ def test_decode_pose_rejects_what_it_does_not_implement(device):
     ('kitti_x4', 3, 96, 320, 4, 100, False),           # 1024-pixel segments, every one full: stage 2a (3 slices)
     ('nusc_x1', 10, 112, 200, 1, 100, False),          # 44 000 slots, stage 2a
     ('mot_x1', 1, 128, 128, 1, 100, False),            # ~1800 candidates: compacted and sorted in LDS by stage 2 alone
-    ('dense_160', 1, 160, 160, 1, 100, True),          # 6400 peaks (> the LDS list): threshold + rank-counting path
-    ('dense_k512', 2, 160, 160, 1, 512, True),         # the same with the largest K
+    ('dense_160', 1, 160, 160, 1, 100, True),          # 6400 peaks, 10 000 slots: stage 2a + stage 2
+    ('dense_k512', 2, 160, 160, 1, 512, True),         # the same with the largest K: stage 2 gets 13 x 512 keys
+    ('cluster_mot', 1, 128, 128, 1, 100, 'cluster'),   # every score inside ONE histogram bin: the general path of stage 2
+    ('cluster_coco', 20, 128, 128, 2, 100, 'cluster'),  # ... and the radix-select fallback of stage 2a
 ])
 def test_decode_selection_paths_full_size(device, name, C, h, w, B, K, dense):
-    """every selection path of stage 2 / 2a (round 3) against the oracle's generic_decode: indices, classes, scores
-    and boxes bit-exact"""
+    """every selection path of stage 2 / 2a (round 3: candidates in registers, linear score histogram, ranked boundary
+    bin; fallbacks for clustered scores) against the oracle's generic_decode: indices, classes, scores and boxes
+    bit-exact.  Scores are DISTINCT by construction (a permutation of an arithmetic sequence): exact float32 ties among
+    the top K would be ordered arbitrarily by torch.topk."""
     from collections import OrderedDict
     from centertrack_amd import ops
     from oracle import decode as odecode
     g = torch.Generator().manual_seed(len(name) * 131 + C)
-    hm = (torch.rand((B, C, h, w), generator=g, dtype=torch.float64) ** 2 * 0.98 + 0.001).float()
-    if dense:                                          # a peak on every other pixel in both directions
-        peaks = torch.zeros_like(hm)
-        peaks[:, :, 0::2, 0::2] = 0.5 + 0.45 * torch.rand((B, C, (h + 1) // 2, (w + 1) // 2), generator=g)
-        hm = torch.maximum(hm * 0.3, peaks)
+    n = B * C * h * w
+    distinct = ((torch.randperm(n, generator=g).double() + 1) / (n + 1)).view(B, C, h, w)      # n distinct values in (0, 1)
+    if dense == 'cluster':
+        # ~1850 peaks per class and image (every third pixel), those of class c ALL inside histogram bin 300 + 10 c
+        # (1/1024 wide), 2e-7 apart -- distinct float32 values, far more than the boundary bin's tie list holds
+        hm = (distinct * 0.2).float()
+        ph, pw = (h + 2) // 3, (w + 2) // 3
+        for c in range(C):
+            rank = torch.randperm(B * ph * pw, generator=g).double().view(B, ph, pw)
+            hm[:, c, 0::3, 0::3] = ((300 + 10 * c) / 1024.0 + 1e-5 + 2e-7 * rank).float()
+    elif dense:                                        # a peak on every other pixel in both directions
+        hm = (distinct * 0.3).float()
+        hm[:, :, 0::2, 0::2] = (0.5 + 0.45 * distinct[:, :, 0::2, 0::2]).float()
+    else:
+        hm = (distinct * 0.98 + 0.001).float()
     maps = OrderedDict([('hm', hm), ('reg', torch.rand((B, 2, h, w), generator=g)), ('wh', torch.rand((B, 2, h, w), generator=g) * 9),
                         ('tracking', torch.randn((B, 2, h, w), generator=g))])
     dev = {k: v.to(device).contiguous() for k, v in maps.items()}
