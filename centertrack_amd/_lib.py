@@ -115,6 +115,12 @@ class Track(ctypes.Structure):
                 ('row', ctypes.c_int)]
 
 
+class PrestageDesc(ctypes.Structure):
+    _fields_ = [('enabled', ctypes.c_int), ('N', ctypes.c_int), ('H', ctypes.c_int), ('W', ctypes.c_int),
+                ('w_x', ctypes.c_void_p), ('w_img', ctypes.c_void_p), ('scale3', ctypes.c_void_p), ('shift3', ctypes.c_void_p),
+                ('partial', ctypes.c_void_p * 3), ('ldp', ctypes.c_int), ('flip_B', ctypes.c_int)]
+
+
 class FrameLoopDesc(ctypes.Structure):
     _fields_ = [('B', ctypes.c_int), ('K', ctypes.c_int), ('F', ctypes.c_int),
                 ('trackers', ctypes.POINTER(ctypes.c_void_p)),
@@ -127,7 +133,7 @@ class FrameLoopDesc(ctypes.Structure):
                 ('graphs', ctypes.c_void_p * 3), ('frames', ctypes.c_void_p * 3),
                 ('frame_bytes', ctypes.c_size_t),
                 ('stream', ctypes.c_void_p),
-                ('results', ctypes.c_void_p), ('results_cap', ctypes.c_int)]
+                ('results', ctypes.c_void_p), ('results_cap', ctypes.c_int), ('pre', PrestageDesc)]
 
 
 class FrameStepArgs(ctypes.Structure):
@@ -152,7 +158,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_flip_merge', 'ct_flip_images',
            'ct_frame_loop_create', 'ct_frame_loop_destroy', 'ct_frame_loop_submit', 'ct_frame_loop_wait', 'ct_frame_loop_finish',
            'ct_frame_loop_finish_submit', 'ct_frame_loop_upload', 'ct_frame_loop_pending_slot', 'ct_frame_loop_in_flight',
-           'ct_frame_loop_forget_upload']
+           'ct_frame_loop_forget_upload', 'ct_frame_loop_prestage', 'ct_stem_forward_parts']
 
 _lib = None
 
@@ -199,6 +205,7 @@ def load():
     lib.ct_dcn_v2_group_workspace_bytes.argtypes = [ctypes.POINTER(DcnDesc)]
     lib.ct_dcn_v2_group_plan.argtypes = [ctypes.POINTER(DcnDesc), ctypes.POINTER(ctypes.c_size_t), ctypes.POINTER(ctypes.c_int)]
     lib.ct_stem_forward.argtypes = [p, p, p, i, i, i, p, p, p, p, p, p, i, p]
+    lib.ct_stem_forward_parts.argtypes = [p, p, p, p, i, i, i, i, p, p, p, p, p, p, i, p]
     lib.ct_maxpool2x2.argtypes = [p, i, i, i, i, i, p, i, p]
     lib.ct_upsample_add.argtypes = [p, i, i, i, i, i, p, i, p, i, p, i, p]
     lib.ct_nchw_to_nhwc.argtypes = [p, i, i, i, i, p, i, p]
@@ -253,6 +260,7 @@ def load():
     lib.ct_frame_loop_finish_submit.argtypes = [p, ctypes.POINTER(FrameStepArgs), p, ctypes.POINTER(FrameStepArgs)]
     lib.ct_frame_loop_upload.argtypes = [p, i, p]
     lib.ct_frame_loop_pending_slot.argtypes = [p]
+    lib.ct_frame_loop_prestage.argtypes = [p, i]
     lib.ct_frame_loop_in_flight.argtypes = [p]
     lib.ct_frame_loop_forget_upload.restype = None
     lib.ct_frame_loop_forget_upload.argtypes = [p]

@@ -25,7 +25,9 @@ struct Loop {
     ct_frame_loop_desc d;
     hipStream_t copy_stream = nullptr;
     hipEvent_t frame_ready = nullptr;     // the upload into the next slot finished (recorded on copy_stream)
+    hipEvent_t frame_done = nullptr;      // the graph of the frame in flight finished (recorded right behind its launch)
     int uploaded_slot = -1;               // slot the pending upload targets (-1: none)
+    int pre_done_slot = -1;               // slot whose pre-stage has been enqueued for the frame it holds now (-1: none)
     bool in_flight = false;               // a graph was launched and not yet waited for
     int flight_slot = -1;
 };
@@ -34,6 +36,26 @@ int fail(const char *what, hipError_t e)
 {
     ct_set_error("%s: %s", what, hipGetErrorString(e));
     return CT_ERR_LAUNCH;
+}
+
+// everything of the frame in `slot` that does not depend on the tracker, enqueued on the loop's stream
+int prestage(Loop *L, int slot)
+{
+    const ct_frame_loop_desc &d = L->d;
+    if (!d.pre.enabled || L->pre_done_slot == slot) return CT_OK;
+    const ct_prestage_desc &p = d.pre;
+    float *cur = d.frames[slot];
+    const float *prev = d.frames[(slot + d.nslots - 1) % d.nslots];
+    if (p.flip_B > 0) {
+        const size_t half = (size_t)p.flip_B * 3 * p.H * p.W;
+        int rc = ct_flip_images(cur, cur + half, (size_t)p.flip_B * 3 * p.H, p.W, d.stream);
+        if (rc != CT_OK) return rc;
+    }
+    int rc = ct_stem_forward_parts(cur, prev, nullptr, nullptr, 0, p.N, p.H, p.W, p.w_x, p.w_img, nullptr, p.scale3, p.shift3,
+                                   p.partial[slot], p.ldp, d.stream);
+    if (rc != CT_OK) return rc;
+    L->pre_done_slot = slot;
+    return CT_OK;
 }
 
 }  // namespace
@@ -58,6 +80,12 @@ extern "C" void *ct_frame_loop_create(const ct_frame_loop_desc *d)
     L->d = *d;
     hipError_t e = hipStreamCreateWithFlags(&L->copy_stream, hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&L->frame_ready, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&L->frame_done, hipEventDisableTiming);
+    if (d->pre.enabled && (d->nslots != 3 || !d->pre.w_x || !d->pre.w_img || !d->pre.scale3 || !d->pre.shift3 ||
+                           !d->pre.partial[0] || !d->pre.partial[1] || !d->pre.partial[2] || d->pre.ldp < 16)) {
+        ct_set_error("ct_frame_loop_create: incomplete pre-stage description");
+        e = hipErrorInvalidValue;
+    }
     if (e != hipSuccess) {
         ct_set_error("ct_frame_loop_create: %s", hipGetErrorString(e));
         if (L->copy_stream) (void)hipStreamDestroy(L->copy_stream);
@@ -73,6 +101,7 @@ extern "C" void ct_frame_loop_destroy(void *loop)
     if (!L) return;
     if (L->copy_stream) { (void)hipStreamSynchronize(L->copy_stream); (void)hipStreamDestroy(L->copy_stream); }
     if (L->frame_ready) (void)hipEventDestroy(L->frame_ready);
+    if (L->frame_done) (void)hipEventDestroy(L->frame_done);
     delete L;
 }
 
@@ -86,6 +115,17 @@ extern "C" void ct_frame_loop_forget_upload(void *loop)
     if (!L) return;
     if (L->uploaded_slot >= 0) (void)hipStreamSynchronize(L->copy_stream);     // (the slot may be rewritten by the caller)
     L->uploaded_slot = -1;
+    L->pre_done_slot = -1;                                                      // (... and its pre-stage is stale then)
+}
+
+extern "C" int ct_frame_loop_prestage(void *loop, int slot)
+{
+    Loop *L = (Loop *)loop;
+    if (!L) CT_FAIL_ARG("ct_frame_loop_prestage: null loop");
+    if (slot < 0 || slot >= L->d.nslots) CT_FAIL_ARG("ct_frame_loop_prestage: slot %d of %d", slot, L->d.nslots);
+    const int rc = prestage(L, slot);
+    L->pre_done_slot = -1;          // (the caller launches the frame itself: consumed)
+    return rc;
 }
 
 extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
@@ -125,8 +165,14 @@ extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
         CT_FAIL_ARG("ct_frame_loop_submit: frame_kind %d", a->frame_kind);
     }
     L->uploaded_slot = -1;
-    // 3. the frame: one graph launch
+    // 3. the frame: its tracker-independent part unless that ran ahead, then one graph launch
+    {
+        const int rc = prestage(L, a->slot);
+        if (rc != CT_OK) return rc;
+        L->pre_done_slot = -1;
+    }
     e = hipGraphLaunch((hipGraphExec_t)d.graphs[a->slot], s);
+    if (e == hipSuccess) e = hipEventRecord(L->frame_done, s);
     if (e != hipSuccess) return fail("ct_frame_loop_submit(graph launch)", e);
     L->in_flight = true;
     L->flight_slot = a->slot;
@@ -139,6 +185,13 @@ extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
         if (e == hipSuccess) e = hipEventRecord(L->frame_ready, L->copy_stream);
         if (e != hipSuccess) return fail("ct_frame_loop_submit(upload of the next frame)", e);
         L->uploaded_slot = ns;
+        if (d.pre.enabled) {
+            // ... and its pre-stage right behind this frame's graph: it runs while the host associates this frame
+            e = hipStreamWaitEvent(s, L->frame_ready, 0);
+            if (e != hipSuccess) return fail("ct_frame_loop_submit(pre-stage of the next frame)", e);
+            const int rc = prestage(L, ns);
+            if (rc != CT_OK) return rc;
+        }
     }
     return CT_OK;
 }
@@ -155,6 +208,14 @@ extern "C" int ct_frame_loop_upload(void *loop, int slot, const float *frame)
     if (e == hipSuccess) e = hipEventRecord(L->frame_ready, L->copy_stream);
     if (e != hipSuccess) return fail("ct_frame_loop_upload", e);
     L->uploaded_slot = slot;
+    L->pre_done_slot = -1;
+    if (d.pre.enabled && L->in_flight) {
+        // behind the graph of the frame in flight (already launched): runs while the host associates that frame
+        e = hipStreamWaitEvent((hipStream_t)d.stream, L->frame_ready, 0);
+        if (e != hipSuccess) return fail("ct_frame_loop_upload(pre-stage)", e);
+        const int rc = prestage(L, slot);
+        if (rc != CT_OK) return rc;
+    }
     return CT_OK;
 }
 
@@ -163,7 +224,8 @@ extern "C" int ct_frame_loop_wait(void *loop)
     Loop *L = (Loop *)loop;
     if (!L) CT_FAIL_ARG("ct_frame_loop_wait: null loop");
     if (!L->in_flight) return CT_OK;
-    hipError_t e = hipStreamSynchronize((hipStream_t)L->d.stream);
+    // (the graph's last node, not whatever was enqueued behind it for the next frame)
+    hipError_t e = hipEventSynchronize(L->frame_done);
     if (e != hipSuccess) return fail("ct_frame_loop_wait", e);
     L->in_flight = false;
     return CT_OK;

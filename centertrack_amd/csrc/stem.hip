@@ -20,12 +20,13 @@ __host__ __device__ constexpr int st_koff(int s) { return s * 148; }            
 constexpr int ST_KTOT = 348;
 
 struct StemArgs {
-    const float *in[3];
+    const float *in[3];   // nullptr = stem not part of this launch
     const float *w[3];
     const float *scale;   // [3][16]
     const float *shift;   // [3][16]
+    const float *add;     // NHWC [N,H,W,16] (pitch ldadd) the stems of this launch are accumulated on, or nullptr (= 0)
     float *y;
-    int N, H, W, ldy, tilesX, tilesY;
+    int N, H, W, ldy, ldadd, tilesX, tilesY;
 };
 
 // per-thread staging register counts: plane values (3 planes: 3*14*38/256 -> 7) and weights (148*16/256 -> 10)
@@ -115,18 +116,35 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) pbase[mt] = (2 * wave + (mt >> 1)) * ST_PW + (mt & 1) * 16 + li;
 
+    // The three terms are summed in the order 0, 1, 2 starting from `add` (or 0): a launch of stems {0, 1} into a
+    // partial map followed by a launch of stem {2} on top of it gives the bits of ONE launch of all three
+    // ((0 + r0) + r1) + r2 -- the detector computes the first two terms of frame t+1, which do not depend on the
+    // tracker, while the host still associates frame t (round 3).
     f32x4 out[4];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mt = 0; mt < 4; ++mt) {
+        out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (a.add) {
+            const int oy = oy0 + 2 * wave + (mt >> 1);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ox = ox0 + (mt & 1) * 16 + lg * 4 + e;
+                if (oy < a.H && ox < a.W) out[mt][e] = a.add[(((size_t)n * a.H + oy) * a.W + ox) * a.ldadd + li];
+            }
+        }
+    }
 
-    // (stem 0 = the current frame is always present)
-    stage_load(0);
-    stage_store(0);
+    // stems of this launch, in order (uniform): first, and for every stem the next active one (3 = none)
+    const int first = a.in[0] ? 0 : (a.in[1] ? 1 : 2);
+    stage_load(first);
+    stage_store(first);
     __syncthreads();
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
-        const bool have_next = (s < 2) && a.in[s + 1] != nullptr;
-        if (have_next) stage_load(s + 1);
+        if (s < first) continue;
+        const int nxt = (s < 1 && a.in[1]) ? 1 : ((s < 2 && a.in[2]) ? 2 : 3);
+        const bool have_next = a.in[s] != nullptr && nxt < 3;
+        if (have_next) stage_load(nxt);
         if (a.in[s]) {
             f32x4 acc[4];
 #pragma unroll
@@ -147,7 +165,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) out[mt][e] += fmaxf(acc[mt][e] * sc + sh, 0.0f);
         }
-        if (have_next) stage_store(s + 1);
+        if (have_next) stage_store(nxt);
         if (s < 2) __syncthreads();
     }
 
@@ -169,13 +187,22 @@ extern "C" int ct_stem_forward(const float *x, const float *pre_img, const float
                                const float *w_x, const float *w_img, const float *w_hm, const float *scale3,
                                const float *shift3, float *y, int ldy, void *stream)
 {
-    if (!x || !w_x || !scale3 || !shift3 || !y) CT_FAIL_ARG("ct_stem_forward: null pointer");
-    if ((pre_img && !w_img) || (pre_hm && !w_hm)) CT_FAIL_ARG("ct_stem_forward: input given without its weights");
-    if (N <= 0 || H <= 0 || W <= 0 || ldy < 16) CT_FAIL_ARG("ct_stem_forward: bad shape");
+    if (!x) CT_FAIL_ARG("ct_stem_forward: null pointer");
+    return ct_stem_forward_parts(x, pre_img, pre_hm, nullptr, 0, N, H, W, w_x, w_img, w_hm, scale3, shift3, y, ldy, stream);
+}
+
+extern "C" int ct_stem_forward_parts(const float *x, const float *pre_img, const float *pre_hm, const float *add, int ldadd,
+                                     int N, int H, int W, const float *w_x, const float *w_img, const float *w_hm,
+                                     const float *scale3, const float *shift3, float *y, int ldy, void *stream)
+{
+    if (!scale3 || !shift3 || !y) CT_FAIL_ARG("ct_stem_forward: null pointer");
+    if (!x && !pre_img && !pre_hm) CT_FAIL_ARG("ct_stem_forward_parts: no stem selected");
+    if ((x && !w_x) || (pre_img && !w_img) || (pre_hm && !w_hm)) CT_FAIL_ARG("ct_stem_forward: input given without its weights");
+    if (N <= 0 || H <= 0 || W <= 0 || ldy < 16 || (add && ldadd < 16)) CT_FAIL_ARG("ct_stem_forward: bad shape");
     StemArgs a;
     a.in[0] = x; a.in[1] = pre_img; a.in[2] = pre_hm;
     a.w[0] = w_x; a.w[1] = w_img; a.w[2] = w_hm;
-    a.scale = scale3; a.shift = shift3; a.y = y;
+    a.scale = scale3; a.shift = shift3; a.y = y; a.add = add; a.ldadd = ldadd;
     a.N = N; a.H = H; a.W = W; a.ldy = ldy;
     a.tilesX = ct_cdiv(W, ST_TW); a.tilesY = ct_cdiv(H, ST_TH);
     const long blocks = (long)N * a.tilesX * a.tilesY;

@@ -25,6 +25,9 @@ import torch
 
 from . import _lib, fast_track, ops
 NATIVE_LOOP = os.environ.get('CENTERTRACK_NATIVE_LOOP', '1') != '0'   # (A/B switch: 0 = the Python frame loop)
+# split stem (round 3): the x / pre_img terms of frame t+1's stem run behind frame t's graph, in the GPU time the host
+# needs for the association of frame t; costs one extra 16-channel map round trip per frame, so only for small batches
+SPLIT_STEM_MAX = int(os.environ.get('CENTERTRACK_SPLIT_STEM_MAX', '4'))
 from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, get_affine_transform, make_meta)
 from .model import create_model, load_model
 from .post_process import generic_post_process
@@ -245,6 +248,20 @@ class StreamDetector(object):
         ctx['loop'] = None
         ctx['launched'] = None             # (frame tensor, version, metas) of a frame the native loop launched ahead
         ctx['copy_stream'] = None
+        split = img_in is not None and hm_in is not None and 0 < NB <= SPLIT_STEM_MAX
+        ctx['partial'] = [ops.new_view(NB, H, W, 16, self.device) for _ in range(nslots)] if split else None
+
+        def pre_stage(slot):
+            """the part of a frame that does not depend on the tracker: the mirrored half of a flip_test batch and the
+            x / pre_img terms of the stem.  The native loop runs it for frame t+1 behind the graph of frame t."""
+            if not split:
+                return
+            cur, prev = ctx['frames'][slot], ctx['frames'][(slot - 1) % nslots]
+            if self.flip:
+                _lib.check(_lib.load().ct_flip_images(cur.data_ptr(), cur[self.B:].data_ptr(), self.B * 3 * H, W,
+                                                      _lib.stream_ptr()), 'ct_flip_images')
+            self.model.run_stem_partial(cur, prev, ctx['partial'][slot])
+        ctx['pre_stage'] = pre_stage
 
         def device_frame(slot=0, with_copies=False):
             """all device work of one frame; ``with_copies``: also the H2D of the prior-heat-map blobs and the D2H
@@ -259,11 +276,11 @@ class StreamDetector(object):
                 _lib.check(lib.ct_render_pre_hm(ctx['prm_dev'].data_ptr(), ctx['cnt_dev'].data_ptr(),
                                                 ctx['max_blobs'], self.B, H, W, hm_in.data_ptr(),
                                                 1 if self.flip else 0, _lib.stream_ptr()), 'ct_render_pre_hm')
-            if self.flip:
+            if self.flip and not split:
                 # the mirrored half of the batch (detector.py:224-226), built from the frames already in HBM
                 _lib.check(lib.ct_flip_images(cur.data_ptr(), cur[self.B:].data_ptr(), self.B * 3 * H, W,
                                               _lib.stream_ptr()), 'ct_flip_images')
-            self.model._run_plan(plan, inputs=(cur, prev, hm_in))
+            self.model._run_plan(plan, inputs=(cur, prev, hm_in), stem_partial=ctx['partial'][slot] if split else None)
             if self.flip:
                 arr, n, pairs, h, w = ctx['flip_call']
                 _lib.check(lib.ct_flip_merge(arr, n, pairs.ctypes.data, len(pairs), self.B, h, w, _lib.stream_ptr()),
@@ -284,6 +301,7 @@ class StreamDetector(object):
                 side = torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
+                    pre_stage(0)
                     device_frame(0)           # warm-up (lazy module loads must not happen in capture)
                 torch.cuda.current_stream().wait_stream(side)
                 torch.cuda.synchronize()
@@ -338,6 +356,16 @@ class StreamDetector(object):
         d.frame_bytes = self.B * 3 * H * W * 4
         ctx['loop_stream'] = torch.cuda.current_stream()
         d.stream = ctx['loop_stream'].cuda_stream
+        if ctx['partial'] is not None:
+            P = self.model._prepare()
+            d.pre.enabled = 1
+            d.pre.N, d.pre.H, d.pre.W = ctx['NB'], int(H), int(W)
+            d.pre.w_x, d.pre.w_img = P['stem_w'][0].data_ptr(), P['stem_w'][1].data_ptr()
+            d.pre.scale3, d.pre.shift3 = P['stem_scale'].data_ptr(), P['stem_shift'].data_ptr()
+            for i in range(ctx['nslots']):
+                d.pre.partial[i] = ctx['partial'][i].ptr
+            d.pre.ldp = ctx['partial'][0].ld
+            d.pre.flip_B = self.B if self.flip else 0
         ctx['res_cap'] = self.fast[0].cap
         ctx['res_buf'] = np.zeros((self.B, ctx['res_cap']), fast_track.TRACK_DTYPE)
         d.results, d.results_cap = ctx['res_buf'].ctypes.data, ctx['res_cap']
@@ -398,6 +426,7 @@ class StreamDetector(object):
         give its slot back -- the trackers never saw it"""
         if ctx.get('loop') is not None and ctx['launched'] is not None:
             _lib.check(_lib.load().ct_frame_loop_wait(ctx['loop']), 'ct_frame_loop_wait')
+            _lib.load().ct_frame_loop_forget_upload(ctx['loop'])      # (also: whatever was pre-staged is stale)
             ctx['slot'] = (ctx['slot'] - 1) % ctx['nslots']
             ctx['launched'] = None
 
@@ -600,6 +629,11 @@ class StreamDetector(object):
         if self._rows_free is not None:                        # (a side-stream reader of the previous frame's rows)
             cur.wait_event(self._rows_free)
             self._rows_free = None
+        if ctx['partial'] is not None:                         # the tracker-independent part (unless it ran ahead)
+            if ctx['loop'] is not None:
+                _lib.check(lib.ct_frame_loop_prestage(ctx['loop'], slot), 'ct_frame_loop_prestage')
+            else:
+                ctx['pre_stage'](slot)
         if ctx['raw']:
             ctx['graphs'][slot].replay(sp)
         elif ctx['graphs'][slot] is not None:

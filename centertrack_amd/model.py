@@ -426,10 +426,25 @@ class DLASegHIP(torch.nn.Module):
                 outputs[h] = o
         return OrderedDict((h, outputs[h]) for h in self.heads)
 
-    def _run_plan(self, plan, inputs=None):
+    def run_stem_partial(self, x, pre_img, out):
+        """the terms of the stem that do not depend on the tracker (dla.py:305-311: base_layer(x) + pre_img_layer(
+        pre_img)) into the NHWC view ``out`` -- a detector runs this for frame t+1 while the host still associates
+        frame t; ``_run_plan(..., stem_partial=out)`` then only adds the pre_hm term (bit-identical to one launch)"""
+        P = self._prepare()
+        lib = _lib.load()
+        w = P['stem_w']
+        rc = lib.ct_stem_forward_parts(x.data_ptr(), ops._p(pre_img), None, None, 0, x.shape[0], x.shape[2], x.shape[3],
+                                       w[0].data_ptr(), ops._p(w[1]) if pre_img is not None else None, None,
+                                       P['stem_scale'].data_ptr(), P['stem_shift'].data_ptr(), out.ptr, out.ld,
+                                       _lib.stream_ptr())
+        if rc != 0:
+            _lib.check(rc, 'stem (x / pre_img terms)')
+
+    def _run_plan(self, plan, inputs=None, stem_partial=None):
         """Enqueue every launch of the plan on the current stream.  ``inputs`` = (x, pre_img, pre_hm) tensors to read
-        instead of the plan's own static input buffers (a detector ping-pongs two frame buffers so that the
-        previous frame never has to be copied)."""
+        instead of the plan's own static input buffers (a detector rotates its frame buffers so that the
+        previous frame never has to be copied).  ``stem_partial``: NHWC view that already holds the x / pre_img terms
+        of the stem (``run_stem_partial``): only the pre_hm term is computed, on top of it."""
         P = self._prepared
         lib = _lib.load()
         st = _lib.stream_ptr()
@@ -449,6 +464,15 @@ class DLASegHIP(torch.nn.Module):
                 if inputs is not None:
                     x, img, hm = inputs
                 w = P['stem_w']
+                if stem_partial is not None:
+                    if hm is None:
+                        raise _lib.CTError('a split stem needs the pre_hm input')
+                    rc = lib.ct_stem_forward_parts(None, None, hm.data_ptr(), stem_partial.ptr, stem_partial.ld,
+                                                   x.shape[0], x.shape[2], x.shape[3], None, None, w[2].data_ptr(),
+                                                   P['stem_scale'].data_ptr(), P['stem_shift'].data_ptr(), y.ptr, y.ld, st)
+                    if rc != 0:
+                        _lib.check(rc, l.name)
+                    continue
                 rc = lib.ct_stem_forward(x.data_ptr(), ops._p(img), ops._p(hm), x.shape[0], x.shape[2], x.shape[3],
                                          w[0].data_ptr(), ops._p(w[1]) if img is not None else None,
                                          ops._p(w[2]) if hm is not None else None,

@@ -186,6 +186,14 @@ int ct_stem_forward(const float *x, const float *pre_img, const float *pre_hm, i
                     const float *w_x, const float *w_img, const float *w_hm,
                     const float *scale3, const float *shift3,   /* [3][16] each */
                     float *y, int ldy, void *stream);
+/* The same with any subset of the three stems (a NULL input skips its stem), accumulated on top of `add` (NHWC, 16
+ * channels, pitch ldadd; NULL = 0).  The terms are added in the order x, pre_img, pre_hm, so a launch of {x, pre_img}
+ * into a partial map followed by a launch of {pre_hm} with add = that map is bit-identical to ct_stem_forward: the
+ * detector runs the first for frame t+1 -- those two terms do not depend on the tracker (dla.py:305-311) -- while
+ * the host still associates frame t. */
+int ct_stem_forward_parts(const float *x, const float *pre_img, const float *pre_hm, const float *add, int ldadd,
+                          int N, int H, int W, const float *w_x, const float *w_img, const float *w_hm,
+                          const float *scale3, const float *shift3, float *y, int ldy, void *stream);
 
 /* ---- glue ops ---------------------------------------------------------------------- */
 /* nn.MaxPool2d(2,2) of Tree.downsample (dla.py:207-208,216), NHWC views */
@@ -381,6 +389,17 @@ int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
  * trans_input: float64 [B][2][3] network-input affine of each stream's frame (prior heat-map); trans_inv: float32
  * [B][2][3] output-grid -> image affine (post-process).  One frame in flight at a time. */
 enum { CT_FRAME_DEVICE = 0, CT_FRAME_HOST = 1, CT_FRAME_IN_PLACE = 2, CT_FRAME_UPLOADED = 3 };
+typedef struct ct_prestage_desc {          /* the part of a frame that does not depend on the tracker (round 3): the mirrored
+                                              half of a flip_test batch and the x / pre_img terms of the stem
+                                              (ct_stem_forward_parts into a partial map the frame graph completes).  The loop
+                                              runs it for frame t+1 right behind the graph of frame t -- while the host
+                                              still associates frame t -- whenever frame t+1 has been uploaded by then. */
+    int enabled;
+    int N, H, W;                           /* images of a frame batch (mirrored half included), input size */
+    const float *w_x, *w_img, *scale3, *shift3;
+    float *partial[3]; int ldp;            /* NHWC [N,H,W,16] partial stem maps, one per rotation slot */
+    int flip_B;                            /* > 0: images [0, flip_B) of the slot are mirrored into [flip_B, 2 flip_B) first */
+} ct_prestage_desc;
 typedef struct ct_frame_loop_desc {
     int B, K, F;
     void *const *trackers;                 /* [B] ct_tracker_create handles */
@@ -399,6 +418,7 @@ typedef struct ct_frame_loop_desc {
     size_t frame_bytes;                    /* bytes of one frame batch as the caller hands it over ([B,3,H,W] fp32) */
     void *stream;
     ct_track *results; int results_cap;    /* HOST [B][results_cap] */
+    ct_prestage_desc pre;
 } ct_frame_loop_desc;
 typedef struct ct_frame_step_args {
     int slot, frame_kind;
@@ -415,6 +435,8 @@ int ct_frame_loop_finish(void *loop, const ct_frame_step_args *a, int *counts);
 int ct_frame_loop_finish_submit(void *loop, const ct_frame_step_args *cur, int *counts, const ct_frame_step_args *next);
 int ct_frame_loop_upload(void *loop, int slot, const float *frame);   /* upload a pinned HOST frame into `slot` on the copy stream
                                                                          (the frame a later submit names with CT_FRAME_UPLOADED) */
+int ct_frame_loop_prestage(void *loop, int slot); /* run the pre-stage of `slot` now unless it already ran (callers that launch a
+                                                     frame graph themselves) */
 int ct_frame_loop_pending_slot(void *loop);      /* slot an upload is pending for, or -1 */
 int ct_frame_loop_in_flight(void *loop);         /* slot of the frame in flight, or -1 */
 void ct_frame_loop_forget_upload(void *loop);    /* drop a pending upload (waits for the copy) */

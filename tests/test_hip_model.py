@@ -111,3 +111,29 @@ def test_fused_sigmoid_and_batch_consistency(device):
         one = model(x[b:b + 1], pre[b:b + 1], hm[b:b + 1])[-1]
         for k in heads:
             np.testing.assert_allclose(one[k].cpu().numpy(), raw[k][b:b + 1].cpu().numpy(), atol=1e-4, err_msg=k)
+
+
+def test_split_stem_is_bit_identical(device):
+    """round 3: the x / pre_img terms of the stem computed ahead into a partial map (run_stem_partial) + the pre_hm term
+    on top of it (stem_partial=) give the bits of the single three-term launch -- for the stem output and for every
+    head map of the forward"""
+    from centertrack_amd import ops, weights as W
+    from centertrack_amd.model import DLASegHIP
+    heads = W.MOT_HEADS
+    model = DLASegHIP(heads)
+    model.load_state_dict(W.make_synthetic_state_dict(heads, seed=5))
+    model = model.to(device)
+    N, H, Wd = 2, 96, 160
+    x, pre, hm = W.synthetic_inputs(N, H, Wd, seed=11)
+    x, pre, hm = x.to(device), pre.to(device), hm.to(device)
+    plan = model.get_plan(N, H, Wd, True, True, True)
+    model._run_plan(plan, inputs=(x, pre, hm))
+    torch.cuda.synchronize()
+    want = {k: v.clone() for k, v in plan['outputs'].items()}
+    partial = ops.new_view(N, H, Wd, 16, device)
+    model.run_stem_partial(x, pre, partial)
+    model._run_plan(plan, inputs=(x, pre, hm), stem_partial=partial)
+    torch.cuda.synchronize()
+    for k, v in plan['outputs'].items():
+        assert torch.equal(v, want[k]), k
+    assert float(want['hm'].abs().sum()) > 0
