@@ -133,7 +133,8 @@ class FrameLoopDesc(ctypes.Structure):
                 ('graphs', ctypes.c_void_p * 3), ('frames', ctypes.c_void_p * 3),
                 ('frame_bytes', ctypes.c_size_t),
                 ('stream', ctypes.c_void_p),
-                ('results', ctypes.c_void_p), ('results_cap', ctypes.c_int), ('pre', PrestageDesc)]
+                ('results', ctypes.c_void_p), ('results_cap', ctypes.c_int), ('done_flag', ctypes.c_void_p),
+                ('pre', PrestageDesc)]
 
 
 class FrameStepArgs(ctypes.Structure):
@@ -158,7 +159,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_flip_merge', 'ct_flip_images',
            'ct_frame_loop_create', 'ct_frame_loop_destroy', 'ct_frame_loop_submit', 'ct_frame_loop_wait', 'ct_frame_loop_finish',
            'ct_frame_loop_finish_submit', 'ct_frame_loop_upload', 'ct_frame_loop_pending_slot', 'ct_frame_loop_in_flight',
-           'ct_frame_loop_forget_upload', 'ct_frame_loop_prestage', 'ct_stem_forward_parts']
+           'ct_frame_loop_forget_upload', 'ct_frame_loop_prestage', 'ct_stem_forward_parts', 'ct_signal_host']
 
 _lib = None
 
@@ -247,6 +248,7 @@ def load():
     lib.ct_memcpy_async.argtypes = [p, p, sz, i, p]
     lib.ct_stream_synchronize.argtypes = [p]
     lib.ct_memset_async.argtypes = [p, i, sz, p]
+    lib.ct_signal_host.argtypes = [p, i, p]
     lib.ct_calib_mfma.argtypes = [i, i, p, p]
     lib.ct_flip_merge.argtypes = [ctypes.POINTER(FlipHead), i, p, i, i, i, i, p]
     lib.ct_flip_images.argtypes = [p, p, sz, i, p]

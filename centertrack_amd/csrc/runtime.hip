@@ -106,3 +106,17 @@ extern "C" int ct_calib_mfma(int blocks, int iters, float *out, void *stream)
     CT_CHECK_LAUNCH("ct_calib_mfma");
     return CT_OK;
 }
+
+// ---- end-of-frame flag in pinned host memory ----
+__global__ void signal_host_kernel(int *flag, int value)
+{
+    __hip_atomic_store(flag, value, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+extern "C" int ct_signal_host(int *flag, int value, void *stream)
+{
+    if (!flag) CT_FAIL_ARG("ct_signal_host: null flag");
+    hipLaunchKernelGGL(signal_host_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, flag, value);
+    CT_CHECK_LAUNCH("ct_signal_host");
+    return CT_OK;
+}

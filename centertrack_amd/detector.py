@@ -28,6 +28,7 @@ NATIVE_LOOP = os.environ.get('CENTERTRACK_NATIVE_LOOP', '1') != '0'   # (A/B swi
 # split stem (round 3): the x / pre_img terms of frame t+1's stem run behind frame t's graph, in the GPU time the host
 # needs for the association of frame t; costs one extra 16-channel map round trip per frame, so only for small batches
 SPLIT_STEM_MAX = int(os.environ.get('CENTERTRACK_SPLIT_STEM_MAX', '4'))
+HOST_FLAG = os.environ.get('CENTERTRACK_HOST_FLAG', '1') != '0'       # end-of-frame flag in pinned host memory (A/B switch)
 from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, get_affine_transform, make_meta)
 from .model import create_model, load_model
 from .post_process import generic_post_process
@@ -219,6 +220,7 @@ class StreamDetector(object):
         ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
         ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
         ctx['host_rows'] = ctx['host_out'].numpy()
+        ctx['done_flag'] = torch.zeros((16,), dtype=torch.int32).pin_memory()      # (its own cache line)
         ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if (with_hm and not self.native) else None
         render = self.native and with_hm
         if render:
@@ -293,6 +295,8 @@ class StreamDetector(object):
             if with_copies:
                 _lib.check(_lib.load().ct_memcpy_async(ctx['host_out'].data_ptr(), ctx['decoder'].out.data_ptr(),
                                                        ctx['host_out'].numel() * 4, 2, _lib.stream_ptr()), 'D2H')
+                if HOST_FLAG:         # the native loop polls this flag instead of waiting in the runtime
+                    _lib.check(_lib.load().ct_signal_host(ctx['done_flag'].data_ptr(), 1, _lib.stream_ptr()), 'ct_signal_host')
 
         ctx['device_frame'] = device_frame
         if self.use_graph:
@@ -369,6 +373,7 @@ class StreamDetector(object):
         ctx['res_cap'] = self.fast[0].cap
         ctx['res_buf'] = np.zeros((self.B, ctx['res_cap']), fast_track.TRACK_DTYPE)
         d.results, d.results_cap = ctx['res_buf'].ctypes.data, ctx['res_cap']
+        d.done_flag = ctx['done_flag'].data_ptr() if HOST_FLAG else None
         h = lib.ct_frame_loop_create(ctypes.byref(d))
         if not h:
             raise _lib.CTError('ct_frame_loop_create: %s' % lib.ct_last_error().decode())

@@ -362,6 +362,10 @@ void ct_graph_destroy(void *graph_exec);
 int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kind /*0 D2D, 1 H2D, 2 D2H*/, void *stream);
 int ct_memset_async(void *dst, int value, size_t bytes, void *stream);      /* DEVICE memory (zero_tracking) */
 int ct_stream_synchronize(void *stream);
+/* One-thread kernel that stores `value` to *flag (pinned HOST memory, system-scope release): appended to a frame graph
+ * behind its last copy node, it lets the host see the end of the frame by polling a cache line instead of waiting in
+ * the runtime (ct_frame_loop_wait) -- and independently of work that was enqueued behind the graph for the next frame. */
+int ct_signal_host(int *flag, int value, void *stream);
 /* Box calibration (diagnostics; no reference equivalent): `blocks` workgroups of 4 waves each run `iters` rounds of 16
  * independent-chain v_mfma_f32_16x16x4_f32 on registers -- the sustained fp32 MFMA rate of the box a bench line was
  * measured on (bench.py's "box_calibration").  out: DEVICE float[>= blocks * 256] (never written in practice). */
@@ -418,6 +422,8 @@ typedef struct ct_frame_loop_desc {
     size_t frame_bytes;                    /* bytes of one frame batch as the caller hands it over ([B,3,H,W] fp32) */
     void *stream;
     ct_track *results; int results_cap;    /* HOST [B][results_cap] */
+    int *done_flag;                        /* pinned HOST int the frame graphs set to 1 with their last node (ct_signal_host),
+                                              or NULL: wait through the runtime */
     ct_prestage_desc pre;
 } ct_frame_loop_desc;
 typedef struct ct_frame_step_args {

@@ -88,7 +88,7 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
               'ct_heads_desc': (_lib.HeadsDesc, ['x', 'w0_winograd', 'cout', 'out', 'depth_scale']),
               'ct_frame_loop_desc': (_lib.FrameLoopDesc, ['B', 'trackers', 'layout', 'out_thresh', 'host_rows', 'rows_keep',
                                                           'blob_params', 'blob_cap', 'nslots', 'graphs', 'frames',
-                                                          'frame_bytes', 'stream', 'results', 'results_cap', 'pre']),
+                                                          'frame_bytes', 'stream', 'results', 'results_cap', 'done_flag', 'pre']),
               'ct_prestage_desc': (_lib.PrestageDesc, ['enabled', 'W', 'w_x', 'shift3', 'partial', 'ldp', 'flip_B']),
               'ct_frame_step_args': (_lib.FrameStepArgs, ['slot', 'frame_kind', 'frame', 'next_frame', 'trans_input',
                                                           'trans_inv']),
