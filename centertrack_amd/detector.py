@@ -25,9 +25,12 @@ import torch
 
 from . import _lib, fast_track, ops
 NATIVE_LOOP = os.environ.get('CENTERTRACK_NATIVE_LOOP', '1') != '0'   # (A/B switch: 0 = the Python frame loop)
-# split stem (round 3): the x / pre_img terms of frame t+1's stem run behind frame t's graph, in the GPU time the host
-# needs for the association of frame t; costs one extra 16-channel map round trip per frame, so only for small batches
-SPLIT_STEM_MAX = int(os.environ.get('CENTERTRACK_SPLIT_STEM_MAX', '4'))
+# split stem (round 3, measured and left OFF): the x / pre_img terms of frame t+1's stem launched behind frame t's graph, to
+# run in the GPU time the host needs for the association of frame t.  Bit-identical (tests), but two A/B pairs on an
+# MI355X showed no overlap: wall - graph grew from 11 us to 73-80 us for a 36 us pre-stage -- the kernel launched between
+# two graph launches costs more in front-end transitions than the host gap it was meant to fill.
+# CENTERTRACK_SPLIT_STEM_MAX = largest image batch it is used for (0 = never).
+SPLIT_STEM_MAX = int(os.environ.get('CENTERTRACK_SPLIT_STEM_MAX', '0'))
 HOST_FLAG = os.environ.get('CENTERTRACK_HOST_FLAG', '1') != '0'       # end-of-frame flag in pinned host memory (A/B switch)
 from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, get_affine_transform, make_meta)
 from .model import create_model, load_model

@@ -378,8 +378,8 @@ def _stream_setup(B):
     return opt, model, batches, meta
 
 
-@pytest.mark.parametrize('B', [1, 2])
-def test_native_frame_loop_equals_python_loop(device, monkeypatch, B):
+@pytest.mark.parametrize('B,split', [(1, 0), (2, 0), (1, 4), (2, 4)])
+def test_native_frame_loop_equals_python_loop(device, monkeypatch, B, split):
     """round 3: the native frame loop (ct_frame_loop_*: blobs from the trackers, frame into its rotation slot, graph
     launch, upload of the next frame into ITS slot, wait, association -- and the next frame launched by the call that
     finishes this one) gives bit-identical results, decode rows and ids to the Python loop, with and without
@@ -391,6 +391,9 @@ def test_native_frame_loop_equals_python_loop(device, monkeypatch, B):
 
     def run(native, mode):
         monkeypatch.setattr(D, 'NATIVE_LOOP', native)
+        # (split stem: the x / pre_img stem terms of a frame as a pre-stage, run ahead by the native loop; the
+        # reference run -- Python loop, 'plain' -- always uses the single three-term stem launch)
+        monkeypatch.setattr(D, 'SPLIT_STEM_MAX', split if (native or mode != 'plain') else 0)
         det = D.StreamDetector(opt, model=model, num_streams=B)
         out = []
         for t in range(T):
