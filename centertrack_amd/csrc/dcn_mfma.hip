@@ -351,6 +351,9 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
             // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
             // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
+#if defined(CT_DCN_PRIO)      // (variant build, tools/build_variant.py: the MFMA block of a wave issues ahead of other waves' work)
+            __builtin_amdgcn_s_setprio(CT_DCN_PRIO);
+#endif
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
@@ -361,6 +364,9 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                         for (int nt = 0; nt < WN; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][mt][e], bq[P][kk][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
+#if defined(CT_DCN_PRIO)
+            __builtin_amdgcn_s_setprio(0);
+#endif
             __builtin_amdgcn_sched_barrier(0x386);
 #pragma unroll
             for (int kk = 0; kk < GK; ++kk)

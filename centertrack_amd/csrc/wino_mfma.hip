@@ -25,6 +25,7 @@ struct WinoArgs {
     const float *up;          // packed U
     int N, H, W, Cin, ldx;
     int tilesX, tilesY, coutBlocks, xcdPer;
+    int headMajor;            // HEADS: workgroups ordered head-major (all pixel tiles of head 0, then head 1, ..)
     int NT;                   // CoutPad / 16
     int nchunks;              // Cin / 64
     EpiArgs epi;
@@ -89,7 +90,17 @@ void wino_conv_kernel(WinoArgs a)
     const int li = lane & 15, lg = lane >> 4;
 
     int bid = blockIdx.x;
-    const int cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
+    int cb;
+    if (HEADS && a.headMajor) {
+        // every head has its own 1 MB of Winograd weights: with the head as the SLOWEST index the workgroups resident
+        // at any time work on <= 3 heads (3 MB per XCD L2 of 4 MB) instead of cycling through all of them (5.2 MB for
+        // the five MOT heads: every XCD kept re-streaming the weights, 119 MB of fetches per launch in round 2)
+        const int per_head = (int)(gridDim.x / (unsigned)a.coutBlocks);
+        cb = bid / per_head;
+        bid -= cb * per_head;
+    } else {
+        cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
+    }
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
@@ -516,7 +527,7 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     WinoArgs a;
     a.x = d->x; a.up = d->w_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = d->Cin; a.ldx = d->ldx;
-    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN * NB); a.xcdPer = ct_xcd_per(a.coutBlocks);
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4 * WM); a.coutBlocks = ct_cdiv(d->Cout, 16 * WN * NB); a.xcdPer = ct_xcd_per(a.coutBlocks); a.headMajor = 0;
     a.NT = ct_cdiv(d->Cout, 16); a.nchunks = d->Cin / 64;
     a.epi.scale = d->scale; a.epi.shift = d->shift; a.epi.res = d->res; a.epi.y = d->y;
     a.epi.ldr = d->ldr; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = d->H; a.epi.Wo = d->W;
@@ -557,6 +568,7 @@ extern "C" int ct_heads_fused(const ct_heads_desc *d, void *stream)
     a.x = d->x; a.up = d->w0_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = 64; a.ldx = d->ldx;
     a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.coutBlocks = d->nheads; a.xcdPer = 0;
+    a.headMajor = ct_tune_get(CT_TUNE_HEADS_ORDER) ? 1 : 0;
     a.NT = d->nheads * 16; a.nchunks = 1;
     a.epi.scale = nullptr; a.epi.shift = d->b0; a.epi.res = nullptr; a.epi.y = nullptr;
     a.epi.ldr = 0; a.epi.ldy = 0; a.epi.Cout = d->nheads * 256; a.epi.Ho = d->H; a.epi.Wo = d->W;
