@@ -503,17 +503,26 @@ class DLASegHIP(torch.nn.Module):
         slots hold 256 .. 384 workgroups of 18 (chunk, tap) steps each on 768 workgroup slots -- one wave per SIMD,
         nothing to hide the gather latency behind -- while their layers go through the workspace anyway (IDAUp step in
         the finishing launch); splitting K twice as fine fills the chip and halves every workgroup's loop.  0 = off,
-        2 = two chunks per split, 1 = one chunk per split (then in 32-channel steps)."""
+        2 = two chunks per split, 1 = one chunk per split (then in 32-channel steps).  knobs[5] = 1: the layers of
+        those slots also leave their offset convs to the slot's K-split OFFSETS launch (a fused conv would be repeated
+        by every split)."""
         lib = _lib.load()
         P = self._prepared
         fuse_max_cin, cps, nkk = knobs[:3]
         split_offsets = knobs[3] if len(knobs) > 3 else 1
         cps_small = knobs[4] if len(knobs) > 4 else 0
+        small_unfuse = knobs[5] if len(knobs) > 5 else 0      # small slots: offset convs out of the MAIN launch too
         slot_cps = {}
+        sizes, mains = self._dcn_slot_sizes(layers, produced0, N, cps, with_mains=True)
         if cps_small and cps_small < cps:
-            for t, wgs in self._dcn_slot_sizes(layers, produced0, N, cps).items():
+            for t, wgs in sizes.items():
                 if wgs < SMALL_SLOT_WGS:
                     slot_cps[t] = cps_small
+        # knobs[5] == 2: every slot that needs an OFFSETS launch anyway (a layer above the fuse threshold) leaves ALL its
+        # offset convs to that launch -- a fused conv is repeated by every cout block and split of its layer
+        unfuse_slots = set()
+        if small_unfuse == 2:
+            unfuse_slots = {m for ly, m in zip(layers, mains) if not (ly.x.C % 64 == 0 and ly.x.C <= fuse_max_cin and FUSE_OFFSET)}
         time_of = dict(produced0)                    # buffer id -> time after which it is readable
 
         def t_of(view):
@@ -524,10 +533,13 @@ class DLASegHIP(torch.nn.Module):
         offs = {}
         for ly in layers:                            # (reference order: producers come first)
             pk = P[ly.name]
-            ly.fused = ly.x.C % 64 == 0 and ly.x.C <= fuse_max_cin and FUSE_OFFSET
             nchunks = ly.x.C // 32
             ly.main = t_of(ly.x) // 2 + 1
             c = slot_cps.get(ly.main, cps)
+            # (a finely split layer would repeat a fused offset conv in every split: knobs[5] moves it to the slot's
+            #  K-split OFFSETS launch instead)
+            ly.fused = (ly.x.C % 64 == 0 and ly.x.C <= fuse_max_cin and FUSE_OFFSET
+                        and not (small_unfuse and ly.main in slot_cps) and ly.main not in unfuse_slots)
             ly.nkk = 2 if (c == 1 or ly.x.C % 64) else nkk
             ly.splits = max(1, nchunks // c)
             om = part = None
@@ -605,14 +617,16 @@ class DLASegHIP(torch.nn.Module):
         return out
 
     @staticmethod
-    def _dcn_slot_sizes(layers, produced0, N, cps):
+    def _dcn_slot_sizes(layers, produced0, N, cps, with_mains=False):
         """{MAIN slot: workgroups} of the schedule with ``cps`` chunks per split everywhere (the slot of a layer does
         not depend on how finely it is split: a split layer is readable one time step later, which rounds to the same
         next slot)"""
         time_of = dict(produced0)
         sizes = {}
+        mains = []
         for ly in layers:
             main = time_of.get(id(ly.x.buf), 0) // 2 + 1
+            mains.append(main)
             splits = max(1, (ly.x.C // 32) // cps)
             use_ws = splits > 1 or ly.up is not None
             if use_ws:
@@ -623,7 +637,7 @@ class DLASegHIP(torch.nn.Module):
             time_of[id((ly.up[3] if ly.up is not None else ly.out).buf)] = done
             tiles = N * ((ly.x.H + 1) // 2) * ((ly.x.W + 15) // 16) * ((ly.cout + 63) // 64)
             sizes[main] = sizes.get(main, 0) + tiles * splits
-        return sizes
+        return (sizes, mains) if with_mains else sizes
 
     def _time_launches(self, launches, reps=10):
         """device time (us) of a launch list, by graph replay on a side stream"""
@@ -666,17 +680,17 @@ class DLASegHIP(torch.nn.Module):
         if env:
             knobs = tuple(int(v) for v in env.split(','))
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs, tune)
-        default = (128, 4, 2, 1, 0)
+        default = (128, 4, 2, 1, 0, 0)
         if not tune:
             return default, self._schedule_dcn(layers, produced0, N, dev, default, tune)
         key = 'dcnplan4:%d,%d,%d' % (N, H, W)
         key3 = 'dcnplan3:%d,%d,%d' % (N, H, W)          # (round-2 tables: four knobs, no fine-split slots)
         autotune._load_file()
         if key in autotune._CACHE:
-            knobs = tuple(int(v) for v in autotune._CACHE[key][:5])
+            knobs = tuple(int(v) for v in autotune._CACHE[key][:-1])
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         if key3 in autotune._CACHE and os.environ.get('CENTERTRACK_DCN_RETUNE', '0') != '1':
-            knobs = tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0,)
+            knobs = tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0, 0)
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         best = None
         # (split_offsets = 0 -- one conv launch per un-fused layer -- never won in round 2's sweeps: 368 against 336 us
@@ -688,8 +702,9 @@ class DLASegHIP(torch.nn.Module):
                 for nkk in (2, 4):
                     for so in ((1, 2) if fuse_max < 256 else (1,)):
                         small = [t for t, w in self._dcn_slot_sizes(layers, produced0, N, cps).items() if w < SMALL_SLOT_WGS]
-                        for cs in ((0,) + tuple(c for c in (2, 1) if c < cps) if small else (0,)):
-                            knobs = (fuse_max, cps, nkk, so, cs)
+                        for cs, un in (((0, 0), (0, 2)) + tuple((c, u) for c in (2, 1) if c < cps for u in (0, 1, 2)) if small
+                                       else ((0, 0), (0, 2))):
+                            knobs = (fuse_max, cps, nkk, so, cs, un)
                             launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
                             us = self._time_launches(launches)
                             if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
