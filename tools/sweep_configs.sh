@@ -6,14 +6,14 @@
 # usage (repo root, GPU box):  bash tools/sweep_configs.sh <tag> [prof]     e.g.  bash tools/sweep_configs.sh r02_a prof
 # Writes gpurun_out/profiles_new/<tag>_sweep.jsonl and, with `prof`, <tag>_kstats_<config>_b<B>.txt.
 set -u
-TAG=${1:-r02_x}
+TAG=${1:-r03_x}
 PROF=${2:-}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$R/gpurun_out/profiles_new
 mkdir -p $OUT
 export CENTERTRACK_TUNE_CACHE=${CENTERTRACK_TUNE_CACHE:-/tmp/tune_sweep.json}
 : > $OUT/${TAG}_sweep.jsonl
-python $R/tools/box_calib.py > $OUT/${TAG}_box.json 2>/dev/null
+python $R/tools/box_calib.py > $OUT/${TAG}_box.json 2>/dev/null   # (every bench line carries its own box_calibration since round 3)
 run() {  # config streams
     cd $R
     python bench.py --config $1 --streams $2 --steps 10 --warmup 3 --no-cpu-baseline \
