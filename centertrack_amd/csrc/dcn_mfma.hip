@@ -65,6 +65,9 @@ struct DcnGroup {
 // NKK = 16-channel slabs per step: 2 (32 channels x 1 tap, 16 * WN MFMAs per wave between barriers) or 4 (64 channels:
 // 32 * WN MFMAs per barrier -- every step pays the same few hundred cycles of LDS round trips, waits and barrier skew, so
 // the matrix pipe's share of a step grows with the work per barrier: measured 47 % busy at 16, 60 % at 32 MFMAs per step).
+#ifndef CT_OFF_PD
+#define CT_OFF_PD 2       // B prefetch distance of the offset/mask conv tiles (variant builds: tools/build_variant.py)
+#endif
 #if defined(CT_DCN_STAMPS)
 // tools/dcn_phases.py: per-workgroup phase stamps (debug build only, never part of the shipped library)
 #define CT_STAMP_WORDS 10
@@ -149,7 +152,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                 if (oy < a.H && ox < a.W) part[((size_t)oy * a.W + ox) * 32 + co] = sum[e];
             }
         };
-        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, split, split + 1, lds_a, fin);
+        ksplit_conv_tile<3, 1, 2, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, split, split + 1, lds_a, fin);
         return;
     }
     const bool fuse = FUSE && a.w_off != nullptr;                // (uniform)
@@ -168,7 +171,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                 om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
             }
         };
-        ksplit_conv_tile<3, 1, 2, 2, 4>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
+        ksplit_conv_tile<3, 1, 2, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
         __syncthreads();
     }
     CT_STAMP(2);

@@ -31,14 +31,17 @@ struct KsCfg {
 // (NT n-tiles of 16 couts); this workgroup's first n-tile is nt0; chunks [c_begin, c_end) of 16*WK
 // channels; lds: >= KsCfg::LDS_BYTES (or LDS1_FLOATS floats for a single chunk), free for reuse on
 // return AFTER a __syncthreads().  fin(mt, nt, sum) is called by exactly one wave per tile.
-template <int KS, int STRIDE, int WM, int WN, int WK, typename Fin>
+// PD = B prefetch distance in (tap) steps: 2 for the multi-chunk backbone layers (registers); the single-chunk offset
+// conv of the DCN launches may fetch every tap's fragments up front (PD = KS*KS - 1): its 9-tap loop is otherwise
+// paced by the L2 latency of the weights (512 MFMA clocks per tap against a > 1000-clock round trip).
+template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin>
 __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W, int ldx, int Cin, const float *wp, int NT,
                                                  int nt0, int oy0, int ox0, int c_begin, int c_end, float *lds, Fin fin)
 {
     using C = KsCfg<KS, STRIDE, WM, WN, WK>;
     constexpr int PAD = KS / 2;
     constexpr int S = KS * KS;                       // steps (taps) per chunk and wave
-    constexpr int D = 2;                             // B prefetch distance (steps)
+    constexpr int D = PD;                            // B prefetch distance (steps)
     constexpr int R = D + 1;                         // register ring
     constexpr int U = (S % R == 0) ? 1 : R;          // chunk unroll so that ring slots stay static
 
