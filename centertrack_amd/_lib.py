@@ -78,7 +78,8 @@ class DecodeDesc(ctypes.Structure):
                 ('out', ctypes.c_void_p), ('inds', ctypes.c_void_p),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
                 ('hm_batch_stride', ctypes.c_size_t), ('head_batch_stride', ctypes.c_size_t * NUM_HEADS),
-                ('out_stride', ctypes.c_int)]
+                ('out_stride', ctypes.c_int),
+                ('host_out', ctypes.c_void_p), ('done_flag', ctypes.c_void_p), ('done_counter', ctypes.c_void_p)]
 
 
 class PoseDesc(ctypes.Structure):

@@ -206,6 +206,9 @@ struct Stage2Args {
     int B, C, h, w, K, nseg, F;
     int M2;                          // candidate slots per image
     int keys_final;                  // the slots already hold (score : ~(class*HW + pixel)) keys (written by stage 2a)
+    float *host_out;                 // optional pinned host copy of the rows, flag raised when all images are done
+    int *done_flag;
+    unsigned *done_counter;
 };
 
 // NMS'd score key of flat index f = cls*HW + p, straight from HBM (slow path only)
@@ -617,6 +620,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         const int p = (int)(flat - (unsigned)cls * (unsigned)HW);
         const float ys0 = (float)(p / a.w), xs0 = (float)(p % a.w);
         float *row = a.out + ((size_t)b * a.K + r) * a.F;
+        float *hrow = a.host_out ? a.host_out + ((size_t)b * a.K + r) * a.F : nullptr;
         if (a.inds) a.inds[(size_t)b * a.K + r] = p;
         // every head value of this row is fetched up front, branch-free (absent heads read hm[0] and are
         // ignored): ~39 independent loads in flight instead of a chain of dependent round trips
@@ -632,7 +636,8 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         }
         auto hv = [&](int hd, int ch) { return hval[hd][ch]; };
         int f = 0;
-        row[f++] = score; row[f++] = (float)cls; row[f++] = xs0; row[f++] = ys0;
+        auto put = [&](float v) { row[f] = v; if (hrow) hrow[f] = v; ++f; };
+        put(score); put((float)cls); put(xs0); put(ys0);
         float xs = xs0 + 0.5f, ys = ys0 + 0.5f;                       // decode.py:102-110
         if (a.heads[CT_HEAD_REG]) { xs = xs0 + hv(CT_HEAD_REG, 0); ys = ys0 + hv(CT_HEAD_REG, 1); }
         const bool has_box = a.heads[CT_HEAD_WH] || a.heads[CT_HEAD_LTRB] || a.heads[CT_HEAD_LTRB_AMODAL];
@@ -653,8 +658,8 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
             am[2] = xs0 + hv(CT_HEAD_LTRB_AMODAL, 2); am[3] = ys0 + hv(CT_HEAD_LTRB_AMODAL, 3);
             for (int i = 0; i < 4; ++i) bb[i] = am[i];
         }
-        if (has_box) for (int i = 0; i < 4; ++i) row[f++] = bb[i];
-        if (a.heads[CT_HEAD_LTRB_AMODAL]) for (int i = 0; i < 4; ++i) row[f++] = am[i];
+        if (has_box) for (int i = 0; i < 4; ++i) put(bb[i]);
+        if (a.heads[CT_HEAD_LTRB_AMODAL]) for (int i = 0; i < 4; ++i) put(am[i]);
         const int rest[7] = {CT_HEAD_TRACKING, CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET,
                              CT_HEAD_NUSCENES_ATT, CT_HEAD_VELOCITY};
 #pragma unroll
@@ -662,7 +667,19 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
             const int hd = rest[q];
             if (!a.heads[hd]) continue;
 #pragma unroll
-            for (int ch = 0; ch < HCH[hd]; ++ch) row[f++] = hval[hd][ch];
+            for (int ch = 0; ch < HCH[hd]; ++ch) put(hval[hd][ch]);
+        }
+    }
+    if (a.done_flag) {
+        // every row of this image is out (device + host copy): the last image raises the host flag
+        __threadfence_system();
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const unsigned prev = atomicAdd(a.done_counter, 1u);
+            if (prev == (unsigned)a.B - 1u) {
+                *a.done_counter = 0u;
+                __hip_atomic_store(a.done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
         }
     }
 }
@@ -766,6 +783,8 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     a2.F = d->out_stride ? d->out_stride : ct_decode_row_floats(d);   // floats between consecutive rows
     if (a2.F < ct_decode_row_floats(d)) CT_FAIL_ARG("ct_decode: out_stride %d < row floats", d->out_stride);
     a2.M2 = (int)M2; a2.keys_final = 0;
+    a2.host_out = d->host_out; a2.done_flag = d->done_flag; a2.done_counter = d->done_counter;
+    if (d->done_flag && (!d->done_counter || !d->host_out)) CT_FAIL_ARG("ct_decode: done_flag needs host_out and done_counter");
     if (G > 0) {
         Stage2aArgs aa;
         aa.cand = a1.cand; aa.cand2 = a1.cand + (size_t)d->B * M2;

@@ -32,6 +32,7 @@ NATIVE_LOOP = os.environ.get('CENTERTRACK_NATIVE_LOOP', '1') != '0'   # (A/B swi
 # CENTERTRACK_SPLIT_STEM_MAX = largest image batch it is used for (0 = never).
 SPLIT_STEM_MAX = int(os.environ.get('CENTERTRACK_SPLIT_STEM_MAX', '0'))
 HOST_FLAG = os.environ.get('CENTERTRACK_HOST_FLAG', '1') != '0'       # end-of-frame flag in pinned host memory (A/B switch)
+HOST_ROWS = os.environ.get('CENTERTRACK_HOST_ROWS', '1') != '0'       # decode writes the rows to pinned host memory itself
 from .image import (affine_transform, draw_umich_gaussian, gaussian_radius, get_affine_transform, make_meta)
 from .model import create_model, load_model
 from .post_process import generic_post_process
@@ -220,10 +221,17 @@ class StreamDetector(object):
             merged = outs
         ctx['merged'] = merged
         dec_heads = {k: v for k, v in merged.items() if k != 'hm'}
-        ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K)
-        ctx['host_out'] = torch.empty(ctx['decoder'].out.shape, dtype=torch.float32).pin_memory()
-        ctx['host_rows'] = ctx['host_out'].numpy()
         ctx['done_flag'] = torch.zeros((16,), dtype=torch.int32).pin_memory()      # (its own cache line)
+        F = ops.Decoder.row_floats(dec_heads)
+        ctx['host_out'] = torch.zeros((merged['hm'].shape[0], opt.K, F), dtype=torch.float32).pin_memory()
+        # (round 3: the decode stores its rows straight into the pinned block and raises the end-of-frame flag itself --
+        #  no D2H copy node and no flag kernel at the end of the frame graph; not with pose heads, whose kernels
+        #  complete the rows after the decode)
+        direct = HOST_FLAG and HOST_ROWS
+        ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K, host_out=ctx['host_out'] if direct else None,
+                                     done_flag=ctx['done_flag'] if direct else None)
+        assert tuple(ctx['decoder'].out.shape) == tuple(ctx['host_out'].shape)
+        ctx['host_rows'] = ctx['host_out'].numpy()
         ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if (with_hm and not self.native) else None
         render = self.native and with_hm
         if render:
@@ -295,7 +303,7 @@ class StreamDetector(object):
                 for b in range(t.shape[0]):
                     _lib.check(lib.ct_memset_async(t[b].data_ptr(), 0, t[b].numel() * 4, _lib.stream_ptr()), 'memset')
             ctx['decoder'].run()
-            if with_copies:
+            if with_copies and not ctx['decoder'].direct:
                 _lib.check(_lib.load().ct_memcpy_async(ctx['host_out'].data_ptr(), ctx['decoder'].out.data_ptr(),
                                                        ctx['host_out'].numel() * 4, 2, _lib.stream_ptr()), 'D2H')
                 if HOST_FLAG:         # the native loop polls this flag instead of waiting in the runtime

@@ -240,7 +240,17 @@ class Decoder(object):
     shapes (graph-capture friendly).  One packed buffer ``out`` [B,K,F]: the rows of ct_decode followed, for the
     pose task, by the refined key points [2J] and ``kps_score`` [1]."""
 
-    def __init__(self, hm, heads, K):
+    @staticmethod
+    def row_floats(heads):
+        """floats per packed row for this set of heads (the pose fields included)"""
+        _, F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX])
+        if 'hps' in heads and 'hm_hp' in heads:
+            F += heads['hps'].shape[1] + 1
+        return F
+
+    def __init__(self, hm, heads, K, host_out=None, done_flag=None):
+        """``host_out`` (pinned host float32 [B,K,F]) / ``done_flag`` (pinned host int32): the decode also stores the
+        rows straight into host memory and raises the flag when they are complete (no pose heads)"""
         lib = _lib.load()
         self.K = K
         B, C, h, w = hm.shape
@@ -277,6 +287,13 @@ class Decoder(object):
         d.out, d.inds = self.out.data_ptr(), self.inds.data_ptr()
         d.out_stride = self.F
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes
+        self.direct = False
+        if host_out is not None and done_flag is not None and 'hps' not in heads:
+            assert tuple(host_out.shape) == (B, K, self.F) and host_out.is_pinned() and done_flag.is_pinned()
+            self.done_counter = torch.zeros((4,), dtype=torch.int32, device=hm.device)
+            d.host_out, d.done_flag = host_out.data_ptr(), done_flag.data_ptr()
+            d.done_counter = self.done_counter.data_ptr()
+            self.direct = True
         self.desc = d
         if 'hps' in heads:
             hps, hm_hp = heads['hps'], heads['hm_hp']

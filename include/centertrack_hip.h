@@ -228,6 +228,11 @@ typedef struct ct_decode_desc {
      * Lets the head maps be channel slices of one wider NCHW tensor (all heads written by one conv launch). */
     size_t hm_batch_stride; size_t head_batch_stride[CT_NUM_HEADS];
     int out_stride;            /* floats between consecutive rows of out; 0 = F (lets a wider row carry the pose fields) */
+    /* optional (round 3): the same rows ALSO stored straight into pinned HOST memory (same pitch), and *done_flag (pinned
+     * HOST int) set to 1 with system-scope release once every image's rows are there -- the frame graph then needs
+     * neither a D2H copy node nor a separate flag kernel behind the decode.  done_counter: DEVICE unsigned, zero before
+     * the first launch (the last workgroup resets it).  All three NULL: device rows only. */
+    float *host_out; int *done_flag; unsigned *done_counter;
 } ct_decode_desc;
 /* row layout: score, cls, xs0, ys0, then for each present field in this order:
  * bbox[4] (if wh|ltrb|ltrb_amodal), bbox_amodal[4] (if ltrb_amodal), tracking[2], dep[1],

@@ -84,7 +84,8 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
               'ct_conv_desc': (_lib.ConvDesc, ['x', 'split_k', 'algo', 'w_winograd']),
               'ct_pose_desc': (_lib.PoseDesc, ['rows', 'box_col', 'hp_offset', 'out', 'workspace_bytes', 'box_wh', 'box_ltrb',
                                                'box_ltrb_batch_stride']),
-              'ct_decode_desc': (_lib.DecodeDesc, ['hm', 'heads', 'out', 'hm_batch_stride', 'out_stride']),
+              'ct_decode_desc': (_lib.DecodeDesc, ['hm', 'heads', 'out', 'hm_batch_stride', 'out_stride', 'host_out', 'done_flag',
+                                                   'done_counter']),
               'ct_heads_desc': (_lib.HeadsDesc, ['x', 'w0_winograd', 'cout', 'out', 'depth_scale']),
               'ct_frame_loop_desc': (_lib.FrameLoopDesc, ['B', 'trackers', 'layout', 'out_thresh', 'host_rows', 'rows_keep',
                                                           'blob_params', 'blob_cap', 'nslots', 'graphs', 'frames',

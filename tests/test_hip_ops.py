@@ -645,6 +645,32 @@ def test_decode_selection_paths_full_size(device, name, C, h, w, B, K, dense):
         np.testing.assert_array_equal(got[k], want[k].numpy(), err_msg='%s.%s' % (name, k))
 
 
+@pytest.mark.parametrize('B', [1, 3])
+def test_decode_writes_rows_to_pinned_host_memory_and_raises_the_flag(device, B):
+    """round 3: ct_decode with host_out / done_flag -- the packed rows land in pinned host memory too (bit-identical to
+    the device rows), the flag is raised once every image is done, the arrival counter is back at zero (graph replays)"""
+    import scenarios as S
+    from centertrack_amd import ops
+    case = dict(name='host_rows', heads=S.HEAD_SETS['nusc'], B=B, h=28, w=50, K=64, seed=9)
+    maps = S.make_head_maps(case)
+    dev = {k: v.to(device).contiguous() for k, v in maps.items()}
+    heads = {k: v for k, v in dev.items() if k != 'hm'}
+    F = ops.Decoder.row_floats(heads)
+    host = torch.zeros((B, 64, F), dtype=torch.float32).pin_memory()
+    flag = torch.zeros((16,), dtype=torch.int32).pin_memory()
+    dec = ops.Decoder(dev['hm'], heads, 64, host_out=host, done_flag=flag)
+    assert dec.direct
+    for rep in range(3):
+        host.zero_()
+        flag.zero_()
+        out = dec.run()
+        torch.cuda.synchronize()
+        assert int(flag[0]) == 1 and int(dec.done_counter[0]) == 0
+        np.testing.assert_array_equal(host.numpy(), out.cpu().numpy())
+    plain = ops.Decoder(dev['hm'], heads, 64)
+    np.testing.assert_array_equal(plain.run().cpu().numpy(), host.numpy())
+
+
 def test_decode_nms_plateau_and_ties(device):
     """KAT-5: equal neighbours are both kept by the 3x3 NMS; exact ties order by lower
     class, then lower pixel (documented tie rule; torch leaves it unspecified)."""
