@@ -44,7 +44,7 @@ def build(force=False, verbose=False):
         if p.wait() != 0:
             raise RuntimeError('hipcc failed on %s' % src)
     if force or _stale(LIB, objs):
-        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs
+        cmd = [hipcc, '--offload-arch=gfx950', '-shared', '-fPIC', '-pthread', '-o', LIB] + objs
         if verbose:
             print(' '.join(cmd))
         subprocess.check_call(cmd)

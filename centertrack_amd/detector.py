@@ -184,10 +184,24 @@ class StreamDetector(object):
         self._rows_free = None
         self._ctx = None
 
+    def __del__(self):
+        try:
+            ctx = self._ctx
+            if ctx is not None and ctx.get('loop') is not None:
+                torch.cuda.synchronize()
+                _lib.load().ct_frame_loop_destroy(ctx['loop'])      # (joins its helper threads)
+                ctx['loop'] = None
+        except Exception:
+            pass
+
     # ---- per-shape device context (static buffers + captured graph) ----------------------
     def _context(self, H, W):
         if self._ctx is not None and self._ctx['hw'] == (H, W):
             return self._ctx
+        if self._ctx is not None and self._ctx.get('loop') is not None:      # another input size: a new loop below
+            torch.cuda.synchronize()
+            _lib.load().ct_frame_loop_destroy(self._ctx['loop'])
+            self._ctx['loop'] = None
         opt = self.opt
         NB = self.B * (2 if self.flip else 1)
         with_img = bool(getattr(opt, 'tracking', False)) and bool(getattr(opt, 'pre_img', True))

@@ -446,3 +446,27 @@ def test_native_loop_reset_tracking_and_single_detector_run(device):
     for a, b in zip(first, second):
         for f in ('tracking_id', 'score', 'bbox'):
             np.testing.assert_array_equal(a[f], b[f])
+
+
+def test_native_loop_with_helper_threads_equals_python_loop(device, monkeypatch):
+    """the per-stream post-process + association of a frame spread over helper threads (default from 8 streams on; forced
+    here for 3 streams): results identical to the Python loop"""
+    from centertrack_amd import detector as D
+    opt, model, batches, meta = _stream_setup(3)
+    metas = [dict(meta) for _ in range(3)]
+
+    def run(native, threads):
+        monkeypatch.setattr(D, 'NATIVE_LOOP', native)
+        monkeypatch.setenv('CENTERTRACK_HOST_THREADS', str(threads))
+        det = D.StreamDetector(opt, model=model, num_streams=3)
+        out = []
+        for t in range(len(batches)):
+            res = det.step(batches[t], metas, prefetch=batches[t + 1] if t + 1 < len(batches) else None, prefetch_metas=metas)
+            out.append([r.copy() for r in res])
+        return out
+    ref, got = run(False, 1), run(True, 3)
+    for a, b in zip(ref, got):
+        for x, y in zip(a, b):
+            assert len(x) == len(y) and len(x) > 0
+            for f in ('tracking_id', 'score', 'bbox', 'ct', 'class', 'age', 'active', 'row'):
+                np.testing.assert_array_equal(x[f], y[f])
