@@ -497,7 +497,10 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     if (algo == 43264) { p->NKK = 4; algo = 3264; }
     else if (algo == 432128) { p->NKK = 4; algo = 32128; }
     if (grouped) {
-        if (algo != 0 && algo != 3264 && algo != 32128) CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128)");
+        // (64-pixel tiles -- half the weight-fragment traffic per flop -- only without a fused offset conv: that stage
+        //  works on 32-pixel tiles)
+        if (algo != 0 && algo != 3264 && algo != 32128 && !((algo == 64 || algo == 128) && d->fuse_offset != 1))
+            CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128), or on 64-pixel tiles (64 / 128) when no offset conv is fused");
         if (algo == 0) algo = 3264;
     }
     if (algo == 3264) { p->BM = 32; p->BN = 64; }

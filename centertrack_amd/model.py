@@ -24,6 +24,7 @@ SMALL_SLOT_WGS = 600      # a MAIN slot with fewer workgroups than this (of 768 
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
+DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
 
 
 def _fold_bn(sd, p):
@@ -601,6 +602,8 @@ class DLASegHIP(torch.nn.Module):
                 for j, ly in enumerate(part):
                     ctypes.memmove(ctypes.byref(arr[j]), ctypes.byref(ly.desc[0]), ctypes.sizeof(_lib.DcnDesc))
                     arr[j].algo = 43264 if ly.nkk == 4 else 3264
+                    if DCN_TILE64 and not any(l2.fused for l2 in part):      # (experiment: 64-pixel tiles, un-fused slots)
+                        arr[j].algo = 64
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
