@@ -1,4 +1,4 @@
-"""Tie / threshold-flip report: the HIP path against the CPU oracle over >= 500 full-size frames, NOTHING re-seeded.
+"""Tie / threshold-flip report: the HIP path against the CPU oracle over 1664 full-size frames, NOTHING re-seeded.
 
 VERDICT r2 ("missing" 2): the parity tests refuse a stream that contains a *threshold tie* (an oracle score within 1e-5
 of out_thresh / new_thresh / pre_thresh) instead of measuring what happens on it.  This tool measures: every stream
@@ -38,7 +38,7 @@ import numpy as np  # noqa: E402
 TIE = 1e-5
 # (configuration, streams per detector = launch plan, runs, frames per run)
 PLAN = [
-    ('mot17_512', 1, 8, 32),          # the headline plan: 8 x 32 = 256 frames
+    ('mot17_512', 1, 40, 32),         # the headline plan: 40 x 32 = 1280 frames (half a MOT17-half)
     ('mot17_512', 8, 1, 16),          # 8-stream plan (Winograd raw-sum offsets): 128 frames
     ('coco_512', 4, 1, 24),           # 80 classes, BASELINE per-GPU batch: 96 frames
     ('nusc_800x448', 4, 1, 24),       # 3D heads: 96 frames
@@ -265,10 +265,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r03_tie_report.json'))
     ap.add_argument('--quick', action='store_true', help='a few frames (plumbing check)')
+    ap.add_argument('--mot-runs', type=int, default=0, help='runs of the headline plan (32 frames each); 0 = the PLAN default')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--threads', type=int, default=8)
     args = ap.parse_args()
-    plan = QUICK if args.quick else PLAN
+    plan = QUICK if args.quick else list(PLAN)
+    if args.mot_runs > 0 and not args.quick:
+        plan[0] = (plan[0][0], plan[0][1], args.mot_runs, plan[0][3])
     ncpu = os.cpu_count() or 8
     # (the oracle forward is memory-bound: 24 workers x 8 threads gave 2 frames/s in total on a 256-thread host, a single
     #  16-thread process gives 3.4 -- a third of the hardware threads is the sweet spot)
