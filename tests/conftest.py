@@ -16,6 +16,14 @@ def pytest_configure(config):
 def pytest_sessionstart(session):
     """a fresh checkout carries no built artefacts (they are git-ignored): build the HIP library and the oracle's C
     restatement once, exactly as __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU)"""
+    # the CPU oracle (torch conv / gather on the host) is fastest at ~16 threads: on the GPU box's 256 hardware threads
+    # the default (one thread per core) makes every oracle frame several times slower (bench.py's thread sweep)
+    try:
+        import torch
+        if (os.cpu_count() or 1) > 16:
+            torch.set_num_threads(16)
+    except Exception:
+        pass
     from centertrack_amd import _lib
     if not os.path.exists(_lib.LIB_PATH):
         import __graft_entry__
