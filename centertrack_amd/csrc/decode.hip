@@ -744,6 +744,7 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     int rc = check(d, "ct_decode");
     if (rc != CT_OK) return rc;
     if (!d->out) CT_FAIL_ARG("ct_decode: null output");
+    if (d->done_flag && (!d->done_counter || !d->host_out)) CT_FAIL_ARG("ct_decode: done_flag needs host_out and done_counter");
     const int seg = pick_seg(d);
     const int nseg = ct_cdiv(d->h * d->w, seg);
     const long M2 = (long)d->C * nseg * d->K;
@@ -784,7 +785,6 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     if (a2.F < ct_decode_row_floats(d)) CT_FAIL_ARG("ct_decode: out_stride %d < row floats", d->out_stride);
     a2.M2 = (int)M2; a2.keys_final = 0;
     a2.host_out = d->host_out; a2.done_flag = d->done_flag; a2.done_counter = d->done_counter;
-    if (d->done_flag && (!d->done_counter || !d->host_out)) CT_FAIL_ARG("ct_decode: done_flag needs host_out and done_counter");
     if (G > 0) {
         Stage2aArgs aa;
         aa.cand = a1.cand; aa.cand2 = a1.cand + (size_t)d->B * M2;

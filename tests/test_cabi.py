@@ -160,6 +160,35 @@ def test_group_plan_query_reports_errors_instead_of_zero(lib):
     assert b'Cin' in l.ct_last_error()
 
 
+def test_round3_entry_points_validate_their_arguments_without_gpu(lib):
+    """ct_frame_loop_create / ct_signal_host / ct_stem_forward_parts / ct_decode (host rows) reject bad descriptors before
+    anything touches a device"""
+    from centertrack_amd import _lib
+    l = _lib.load()
+    assert not l.ct_frame_loop_create(None) and b'bad descriptor' in l.ct_last_error()
+    d = _lib.FrameLoopDesc()
+    d.B, d.K, d.F = 1, 100, 17
+    assert not l.ct_frame_loop_create(ctypes.byref(d)) and b'bad descriptor' in l.ct_last_error()     # no trackers / rows / results
+    assert l.ct_frame_loop_submit(None, None) == _lib.CT_ERR_ARG
+    assert l.ct_frame_loop_wait(None) == _lib.CT_ERR_ARG
+    assert l.ct_frame_loop_pending_slot(None) == -1 and l.ct_frame_loop_in_flight(None) == -1
+    l.ct_frame_loop_destroy(None)                                 # a no-op
+    assert l.ct_signal_host(None, 1, None) == _lib.CT_ERR_ARG
+    buf = (ctypes.c_float * 64)()
+    p = ctypes.cast(buf, ctypes.c_void_p)
+    # no stem selected / input without weights
+    assert l.ct_stem_forward_parts(None, None, None, None, 0, 1, 32, 32, None, None, None, p, p, p, 16, None) == _lib.CT_ERR_ARG
+    assert b'no stem' in l.ct_last_error()
+    assert l.ct_stem_forward_parts(p, None, None, None, 0, 1, 32, 32, None, None, None, p, p, p, 16, None) == _lib.CT_ERR_ARG
+    dd = _lib.DecodeDesc()
+    dd.hm, dd.out, dd.B, dd.C, dd.h, dd.w, dd.K = p, p, 1, 1, 16, 16, 10
+    need = l.ct_decode_workspace_bytes(ctypes.byref(dd))
+    assert need > 0
+    dd.workspace, dd.workspace_bytes = p, need
+    dd.done_flag = p                                              # flag without host rows / arrival counter
+    assert l.ct_decode(ctypes.byref(dd), None) == _lib.CT_ERR_ARG and b'done_flag' in l.ct_last_error()
+
+
 def test_pinned_table_wins_over_a_user_cache_and_is_never_copied_into_it(tmp_path, monkeypatch):
     """a CENTERTRACK_TUNE_CACHE file written before the package shipped a re-tuned pinned table must not
     resurrect stale shapes, and the file only ever holds keys the pinned table does not"""
