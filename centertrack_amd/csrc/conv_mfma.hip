@@ -35,7 +35,41 @@ struct ConvArgs {
     float *ws;       // split-K workspace or nullptr
     int wsCout;      // channel pitch of the workspace
     EpiArgs epi;
+    float *pool_y;   // 3x3 stride-2 launches: 2x2 max-pool of the input as a side output (NHWC, pitch pool_ld), or nullptr
+    int pool_ld;
 };
+
+// 2x2 / stride-2 max-pool of the input from the staged LDS patch of a 3x3 stride-2 conv tile: output pixel (oy, ox) of
+// the tile covers input pixels (2oy .. 2oy+1, 2ox .. 2ox+1) = patch pixels (2*oyl + 1 .., 2*oxl + 1 ..) (the patch
+// starts one pixel above / left of the tile).  `buf`: the chunk's [slabs][PP][16] swizzled patch, `c0`: its first
+// channel.  Called by the cout-block-0 workgroups only (every channel chunk of every tile passes exactly one of them).
+template <int TH, int PW, int SLAB, int SLABS, int NTHR>
+__device__ __forceinline__ void pool_from_patch(const float *buf, int c0, float *pool_y, int pool_ld, int n, int oy0,
+                                                int ox0, int Ho, int Wo)
+{
+    constexpr int ITEMS = TH * 16 * SLABS * 4;
+    for (int it = threadIdx.x; it < ITEMS; it += NTHR) {
+        const int q = it & 3;
+        const int kk = (it >> 2) % SLABS;
+        const int px = (it >> 2) / SLABS;
+        const int oxl = px & 15, oyl = px >> 4;
+        const int oy = oy0 + oyl, ox = ox0 + oxl;
+        if (oy >= Ho || ox >= Wo) continue;
+        const int P0 = (2 * oyl + 1) * PW + 2 * oxl + 1;
+        f32x4 m;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int P = P0 + (j >> 1) * PW + (j & 1);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(buf + kk * SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2));
+            if (j == 0) m = v;
+            else {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) m[e] = fmaxf(m[e], v[e]);
+            }
+        }
+        *reinterpret_cast<f32x4 *>(pool_y + (((size_t)n * Ho + oy) * Wo + ox) * pool_ld + c0 + kk * 16 + q * 4) = m;
+    }
+}
 
 template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK>
 struct ConvCfg {
@@ -51,7 +85,9 @@ struct ConvCfg {
     static constexpr size_t LDS_BYTES = 2ull * BUF * sizeof(float);
 };
 
-template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE>
+// POOL: the instantiation that also writes the 2x2 max-pool of its input (3x3 stride-2 only; a separate
+// instantiation because the extra code costs the plain kernels 12-20 VGPRs)
+template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE, bool POOL = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 {
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
@@ -164,6 +200,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             stage_load(cnext);
             if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x386);
             const float *buf = lds + cur * C::BUF;
+            if constexpr (POOL && KS == 3 && STRIDE == 2) {
+                if (cb == 0)                    // (uniform) the input's 2x2 max-pool as a side output
+                    pool_from_patch<C::TH, C::PW, C::SLAB, NKK, 256>(buf, c * (16 * NKK), a.pool_y, a.pool_ld, n, oy0, ox0,
+                                                                     a.epi.Ho, a.epi.Wo);
+            }
 #pragma unroll
             for (int s = 0; s < S; ++s) {
                 const int kk = s / (KS * KS), tap = s % (KS * KS);
@@ -233,7 +274,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 // ---------------------------------------------------------------------------------------------
 // K-split variant for layers with few output tiles (deep levels: 16x16 .. 64x64 maps with
 // 128..1280 input channels): see ksplit_core.h.
-template <int KS, int STRIDE, int WM, int WN, int WK>
+template <int KS, int STRIDE, int WM, int WN, int WK, bool POOL = false>
 __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -249,7 +290,15 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
     const int c_end = min(a.nchunks, c_begin + a.chunksPerSplit);
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
     const int nt0 = cb * WN;
-    ksplit_conv_tile<KS, STRIDE, WM, WN, WK>(
+    using KC = KsCfg<KS, STRIDE, WM, WN, WK>;
+    auto hook = [&](int c, const float *buf) {
+        if constexpr (POOL && KS == 3 && STRIDE == 2) {
+            if (cb == 0)                        // (uniform) the input's 2x2 max-pool as a side output
+                pool_from_patch<WM, KC::PW, KC::SLAB, WK, 64 * WK>(buf, c * (16 * WK), a.pool_y, a.pool_ld, n, oy0, ox0,
+                                                                   a.epi.Ho, a.epi.Wo);
+        }
+    };
+    ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(
         xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds, [&](int mt, int nt, f32x4 sum) {
             const int oy = oy0 + mt;
             if (a.ws) {
@@ -267,7 +316,7 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
             } else {
                 ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane);
             }
-        });
+        }, hook);
 }
 
 // Deterministic split-K reduction + epilogue: one thread per (pixel, 4 couts).
@@ -441,6 +490,20 @@ template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIP
 int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
+    const size_t lds = (a.chunksPerSplit == 1) ? C::LDS_BYTES / 2 : C::LDS_BYTES;
+    if constexpr (KS == 3 && STRIDE == 2) {
+        if (a.pool_y) {
+            auto kp = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE, true>;
+            static bool attr_set_p = false;
+            if (!attr_set_p && C::LDS_BYTES > 48 * 1024) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)C::LDS_BYTES);
+                attr_set_p = true;
+            }
+            hipLaunchKernelGGL(kp, grid, dim3(256), lds, s, a);
+            return CT_OK;
+        }
+    }
     auto k = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE>;
     static bool attr_set = false;   // > 64 KiB dynamic LDS needs the opt-in attribute
     if (!attr_set && C::LDS_BYTES > 48 * 1024) {
@@ -448,7 +511,6 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
                                   (int)C::LDS_BYTES);
         attr_set = true;
     }
-    const size_t lds = (a.chunksPerSplit == 1) ? C::LDS_BYTES / 2 : C::LDS_BYTES;
     hipLaunchKernelGGL(k, grid, dim3(256), lds, s, a);
     return CT_OK;
 }
@@ -481,16 +543,29 @@ int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     using C = KsCfg<KS, STRIDE, WM, WN, WK>;
     static_assert(C::LDS_BYTES <= 160 * 1024, "LDS patch too large");
+    size_t lds = C::LDS_BYTES;
+    if (a.chunksPerSplit == 1) {
+        lds = sizeof(float) * (size_t)((C::BUF > C::RED) ? C::BUF : C::RED);
+    }
+    if constexpr (KS == 3 && STRIDE == 2) {
+        if (a.pool_y) {
+            auto kp = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK, true>;
+            static bool attr_set_p = false;
+            if (!attr_set_p && C::LDS_BYTES > 48 * 1024) {
+                (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                          (int)C::LDS_BYTES);
+                attr_set_p = true;
+            }
+            hipLaunchKernelGGL(kp, grid, dim3(64 * WK), lds, s, a);
+            return CT_OK;
+        }
+    }
     auto k = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK>;
     static bool attr_set = false;
     if (!attr_set && C::LDS_BYTES > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)C::LDS_BYTES);
         attr_set = true;
-    }
-    size_t lds = C::LDS_BYTES;
-    if (a.chunksPerSplit == 1) {
-        lds = sizeof(float) * (size_t)((C::BUF > C::RED) ? C::BUF : C::RED);
     }
     hipLaunchKernelGGL(k, grid, dim3(64 * WK), lds, s, a);
     return CT_OK;
@@ -568,6 +643,13 @@ extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
     a.epi.ldr = d->ldr; a.epi.ldy = d->ldy; a.epi.Cout = d->Cout; a.epi.Ho = p.Ho; a.epi.Wo = p.Wo;
     a.epi.flags = d->flags; a.epi.sig_lo = d->sig_lo; a.epi.sig_hi = d->sig_hi;
     a.epi.dep_lo = d->dep_lo; a.epi.dep_hi = d->dep_hi; a.epi.depth_scale = d->depth_scale;
+    a.pool_y = nullptr; a.pool_ld = 0;
+    if (d->pool_y) {
+        if (!(d->ks == 3 && d->stride == 2)) CT_FAIL_ARG("ct_conv2d: pool_y is a side output of the 3x3 stride-2 shapes");
+        if ((d->H & 1) || (d->W & 1) || d->pool_ld % 4 || d->pool_ld < d->Cin || ((uintptr_t)d->pool_y & 15))
+            CT_FAIL_ARG("ct_conv2d: pool_y needs even H / W and a 16-byte aligned view of >= Cin channels");
+        a.pool_y = d->pool_y; a.pool_ld = d->pool_ld;
+    }
     const long blocks = (long)d->N * p.tilesX * p.tilesY * p.coutBlocks;
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_conv2d: grid too large");
     dim3 grid((unsigned)blocks, (unsigned)p.splits);

@@ -34,9 +34,16 @@ struct KsCfg {
 // PD = B prefetch distance in (tap) steps: 2 for the multi-chunk backbone layers (registers); the single-chunk offset
 // conv of the DCN launches may fetch every tap's fragments up front (PD = KS*KS - 1): its 9-tap loop is otherwise
 // paced by the L2 latency of the weights (512 MFMA clocks per tap against a > 1000-clock round trip).
-template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin>
+struct KsNoHook {
+    __device__ __forceinline__ void operator()(int, const float *) const {}
+};
+
+// hook(chunk, buf): called by all threads at the top of every chunk with the chunk's staged patch in LDS ([WK slabs][PP]
+// [16 ch], swizzled like conv_mfma.hip's) -- lets a caller derive a side output from the input tile (2x2 max-pool)
+template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin, typename Hook = KsNoHook>
 __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W, int ldx, int Cin, const float *wp, int NT,
-                                                 int nt0, int oy0, int ox0, int c_begin, int c_end, float *lds, Fin fin)
+                                                 int nt0, int oy0, int ox0, int c_begin, int c_end, float *lds, Fin fin,
+                                                 Hook hook = Hook())
 {
     using C = KsCfg<KS, STRIDE, WM, WN, WK>;
     constexpr int PAD = KS / 2;
@@ -123,6 +130,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                     const int cur = (c - c_begin) & 1;
                     stage_load(min(c + 1, c_end - 1));
                     __builtin_amdgcn_sched_barrier(0x386);
+                    hook(c, lds + cur * C::BUF);
                     const float *buf = lds + cur * C::BUF + wave * C::SLAB;
 #pragma unroll
                     for (int s = 0; s < S; ++s) {

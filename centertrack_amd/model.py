@@ -24,6 +24,7 @@ SMALL_SLOT_WGS = 600      # a MAIN slot with fewer workgroups than this (of 768 
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
+FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-pools as side outputs of the stride-2 convs
 DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
 
 
@@ -231,7 +232,7 @@ class DLASegHIP(torch.nn.Module):
             d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out,
                                    w_wino=(ww if stride == 1 else None), **kw)
             us = autotune.tune_conv(d, dev)[2] if tune else 10.0
-            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw')), reads=(x, res),
+            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw'), kw.get('pool')), reads=(x, res),
                              writes=(out, kw.get('out_nchw')), us=us,
                              ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             return out
@@ -246,22 +247,31 @@ class DLASegHIP(torch.nn.Module):
         l0 = add_conv('level0', s0, P['level0'], 16, 3, out=alloc(H, W, 16))
         l1 = add_conv('level1', l0, P['level1'], 32, 3, stride=2, out=alloc(H // 2, W // 2, 32))
 
-        def leaf(name, x, pk, cin, cout, stride, R, out, bottom=None, level_root=False):
-            """Tree(levels=1).forward (dla.py:215-228) over the concat buffer R = [x2 | x1 | children]."""
+        def leaf(name, x, pk, cin, cout, stride, R, out, bottom=None, level_root=False, make_bottom=False):
+            """Tree(levels=1).forward (dla.py:215-228) over the concat buffer R = [x2 | x1 | children].  ``bottom`` =
+            Tree.downsample(x) (dla.py:207,217): a 2x2 max-pool that (round 3) tree1.conv1 -- the 3x3 stride-2 conv over
+            the same x -- writes as a side output of its launch instead of a launch of its own (``make_bottom``: the
+            caller owns the buffer and wants it filled here)."""
             h, w = x.H // stride, x.W // stride
+            fold = None
             if stride > 1 and bottom is None:
                 bottom = R.slice(2 * cout, cin) if level_root else alloc(h, w, cin)
-                L.append(_Launch(name + '.pool', 'pool', (x, bottom), reads=(x,), writes=(bottom,)))
+                make_bottom = True
             elif stride == 1:
                 bottom = x
+            if stride > 1 and make_bottom:
+                if FOLD_POOL:
+                    fold = bottom
+                else:
+                    L.append(_Launch(name + '.pool', 'pool', (x, bottom), reads=(x,), writes=(bottom,)))
+            t = alloc(h, w, cout)
+            x1 = R.slice(cout, cout)
+            x2 = R.slice(0, cout)
+            add_conv(name + '.t1.conv1', x, pk['c11'], cout, 3, stride=stride, out=t, pool=fold)
             if cin != cout:
                 residual = add_conv(name + '.project', bottom, pk['proj'], cout, 1, relu=False, out=alloc(h, w, cout))
             else:
                 residual = bottom
-            t = alloc(h, w, cout)
-            x1 = R.slice(cout, cout)
-            x2 = R.slice(0, cout)
-            add_conv(name + '.t1.conv1', x, pk['c11'], cout, 3, stride=stride, out=t)
             add_conv(name + '.t1.conv2', t, pk['c12'], cout, 3, res=residual, out=x1)
             add_conv(name + '.t2.conv1', x1, pk['c21'], cout, 3, out=t)
             add_conv(name + '.t2.conv2', t, pk['c22'], cout, 3, res=x1, out=x2)
@@ -283,10 +293,9 @@ class DLASegHIP(torch.nn.Module):
                 # Tree(levels=2): R2 = [y2 | y1 | bottom | x1]; the outer project is dead code (dla.py:218)
                 R2 = alloc(h, w, 3 * cout + cin)
                 bottom = R2.slice(2 * cout, cin)
-                L.append(_Launch(p + '.pool', 'pool', (x, bottom), reads=(x,), writes=(bottom,)))
                 x1 = R2.slice(2 * cout + cin, cout)
                 R1 = alloc(h, w, 2 * cout)
-                leaf(p + '.tree1', x, P[p + '.tree1'], cin, cout, 2, R1, x1, bottom=bottom)
+                leaf(p + '.tree1', x, P[p + '.tree1'], cin, cout, 2, R1, x1, bottom=bottom, make_bottom=True)
                 leaf(p + '.tree2', x1, P[p + '.tree2'], cout, cout, 1, R2, out)
             feats.append(out)
             x = out

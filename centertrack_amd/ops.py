@@ -87,7 +87,8 @@ def _p(t):
 
 def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, relu=False, out=None,
                    out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0, algo=0,
-                   w_wino=None):
+                   w_wino=None, pool=None):
+    """``pool``: NHWC view [N, H/2, W/2, Cin] that receives the 2x2 max-pool of ``x`` as a side output (3x3 stride-2)"""
     d = ConvDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
     d.w_packed, d.Cout, d.ks, d.stride = wp.data_ptr(), Cout, ks, stride
@@ -111,6 +112,9 @@ def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, 
     d.algo = algo
     if w_wino is not None:
         d.w_winograd = w_wino.data_ptr()
+    if pool is not None:
+        assert ks == 3 and stride == 2 and (pool.N, pool.H, pool.W, pool.C) == (x.N, x.H // 2, x.W // 2, x.C)
+        d.pool_y, d.pool_ld = pool.ptr, pool.ld
     return d
 
 

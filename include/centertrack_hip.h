@@ -87,6 +87,11 @@ typedef struct ct_conv_desc {
                                                    (3x3 stride 1, Cin % 64 == 0, NHWC output, needs w_winograd);
                                                    picked per layer by the host-side autotuner */
     const float *w_winograd;                    /* ct_pack_winograd_weight() of the same OIHW weight, or NULL */
+    /* optional side output of a 3x3 stride-2 conv (round 3): the 2x2 / stride-2 max-pool of its INPUT, NHWC [N, H/2, W/2,
+     * Cin] (pitch pool_ld) -- Tree.downsample (dla.py:207, nn.MaxPool2d(2, 2)) of the tensor tree1.conv1 reads; every
+     * input pixel passes through the workgroups' LDS patches anyway, so the pool costs no launch and no extra read.
+     * H and W must be even; NULL = off. */
+    float *pool_y; int pool_ld;
 } ct_conv_desc;
 int ct_conv2d(const ct_conv_desc *d, void *stream);
 size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);

@@ -81,7 +81,7 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
         pytest.skip('no gcc')
     checks = {'ct_dcn_desc': (_lib.DcnDesc, ['x', 'om', 'w_packed', 'workspace', 'fuse_offset', 'w_off_packed', 'up_w',
                                              'up_ldy', 'om_partial', 'om_partial_bytes']),
-              'ct_conv_desc': (_lib.ConvDesc, ['x', 'split_k', 'algo', 'w_winograd']),
+              'ct_conv_desc': (_lib.ConvDesc, ['x', 'split_k', 'algo', 'w_winograd', 'pool_y', 'pool_ld']),
               'ct_pose_desc': (_lib.PoseDesc, ['rows', 'box_col', 'hp_offset', 'out', 'workspace_bytes', 'box_wh', 'box_ltrb',
                                                'box_ltrb_batch_stride']),
               'ct_decode_desc': (_lib.DecodeDesc, ['hm', 'heads', 'out', 'hm_batch_stride', 'out_stride', 'host_out', 'done_flag',

@@ -158,6 +158,37 @@ def test_conv2d_ksplit_kernel_matches_torch(device, case):
     _close(out.to_nchw(), y, msg='ksplit conv')
 
 
+@pytest.mark.parametrize('algo,N,H,W,Cin,Cout,split_k', [
+    (1, 1, 32, 64, 16, 16, 1), (2, 2, 16, 32, 16, 32, 1), (3, 1, 32, 32, 32, 64, 1), (4, 1, 16, 32, 64, 160, 1),
+    (5, 1, 8, 16, 64, 64, 1), (6, 1, 32, 32, 32, 64, 1), (7, 1, 32, 64, 16, 32, 1), (8, 2, 16, 16, 48, 16, 1),
+    (3, 1, 16, 16, 128, 64, 2), (0, 1, 32, 32, 64, 128, 0),                                   # global split-K, auto plan
+    (101, 1, 16, 16, 64, 128, 1), (102, 1, 8, 8, 128, 256, 1), (103, 1, 4, 4, 256, 512, 1), (104, 1, 12, 20, 128, 64, 1),
+    (102, 2, 6, 10, 256, 96, 2),
+])
+def test_conv2d_stride2_pool_side_output(device, algo, N, H, W, Cin, Cout, split_k):
+    """round 3: the 3x3 stride-2 conv kernels (every row-tiled shape and every K-split shape) also write the 2x2 max-pool
+    of their INPUT (Tree.downsample, dla.py:207) as a side output: bit-identical to F.max_pool2d, the conv result
+    unchanged, nothing written outside the pool view's channel slice"""
+    from centertrack_amd import ops
+    x = _rand(N, Cin, H, W, seed=90 + algo)
+    w = _rand(Cout, Cin, 3, 3, seed=91, scale=(Cin * 9) ** -0.5)
+    shift = _rand(Cout, seed=92)
+    y = F.relu(F.conv2d(x, w, shift, stride=2, padding=1))
+    pb = torch.full((N, H // 2, W // 2, Cin + 12), -7.0).to(device)
+    pv = ops.View(pb, 8, Cin)
+    xv = ops.view_from_nchw(x.to(device))
+    out = ops.conv2d(xv, ops.pack_weight(w.to(device)), Cout, 3, 2, shift=shift.to(device), relu=True, split_k=split_k,
+                     algo=algo, pool=pv)
+    torch.cuda.synchronize()
+    _close(out.to_nchw(), y, msg='conv with pool side output, algo %d' % algo)
+    assert torch.equal(pv.to_nchw().cpu(), F.max_pool2d(x, 2, 2)), 'pooled side output (algo %d)' % algo
+    assert float(pb[..., :8].min()) == -7.0 and float(pb[..., 8 + Cin:].min()) == -7.0, 'wrote outside its slice'
+    plain = ops.conv2d(xv, ops.pack_weight(w.to(device)), Cout, 3, 2, shift=shift.to(device), relu=True, split_k=split_k,
+                       algo=algo)
+    torch.cuda.synchronize()
+    assert torch.equal(plain.to_nchw(), out.to_nchw())
+
+
 @pytest.mark.parametrize('algo,N,H,W,Cin,Cout', [(201, 1, 16, 32, 64, 64), (202, 2, 9, 21, 64, 48), (201, 1, 8, 16, 128, 256),
                                                  (202, 1, 5, 7, 256, 96), (201, 1, 12, 20, 64, 1280), (203, 2, 13, 21, 64, 80),
                                                  (203, 1, 8, 16, 128, 64), (204, 1, 10, 18, 192, 40), (204, 1, 16, 16, 64, 27),
