@@ -63,3 +63,16 @@ def test_unexplained_divergence_is_flagged():
     acc = TR.Acc()
     TR.compare_stream('x', ours, ref, 0.4, [0.4], (acc,))
     assert len(acc.report()['unexplained_divergences']) == 1
+
+
+def test_prior_heatmap_flip_is_counted_and_its_next_frame_is_kept_apart():
+    """a tracked object with score 0.5000001 vs 0.4999999 at pre_thresh = 0.5: rendered into the next prior heat-map on
+    one side only; the deltas of the NEXT frame go into the "after_prior_flip" bucket"""
+    ref = [_frame([0.9, 0.5000001, 0.2], [1, 2, 0]), _frame([0.9, 0.62, 0.2], [1, 2, 0]), _frame([0.9, 0.6, 0.2], [1, 2, 0])]
+    ours = [_frame([0.9, 0.4999999, 0.2], [1, 2, 0]), _frame([0.9, 0.61, 0.2], [1, 2, 0]), _frame([0.9, 0.6, 0.2], [1, 2, 0])]
+    acc = TR.Acc()
+    TR.compare_stream('x', ours, ref, 0.4, [0.4, 0.5], (acc,), pre_thresh=0.5)
+    r = acc.report()
+    assert r['prior_heatmap_flips']['count'] == 1 and r['prior_heatmap_flips']['frames_compared_right_after_one'] == 1
+    assert abs(r['prior_heatmap_flips']['abs_dscore_max_in_those_frames'] - 0.01) < 1e-6
+    assert r['abs_dscore']['max'] < 1e-6 and r['streams_with_id_divergence'] == 0

@@ -10,6 +10,10 @@ trajectory (tracker state, prior heat-map), and frame by frame the tool records
   * rank swaps: pairs of detections above the threshold whose order differs, with the oracle score gap of each pair,
   * threshold exposure: oracle scores within 1e-5 / 1e-4 / 1e-3 of a threshold,
   * threshold flips: detections above the threshold on one side only, with the oracle score's distance from it,
+  * prior-heat-map flips: a tracked object whose score passes ``pre_thresh`` on one side only (a score within fp32 noise
+    of pre_thresh): the two sides render different prior heat-maps for the NEXT frame, whose scores then differ by up to
+    ~1e-2 around that object without any detection or id changing; score / box deltas are therefore reported separately
+    for the frames that follow such a flip ("after_prior_flip") and for all others,
   * ids: the oracle-id <-> hip-id map must stay a bijection; the first frame where it breaks (or where the result lists
     differ in length) is the stream's *id divergence*; its cause is classified (threshold flip this frame or earlier /
     unexplained) and the stream is not compared beyond it (the two trajectories differ from there on).
@@ -115,9 +119,10 @@ def hip_streams(name, plan, B, runs, T):
                                             _slim(det.results_as_dicts(res[s], s, meta))))
     knobs = tuple(det._ctx['plan']['dcn_knobs'])
     thresholds = sorted(set((float(opt.out_thresh), float(opt.new_thresh), float(opt.pre_thresh))))
+    pre_thresh = float(opt.pre_thresh)
     del det, model
     torch.cuda.empty_cache()
-    return out, knobs, float(opt.out_thresh), thresholds
+    return out, knobs, float(opt.out_thresh), thresholds, pre_thresh
 
 
 def _keys(d, n):
@@ -136,6 +141,9 @@ class Acc(object):
         self.unexplained = []
         self.frames_total = 0
         self.events = []                      # every threshold flip / id divergence, spelled out
+        self.prior_flips = []                 # |oracle score - pre_thresh| of tracked objects rendered on one side only
+        self.dscore_after, self.dbox_after = [], []      # deltas in the frames right after such a flip
+        self.frames_after = 0
 
     def report(self):
         per_k = 1000.0 / max(self.frames, 1)
@@ -145,6 +153,11 @@ class Acc(object):
             'frames_compared': self.frames, 'frames_run': self.frames_total, 'detections_compared': self.dets,
             'abs_dscore': {'max': float(ds.max()), 'median': float(np.median(ds)), 'p99': float(np.percentile(ds, 99))},
             'abs_dbox_grid_max': float(db.max()),
+            'prior_heatmap_flips': {'count': len(self.prior_flips), 'per_1000_frames': round(len(self.prior_flips) * per_k, 2),
+                                    'max_oracle_distance_from_pre_thresh': float(max(self.prior_flips)) if self.prior_flips else 0.0,
+                                    'frames_compared_right_after_one': self.frames_after,
+                                    'abs_dscore_max_in_those_frames': float(max(self.dscore_after)) if self.dscore_after else 0.0,
+                                    'abs_dbox_grid_max_in_those_frames': float(max(self.dbox_after)) if self.dbox_after else 0.0},
             'rank_swaps': {'count': len(self.swaps), 'per_1000_frames': round(len(self.swaps) * per_k, 2),
                            'max_oracle_score_gap': float(max(self.swaps)) if self.swaps else 0.0},
             'oracle_scores_near_a_threshold': {k: {'count': v, 'per_1000_frames': round(v * per_k, 2)}
@@ -160,10 +173,11 @@ class Acc(object):
         }
 
 
-def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05):
+def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, pre_thresh=None):
     """ours / ref: per frame (decode arrays, slim results).  Updates every accumulator in ``accs``."""
     id_map, rev = {}, {}
     flipped = False
+    after_prior_flip = False                  # the previous frame rendered different prior heat-maps on the two sides
     for a in accs:
         a.streams += 1
         a.frames_total += len(ref)
@@ -188,8 +202,16 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05):
             ds = abs(float(sg[j]) - float(so[i]))
             db = float(np.abs(gd['bboxes'][j].astype(np.float64) - od['bboxes'][i].astype(np.float64)).max())
             for a in accs:
-                a.dscore.append(ds)
-                a.dbox.append(db)
+                if after_prior_flip:
+                    a.dscore_after.append(ds)
+                    a.dbox_after.append(db)
+                else:
+                    a.dscore.append(ds)
+                    a.dbox.append(db)
+        if after_prior_flip:
+            for a in accs:
+                a.frames_after += 1
+        after_prior_flip = False
         # rank swaps among the common keys
         order_g = [pos_g[k] for k in common]
         pos_o = {k: i for i, k in enumerate(ko)}
@@ -237,6 +259,14 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05):
                     break
                 used.add(cand[0])
                 wid, gid = rw['id'], got[cand[0]]['id']
+                if pre_thresh is not None and rw['active'] and got[cand[0]]['active'] and \
+                        (rw['score'] >= pre_thresh) != (got[cand[0]]['score'] >= pre_thresh):
+                    # rendered into the next frame's prior heat-map on one side only (detector.py:262)
+                    after_prior_flip = True
+                    for a in accs:
+                        a.prior_flips.append(abs(rw['score'] - pre_thresh))
+                        a.events.append({'stream': tag, 'frame': t, 'event': 'prior_heatmap_flip', 'oracle_score': rw['score'],
+                                         'hip_score': got[cand[0]]['score'], 'pre_thresh': pre_thresh})
                 if wid not in id_map and gid not in rev:
                     id_map[wid], rev[gid] = gid, wid
                 if id_map.get(wid) != gid:
@@ -267,6 +297,7 @@ def main():
     ap.add_argument('--quick', action='store_true', help='a few frames (plumbing check)')
     ap.add_argument('--mot-runs', type=int, default=0, help='runs of the headline plan (32 frames each); 0 = the PLAN default')
     ap.add_argument('--workers', type=int, default=0)
+    ap.add_argument('--dump', default='', help='also pickle the raw per-frame outputs of both sides (offline re-analysis)')
     ap.add_argument('--threads', type=int, default=8)
     args = ap.parse_args()
     plan = QUICK if args.quick else list(PLAN)
@@ -288,9 +319,9 @@ def main():
     pending = pool.map_async(oracle_stream, tasks, chunksize=1)
     hip, info = {}, {}
     for pi, (name, B, runs, T) in enumerate(plan):
-        out, knobs, out_thresh, thresholds = hip_streams(name, pi, B, runs, T)
+        out, knobs, out_thresh, thresholds, pre_thresh = hip_streams(name, pi, B, runs, T)
         hip.update(out)
-        info[(name, B)] = (knobs, out_thresh, thresholds)
+        info[(name, B)] = (knobs, out_thresh, thresholds, pre_thresh)
     t_hip = time.time() - t0
     oracle = {}
     cpu_s = 0.0
@@ -299,15 +330,19 @@ def main():
         cpu_s += dt
     pool.close()
     pool.join()
+    if args.dump:
+        import pickle
+        with open(args.dump, 'wb') as f:
+            pickle.dump({'hip': hip, 'oracle': oracle, 'info': info, 'plan': plan}, f)
     total = Acc()
     report = {'tie': TIE, 'plan': [], 'configs': {}}
     for pi, (name, B, runs, T) in enumerate(plan):
         acc = Acc()
-        knobs, out_thresh, thresholds = info[(name, B)]
+        knobs, out_thresh, thresholds, pre_thresh = info[(name, B)]
         for run in range(runs):
             for s in range(B):
                 compare_stream('%s x%d run %d stream %d' % (name, B, run, s), hip[(name, pi, run, s)],
-                               oracle[(name, pi, run, s)], out_thresh, thresholds, (acc, total))
+                               oracle[(name, pi, run, s)], out_thresh, thresholds, (acc, total), pre_thresh=pre_thresh)
         r = acc.report()
         r.update({'streams_per_detector': B, 'runs': runs, 'frames_per_run': T, 'dcn_knobs': list(knobs),
                   'thresholds': thresholds})
