@@ -10,10 +10,12 @@ trajectory (tracker state, prior heat-map), and frame by frame the tool records
   * rank swaps: pairs of detections above the threshold whose order differs, with the oracle score gap of each pair,
   * threshold exposure: oracle scores within 1e-5 / 1e-4 / 1e-3 of a threshold,
   * threshold flips: detections above the threshold on one side only, with the oracle score's distance from it,
-  * prior-heat-map flips: a tracked object whose score passes ``pre_thresh`` on one side only (a score within fp32 noise
-    of pre_thresh): the two sides render different prior heat-maps for the NEXT frame, whose scores then differ by up to
-    ~1e-2 around that object without any detection or id changing; score / box deltas are therefore reported separately
-    for the frames that follow such a flip ("after_prior_flip") and for all others,
+  * prior-heat-map flips: the blobs the two sides render into the NEXT frame's prior heat-map (detector.py:254-290: one
+    Gaussian per active track with score >= pre_thresh, at ``ct.astype(int32)`` with radius ``int(gaussian_radius(ceil(h),
+    ceil(w)))``) differ -- a score within fp32 noise of pre_thresh, or a centre / box size within fp32 noise of an integer
+    boundary (470.00000 vs 469.99997 -> the blob moves one pixel).  The next frame's scores then differ by up to ~1e-2
+    around that object without any detection or id changing; score / box deltas are therefore reported separately for
+    the frames that follow such a flip and for all others,
   * ids: the oracle-id <-> hip-id map must stay a bijection; the first frame where it breaks (or where the result lists
     differ in length) is the stream's *id divergence*; its cause is classified (threshold flip this frame or earlier /
     unexplained) and the stream is not compared beyond it (the two trajectories differ from there on).
@@ -134,6 +136,7 @@ class Acc(object):
         self.frames = self.dets = 0
         self.dscore, self.dbox = [], []
         self.swaps = []                       # oracle score gap of every out-of-order pair
+        self.swaps_after = []                 # ... in the frames right after a prior-heat-map flip
         self.exposure = {'1e-5': 0, '1e-4': 0, '1e-3': 0}
         self.flips = []                       # (|oracle score - threshold|, side) of detections above the threshold on one side only
         self.streams = self.diverged = self.id_permuted_streams = 0
@@ -154,8 +157,9 @@ class Acc(object):
             'abs_dscore': {'max': float(ds.max()), 'median': float(np.median(ds)), 'p99': float(np.percentile(ds, 99))},
             'abs_dbox_grid_max': float(db.max()),
             'prior_heatmap_flips': {'count': len(self.prior_flips), 'per_1000_frames': round(len(self.prior_flips) * per_k, 2),
-                                    'max_oracle_distance_from_pre_thresh': float(max(self.prior_flips)) if self.prior_flips else 0.0,
                                     'frames_compared_right_after_one': self.frames_after,
+                                    'rank_swaps_in_those_frames': len(self.swaps_after),
+                                    'max_oracle_score_gap_of_those_swaps': float(max(self.swaps_after)) if self.swaps_after else 0.0,
                                     'abs_dscore_max_in_those_frames': float(max(self.dscore_after)) if self.dscore_after else 0.0,
                                     'abs_dbox_grid_max_in_those_frames': float(max(self.dbox_after)) if self.dbox_after else 0.0},
             'rank_swaps': {'count': len(self.swaps), 'per_1000_frames': round(len(self.swaps) * per_k, 2),
@@ -173,7 +177,25 @@ class Acc(object):
         }
 
 
-def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, pre_thresh=None):
+def prior_blobs(items, pre_thresh, meta):
+    """the (cx, cy, radius) triples Detector._get_additional_inputs (detector.py:254-290) renders for these tracks"""
+    import math
+    from oracle.detector import trans_bbox
+    from oracle.image import gaussian_radius
+    out = []
+    for it in items:
+        if it['score'] < pre_thresh or it['active'] == 0:
+            continue
+        bb = trans_bbox(np.array(it['bbox'], np.float32), meta['trans_input'], meta['inp_width'], meta['inp_height'])
+        h, w = bb[3] - bb[1], bb[2] - bb[0]
+        if h > 0 and w > 0:
+            r = max(0, int(gaussian_radius((math.ceil(h), math.ceil(w)))))
+            ct = np.array([(bb[0] + bb[2]) / 2, (bb[1] + bb[3]) / 2], np.float32).astype(np.int32)
+            out.append((int(ct[0]), int(ct[1]), r))
+    return sorted(out)
+
+
+def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, pre_thresh=None, meta=None):
     """ours / ref: per frame (decode arrays, slim results).  Updates every accumulator in ``accs``."""
     id_map, rev = {}, {}
     flipped = False
@@ -182,6 +204,8 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
         a.streams += 1
         a.frames_total += len(ref)
     for t, ((gd, got), (od, want)) in enumerate(zip(ours, ref)):
+        post = after_prior_flip               # this frame ran on prior heat-maps that differ between the two sides
+        after_prior_flip = False
         so, sg = od['scores'], gd['scores']
         no, ng = int((so > out_thresh).sum()), int((sg > out_thresh).sum())
         ko, kg = _keys(od, no), _keys(gd, ng)
@@ -202,16 +226,15 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
             ds = abs(float(sg[j]) - float(so[i]))
             db = float(np.abs(gd['bboxes'][j].astype(np.float64) - od['bboxes'][i].astype(np.float64)).max())
             for a in accs:
-                if after_prior_flip:
+                if post:
                     a.dscore_after.append(ds)
                     a.dbox_after.append(db)
                 else:
                     a.dscore.append(ds)
                     a.dbox.append(db)
-        if after_prior_flip:
+        if post:
             for a in accs:
                 a.frames_after += 1
-        after_prior_flip = False
         # rank swaps among the common keys
         order_g = [pos_g[k] for k in common]
         pos_o = {k: i for i, k in enumerate(ko)}
@@ -220,7 +243,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
                 if order_g[x] > order_g[y]:
                     gap = abs(float(so[pos_o[common[x]]]) - float(so[pos_o[common[y]]]))
                     for a in accs:
-                        a.swaps.append(gap)
+                        (a.swaps_after if post else a.swaps).append(gap)
         # threshold flips (out_thresh; new_thresh equals it in tracking mode, pre_thresh acts on the next frame)
         only_o = [k for k in ko if k not in pos_g]
         only_g = [k for k in kg if k not in pos_o]
@@ -259,7 +282,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
                     break
                 used.add(cand[0])
                 wid, gid = rw['id'], got[cand[0]]['id']
-                if pre_thresh is not None and rw['active'] and got[cand[0]]['active'] and \
+                if pre_thresh is not None and meta is None and rw['active'] and got[cand[0]]['active'] and \
                         (rw['score'] >= pre_thresh) != (got[cand[0]]['score'] >= pre_thresh):
                     # rendered into the next frame's prior heat-map on one side only (detector.py:262)
                     after_prior_flip = True
@@ -272,6 +295,16 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
                 if id_map.get(wid) != gid:
                     broken = 'oracle track %d is hip track %d (was %s)' % (wid, gid, id_map.get(wid))
                     break
+        if pre_thresh is not None and meta is not None and broken is None:
+            bo, bg = prior_blobs(want, pre_thresh, meta), prior_blobs(got, pre_thresh, meta)
+            if bo != bg:
+                after_prior_flip = True
+                only_o_b = [b for b in bo if b not in bg]
+                only_g_b = [b for b in bg if b not in bo]
+                for a in accs:
+                    a.prior_flips.append(0.0)
+                    a.events.append({'stream': tag, 'frame': t, 'event': 'prior_heatmap_flip', 'oracle_blobs': only_o_b,
+                                     'hip_blobs': only_g_b})
         if broken is not None:
             # a flip at a pre_thresh tie one frame earlier shows up as a changed prior heat-map: also "threshold" caused
             near_pre = False
@@ -298,11 +331,17 @@ def main():
     ap.add_argument('--mot-runs', type=int, default=0, help='runs of the headline plan (32 frames each); 0 = the PLAN default')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--dump', default='', help='also pickle the raw per-frame outputs of both sides (offline re-analysis)')
+    ap.add_argument('--from-dump', default='', help='recompute the report from a pickle written by --dump (no GPU, no oracle runs)')
     ap.add_argument('--threads', type=int, default=8)
     args = ap.parse_args()
     plan = QUICK if args.quick else list(PLAN)
     if args.mot_runs > 0 and not args.quick:
         plan[0] = (plan[0][0], plan[0][1], args.mot_runs, plan[0][3])
+    if args.from_dump:
+        import pickle
+        with open(args.from_dump, 'rb') as f:
+            raw = pickle.load(f)
+        return write_report(args, raw['plan'], raw['hip'], raw['oracle'], raw['info'], raw.get('timing', {}))
     ncpu = os.cpu_count() or 8
     # (the oracle forward is memory-bound: 24 workers x 8 threads gave 2 frames/s in total on a 256-thread host, a single
     #  16-thread process gives 3.4 -- a third of the hardware threads is the sweet spot)
@@ -330,19 +369,30 @@ def main():
         cpu_s += dt
     pool.close()
     pool.join()
+    timing = {'wall_s': round(time.time() - t0, 1), 'hip_s': round(t_hip, 1), 'oracle_cpu_s': round(cpu_s, 1),
+              'oracle_workers': [workers, args.threads]}
     if args.dump:
         import pickle
         with open(args.dump, 'wb') as f:
-            pickle.dump({'hip': hip, 'oracle': oracle, 'info': info, 'plan': plan}, f)
+            pickle.dump({'hip': hip, 'oracle': oracle, 'info': info, 'plan': plan, 'timing': timing}, f)
+    return write_report(args, plan, hip, oracle, info, timing)
+
+
+def write_report(args, plan, hip, oracle, info, timing):
+    import scenarios as S
+    from centertrack_amd.image import make_meta
     total = Acc()
     report = {'tie': TIE, 'plan': [], 'configs': {}}
     for pi, (name, B, runs, T) in enumerate(plan):
         acc = Acc()
         knobs, out_thresh, thresholds, pre_thresh = info[(name, B)]
+        cfg = S.CONFIGS[name]
+        meta = make_meta(cfg['H'], cfg['W'], 2 * cfg['H'], 2 * cfg['W'])
         for run in range(runs):
             for s in range(B):
                 compare_stream('%s x%d run %d stream %d' % (name, B, run, s), hip[(name, pi, run, s)],
-                               oracle[(name, pi, run, s)], out_thresh, thresholds, (acc, total), pre_thresh=pre_thresh)
+                               oracle[(name, pi, run, s)], out_thresh, thresholds, (acc, total), pre_thresh=pre_thresh,
+                               meta=meta)
         r = acc.report()
         r.update({'streams_per_detector': B, 'runs': runs, 'frames_per_run': T, 'dcn_knobs': list(knobs),
                   'thresholds': thresholds})
@@ -350,10 +400,7 @@ def main():
         report['plan'].append([name, B, runs, T])
     report['total'] = total.report()
     report['seeds'] = 'stream seed = 317 + 7 + 100 * stream + 1000 * run + 100000 * plan index (tests/_parity.scrolled_stream); nothing re-seeded'
-    report['wall_s'] = round(time.time() - t0, 1)
-    report['hip_s'] = round(t_hip, 1)
-    report['oracle_cpu_s'] = round(cpu_s, 1)
-    report['oracle_workers'] = [workers, args.threads]
+    report.update(timing)
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, 'w') as f:
         json.dump(report, f, indent=1)
