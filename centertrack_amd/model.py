@@ -630,9 +630,10 @@ class DLASegHIP(torch.nn.Module):
 
     @staticmethod
     def _dcn_slot_sizes(layers, produced0, N, cps, with_mains=False):
-        """{MAIN slot: workgroups} of the schedule with ``cps`` chunks per split everywhere (the slot of a layer does
-        not depend on how finely it is split: a split layer is readable one time step later, which rounds to the same
-        next slot)"""
+        """{MAIN slot: workgroups} of the schedule with ``cps`` chunks per split everywhere.  A split layer is readable
+        one time step later, which rounds to the same next MAIN slot for a consumer that READS it; only a `proj` node
+        whose SKIP input comes from a split layer finishes one slot later (at 512x512: ida_up.node_1/2 move from slots
+        7/8 to 8/10 when the 64-channel nodes are split, cps = 1)"""
         time_of = dict(produced0)
         sizes = {}
         mains = []
