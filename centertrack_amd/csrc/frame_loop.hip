@@ -31,7 +31,8 @@ namespace {
 
 // A few persistent helper threads for the per-stream host work of a frame (post-process + association: ~10 us per
 // stream, 0.36 ms of serial host time between two 32-stream graphs in round 3's first measurements).  The caller takes
-// part; helpers spin briefly for the next job, then sleep on a condition variable (a frame batch takes milliseconds).
+// part; helpers sleep on a condition variable between jobs (a frame batch takes milliseconds) and the caller spins for the
+// last of them to hand in its share.
 class StreamPool {
 public:
     explicit StreamPool(int helpers) {
@@ -197,6 +198,7 @@ extern "C" void ct_frame_loop_destroy(void *loop)
 {
     Loop *L = (Loop *)loop;
     if (!L) return;
+    if (L->in_flight && L->frame_done) (void)hipEventSynchronize(L->frame_done);   // (the graph writes the caller's host rows and flag)
     if (L->copy_stream) { (void)hipStreamSynchronize(L->copy_stream); (void)hipStreamDestroy(L->copy_stream); }
     if (L->frame_ready) (void)hipEventDestroy(L->frame_ready);
     if (L->frame_done) (void)hipEventDestroy(L->frame_done);
@@ -252,7 +254,7 @@ extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
         if (e != hipSuccess) return fail("ct_frame_loop_submit(wait for the uploaded frame)", e);
     } else if (a->frame_kind == CT_FRAME_DEVICE || a->frame_kind == CT_FRAME_HOST) {
         if (!a->frame) CT_FAIL_ARG("ct_frame_loop_submit: null frame");
-        if (L->uploaded_slot == a->slot) {     // an upload nobody will use targets this slot: let it finish first
+        if (L->uploaded_slot >= 0) {           // an upload nobody will use is pending (this slot or another): let it finish first
             e = hipStreamWaitEvent(s, L->frame_ready, 0);
             if (e != hipSuccess) return fail("ct_frame_loop_submit(wait for a stale upload)", e);
         }
