@@ -91,7 +91,12 @@ extern "C" int ct_dcn_clear_stamps(void)
 #define CT_STAMP_VAL(i, v)
 #endif
 
+// (variant build -DCT_DCN_WAVES=4, tools/build_variant.py: at 148 VGPRs three workgroups share a CU, 768 on the chip, and
+//  the second MAIN launch of the one-stream plan has 1024 -- a full round and a third of one)
 template <int BM, int WN, bool FUSE, int NKK = 2>
+#if defined(CT_DCN_WAVES)
+__attribute__((amdgpu_waves_per_eu(CT_DCN_WAVES)))
+#endif
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 {
     CT_STAMP_RT(0);
