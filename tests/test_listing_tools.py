@@ -1,0 +1,58 @@
+"""CPU: the two listing tools that guard blind kernel work -- tools/isa_diff.py (did a change leave the shipped kernels'
+instruction streams alone?) and tools/occupancy.py (registers / LDS / waves per SIMD from the code-object metadata)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+
+LISTING = '''
+\t.type\t_Z1aPf,@function
+_Z1aPf:                                 ; @_Z1aPf
+; %%bb.0:
+\ts_load_dwordx2 s[0:1], s[0:1], 0x0
+.LBB0_%d:
+\tv_add_f32_e32 v0, %s, v0               ; a comment
+\ts_cbranch_scc1 .LBB0_%d
+\ts_endpgm
+.Lfunc_end0:
+\t.size\t_Z1aPf, .Lfunc_end0-_Z1aPf
+\t.type\t_Z1bPf,@function
+_Z1bPf:                                 ; @_Z1bPf
+\ts_endpgm
+.Lfunc_end1:
+amdhsa.kernels:
+  - .agpr_count:     0
+    .group_segment_fixed_size: 4096
+    .name:           _Z1aPf
+    .private_segment_fixed_size: 0
+    .vgpr_count:     %d
+    .vgpr_spill_count: 0
+  - .agpr_count:     16
+    .group_segment_fixed_size: 0
+    .name:           _Z1bPf
+    .private_segment_fixed_size: 24
+    .vgpr_count:     200
+    .vgpr_spill_count: 6
+amdhsa.target:   amdgcn-amd-amdhsa--gfx950
+'''
+
+
+def test_isa_diff_ignores_label_numbers_and_comments_but_not_instructions(tmp_path, capsys):
+    import isa_diff
+    a, b, c = tmp_path / 'a.s', tmp_path / 'b.s', tmp_path / 'c.s'
+    a.write_text(LISTING % (3, 'v1', 3, 148))
+    b.write_text(LISTING % (7, 'v1', 7, 148))           # labels renumbered only
+    c.write_text(LISTING % (3, 'v2', 3, 148))           # another operand
+    assert isa_diff.main(str(a), str(b)) == 0
+    assert isa_diff.main(str(a), str(c)) == 1
+    out = capsys.readouterr().out
+    assert 'CHANGED _Z1aPf' in out and 'same    _Z1bPf' in out
+
+
+def test_occupancy_reads_registers_spills_and_lds(tmp_path):
+    import occupancy
+    p = tmp_path / 'k.s'
+    p.write_text(LISTING % (1, 'v1', 1, 148))
+    rows = {r['name']: r for r in occupancy.kernels(str(p))}
+    assert rows['_Z1aPf'] == dict(name='_Z1aPf', vgpr=148, spill=0, lds=4096, scratch=0)
+    assert rows['_Z1bPf']['spill'] == 6 and rows['_Z1bPf']['scratch'] == 24 and rows['_Z1bPf']['vgpr'] == 200
