@@ -16,6 +16,10 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt /tmp/pmcA /tmp/pmcB /tmp/pmcC
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- $BENCH > /dev/null 2>&1
 python $R/tools/rocpd_stats.py $(ls /tmp/prof_kt/*/*.db | head -1) 40 > $OUT/${TAG}_rocprofv3_kernel_stats_bench_steps3.txt
+# the same run once more as a CSV trace: grid, registers and LDS of every dispatch -> whole-round table of one frame
+rm -rf /tmp/prof_csv
+rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_csv -o kt -- $BENCH > /dev/null 2>&1
+python $R/tools/rounds.py $(ls /tmp/prof_csv/*kernel_trace.csv /tmp/prof_csv/*/*kernel_trace.csv 2>/dev/null | head -1) > $OUT/${TAG}_rounds_b1.txt 2>&1
 BENCH2="python $R/bench.py --steps 1 --warmup 1 --frames-per-step 24 --no-cpu-baseline --no-roofline --no-resident"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcA -o pmcA -- $BENCH2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcB -o pmcB -- $BENCH2 > /dev/null 2>&1
