@@ -56,3 +56,13 @@ def test_occupancy_reads_registers_spills_and_lds(tmp_path):
     rows = {r['name']: r for r in occupancy.kernels(str(p))}
     assert rows['_Z1aPf'] == dict(name='_Z1aPf', vgpr=148, spill=0, lds=4096, scratch=0)
     assert rows['_Z1bPf']['spill'] == 6 and rows['_Z1bPf']['scratch'] == 24 and rows['_Z1bPf']['vgpr'] == 200
+
+
+def test_rounds_residency_by_registers_lds_and_workgroup_size():
+    import rounds
+    assert rounds.per_cu(148, 0, 29696, 256)[0] == 3          # the fused DCN kernel: registers
+    assert rounds.per_cu(112, 16, 29696, 256)[0] == 4         # 128 in total (unified file): 4 per CU
+    assert rounds.per_cu(124, 0, 40960, 256)[0] == 4          # capped stem: registers and LDS both allow 4
+    assert rounds.per_cu(52, 0, 81920, 256)[0] == 2           # LDS-bound
+    assert rounds.per_cu(164, 0, 0, 512)[0] == 1              # 8-wave workgroups at 3 waves per SIMD: one fits
+    assert rounds.per_cu(96, 0, 0, 1024)[0] == 1              # 16-wave workgroups: 5 waves per SIMD, 4 needed per workgroup
