@@ -552,6 +552,21 @@ __global__ __launch_bounds__(256) void dcn16_kernel(DcnGroup g)
     const int c_end = min(nunits, c_begin + (a.chunksPerSplit >> 1));
 
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
+    if (FUSE && a.offsOnly) {
+        // CT_DCN_OFFSETS on one-row tiles (knob `dcn_offs16`): chunk `split` (64 input channels) of the offset/mask conv
+        // of this row of 16 pixels, raw -- the sums of the 32-pixel launch, pixel by pixel, from twice the workgroups
+        float *part = a.omPart + ((size_t)split * a.N + n) * a.H * a.W * 32;
+        auto fin = [&](int, int nt, f32x4 sum) {
+            const int co = nt * 16 + (lane & 15);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ox = ox0 + (lane >> 4) * 4 + e;
+                if (ox < a.W) part[((size_t)oy0 * a.W + ox) * 32 + co] = sum[e];
+            }
+        };
+        ksplit_conv_tile<3, 1, 1, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, split, split + 1, lds_a, fin);
+        return;
+    }
     const bool fuse = FUSE && a.w_off != nullptr;                // (uniform)
     const bool parts = a.omSplits > 0;                           // (uniform)
     const float *omn = (fuse || parts) ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
@@ -1016,6 +1031,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
     hipStream_t s = (hipStream_t)stream;
     if (phases & CT_DCN_OFFSETS) {
         // the K-split offset/mask convs of the layers that asked for them (fuse_offset == 2), all in one launch
+        const bool offs16 = ct_tune_get(CT_TUNE_DCN_OFFS16) != 0;      // (experiment: one-row tiles, dcn16_kernel)
         DcnGroup og;
         og.n = 0;
         long oblocks = 0;
@@ -1024,7 +1040,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
             if (d->fuse_offset != 2) continue;            // (3: another launch wrote the raw sums)
             DcnArgs &a = og.p[og.n];
             a = g.p[i];
-            a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 2); a.coutBlocks = 1;
+            a.tilesX = ct_cdiv(d->W, 16); a.tilesY = offs16 ? d->H : ct_cdiv(d->H, 2); a.coutBlocks = 1;
             a.tiles = d->N * a.tilesX * a.tilesY;
             a.w_off = d->w_off_packed;
             a.offsOnly = 1;
@@ -1036,7 +1052,8 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
             if (oblocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
             for (int i = og.n; i <= DCN_MAX_GROUP; ++i) og.first[i] = (int)oblocks;
             for (int i = og.n; i < DCN_MAX_GROUP; ++i) og.p[i] = og.p[0];
-            hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), dim3((unsigned)oblocks), dim3(256), lds_bytes(32, true, true), s, og);
+            if (offs16) hipLaunchKernelGGL((dcn16_kernel<true>), dim3((unsigned)oblocks), dim3(256), lds_bytes16(true, true), s, og);
+            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), dim3((unsigned)oblocks), dim3(256), lds_bytes(32, true, true), s, og);
             CT_CHECK_LAUNCH("ct_dcn_v2(offset/mask conv)");
         }
     }

@@ -67,6 +67,28 @@ def test_dcn16_with_its_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, sp
     _close(out.to_nchw(), ref.to_nchw().cpu(), atol=2e-5, rtol=2e-5, msg='16- vs 32-pixel tiles')
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,algo', [(2, 9, 21, 128, 64, 43264), (1, 7, 33, 256, 128, 41664)])
+def test_offsets_launch_on_one_row_tiles_is_bit_identical(device, N, H, W, Cin, Cout, algo):
+    """knob `dcn_offs16`: the K-split offset/mask conv launch on 16-pixel rows writes the partial maps of the 32-pixel
+    launch bit for bit (same slabs, same order per pixel), so the DCN output does not change by a bit either"""
+    from centertrack_amd import _lib, ops
+    lib = _lib.load()
+    x = F.relu(_rand(N, Cin, H, W, seed=140))
+    w, b = _rand(Cout, Cin, 3, 3, seed=141, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=142)
+    wo, bo = _rand(27, Cin, 3, 3, seed=143, scale=0.6 * (Cin * 9) ** -0.5), _rand(27, seed=144, scale=0.3)
+    xv, wp = ops.view_from_nchw(x.to(device)), ops.pack_weight(w.to(device))
+    kw = dict(shift=b.to(device), algo=algo, split_k=1, w_off=ops.pack_weight(wo.to(device)), b_off=bo.to(device),
+              split_offsets=True)
+    try:
+        assert lib.ct_set_tuning(b'dcn_offs16', 0) == 0
+        base = ops.dcn_v2(xv, None, wp, Cout, **kw).to_nchw().clone()
+        assert lib.ct_set_tuning(b'dcn_offs16', 1) == 0
+        got = ops.dcn_v2(xv, None, wp, Cout, **kw).to_nchw().clone()
+    finally:
+        lib.ct_set_tuning(b'dcn_offs16', 0)
+    assert torch.equal(got, base)
+
+
 @pytest.mark.parametrize('f,split_k', [(2, 2), (4, 1)])
 def test_dcn16_group_with_idaup_step(device, f, split_k):
     """two layers in one MAIN launch on 16-pixel tiles + one FINISH launch (split-K reduction, BN, ReLU, IDAUp step) ==

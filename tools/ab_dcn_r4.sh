@@ -49,6 +49,14 @@ for v in w4 deep stemw4 stemco all; do
         echo "$v ops tests rc=$?" | tee -a $OUT/tests.log
     fi
 done
+# the un-fused schedule (every offset conv in its slot's K-split OFFSETS launch: round 3's experiment 2, MAIN launches at
+# 75-90 TFLOP/s but 8.5-9 us per OFFSETS launch) with those launches on one-row tiles (knob dcn_offs16), alone and with
+# the 16-pixel MAIN tiles
+line base A=0
+line unfused CENTERTRACK_DCN_KNOBS=0,4,4,1,0,0
+line unfused_offs16 CENTERTRACK_DCN_KNOBS=0,4,4,1,0,0 CENTERTRACK_TUNE=dcn_offs16=1
+line unfused_offs16_tile16 CENTERTRACK_DCN_KNOBS=0,4,4,1,0,0 CENTERTRACK_TUNE=dcn_offs16=1 CENTERTRACK_DCN_TILE16=1100
+line offs16 CENTERTRACK_TUNE=dcn_offs16=1
 if [ -f $V/libcentertrack_hip_w4.so ]; then line w4_tile16 CENTERTRACK_LIB=$V/libcentertrack_hip_w4.so CENTERTRACK_DCN_TILE16=600; fi
 for B in 8; do
     for v in 0 1000000000; do
