@@ -705,6 +705,240 @@ __global__ __launch_bounds__(256) void dcn16_kernel(DcnGroup g)
     }
 }
 
+// ---- 32 x 32 x 2 MFMA tiles (algo 53264; VERDICT r2 item 2 (ii), written at the end of round 3 without a GPU at hand:
+// `CENTERTRACK_DCN_M32` in model.py is the A/B switch, tests/test_hip_experimental.py covers it, no pinned plan selects it)
+// Same workgroup tile as the 64-channel-step shape (32 pixels = 2 rows x 16, 64 couts, 64 channels per step), same
+// gather, same table; the contraction runs on `v_mfma_f32_32x32x2_f32`: the four waves are 2 n-tiles of 32 couts x 2
+// K halves (slabs {0,1} / {2,3} of a step), every wave owns ONE 32 x 32 accumulator.  Per step and wave: 16 MFMAs of 64
+// cycles (the matrix time of today's 32 MFMAs of 32 cycles), but 4 `ds_read_b128` of A fragments instead of 8 -- half the LDS
+// fragment traffic per flop -- and 16 accumulator + 16 fragment registers instead of 8 + 32.  MFMA t = (slab s, quad
+// pair qq, e) contracts channel 16 s + 4 qq + e (lanes 0..31) and 16 s + 8 + 4 qq + e (lanes 32..63): any pairing
+// works as long as A and B agree, and this one keeps both operands 16-byte loads in the existing layouts.  The two K
+// halves are summed through LDS (half 0 + half 1).
+template <bool FUSE>
+__attribute__((amdgpu_waves_per_eu(3)))      // (unconstrained the fused instantiation takes 184 VGPRs: two workgroups per CU)
+__global__ __launch_bounds__(256) void dcn32x_kernel(DcnGroup g)
+{
+    typedef float f32x16 __attribute__((ext_vector_type(16)));
+    constexpr int BM = 32, NKK = 4;
+    constexpr int SLAB = BM * 16;
+    constexpr int BUF = NKK * SLAB;
+    extern __shared__ __attribute__((aligned(16))) float dlds[];
+    float *om_lds = dlds;
+    float *lds_a = dlds + (FUSE ? BM * 32 : 0);
+    int *tab_off = reinterpret_cast<int *>(lds_a + 2 * BUF);
+    float *tab_w = lds_a + 2 * BUF + BM * 9 * 4;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave & 1, wk = wave >> 1;                     // n-tile of 32 couts, K half of a step
+
+    int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < DCN_MAX_GROUP; ++i)
+        if (i < g.n && bid >= g.first[i]) pi = i;
+    const DcnArgs &a = g.p[pi];
+    bid -= g.first[pi];
+    const int split = bid / a.tiles;
+    bid -= split * a.tiles;
+    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    const int tx = bid % a.tilesX; bid /= a.tilesX;
+    const int ty = bid % a.tilesY; bid /= a.tilesY;
+    const int n = bid;
+    const int oy0 = ty * 2, ox0 = tx * 16;
+    const int nunits = a.nchunks >> 1;
+    const int c_begin = split * (a.chunksPerSplit >> 1);
+    const int c_end = min(nunits, c_begin + (a.chunksPerSplit >> 1));
+
+    const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
+    const bool fuse = FUSE && a.w_off != nullptr;
+    const bool parts = a.omSplits > 0;
+    const float *omn = (fuse || parts) ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
+
+    if (fuse) {
+        // (the offset / mask conv stage of dcn_mfma_kernel, unchanged: 16 x 16 x 4 K-split tile)
+        auto fin = [&](int mt, int nt, f32x4 sum) {
+            const int co = nt * 16 + (lane & 15);
+            const float b = (co < 27) ? a.b_off[co] : 0.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v = sum[e] + b;
+                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
+                om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
+            }
+        };
+        ksplit_conv_tile<3, 1, 2, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
+        __syncthreads();
+    }
+
+    // ---- B fragments from the 16 x 16 x 4 packing: lane (j = lane & 31, kh = lane >> 5) takes, per slab and quad pair
+    //      qq, the float4 of cout j, channels 16 s + 8 kh + 4 qq .. + 3:  ((tap * C16 + slab) * NT + nt16) * 256 +
+    //      (2 kh + qq) * 64 + (j & 15) * 4 ----
+    const int j = lane & 31, kh = lane >> 5;
+    const int NCH16 = a.Cin >> 4;
+    const int nt16 = cb * 4 + wn * 2 + (j >> 4);
+    const float *bbase = a.wp + ((size_t)nt16 << 8) + kh * 128 + ((j & 15) << 2);
+    const size_t slab_stride = (size_t)a.NT << 8;
+    auto load_b = [&](f32x4 (&b)[2][2], int chunk, int tap) {
+#pragma unroll
+        for (int sl = 0; sl < 2; ++sl) {
+            const float *bp = bbase + ((size_t)tap * NCH16 + (size_t)chunk * NKK + 2 * wk + sl) * slab_stride;
+            b[sl][0] = *reinterpret_cast<const f32x4 *>(bp);
+            b[sl][1] = *reinterpret_cast<const f32x4 *>(bp + 64);
+        }
+    };
+    const int nsteps = (c_end - c_begin) * 9;
+    auto step_ct = [&](int st, int &chunk, int &tap) {
+        const int u = min(max(st, 0), max(nsteps - 1, 0));
+        const int c = u / 9;
+        chunk = min(c_begin + c, nunits - 1);
+        tap = u - c * 9;
+    };
+    f32x4 bq[2][2][2];
+    {
+        int ch, tp;
+        step_ct(0, ch, tp);
+        load_b(bq[0], ch, tp);
+    }
+
+    dcn_build_table<BM>(a, n, oy0, ox0, fuse, parts, om_lds, omn, tab_off, tab_w);
+    __syncthreads();
+
+    // ---- gather: the assignment of dcn_mfma_kernel<32, ., ., 4> (pixel tid >> 3, quad tid & 3, slabs (tid >> 2) & 1, + 2) ----
+    const int gm = tid >> 3, gq = tid & 3, gk0 = (tid >> 2) & 1;
+    const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);
+    f32x4 cv[2][2][4];
+    f32x4 gw[2];
+    auto gather_load = [&](int slot, int chunk, int tap) {
+        const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
+        gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
+        const float *base = xin + chunk * (16 * NKK) + gk0 * 16 + gq * 4;
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) {
+            cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * 32);
+            cv[slot][kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * 32);
+            cv[slot][kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * 32);
+            cv[slot][kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * 32);
+        }
+    };
+    auto blend = [&](int slot, int kk) {
+        return gw[slot][0] * cv[slot][kk][0] + gw[slot][1] * cv[slot][kk][1] + gw[slot][2] * cv[slot][kk][2] +
+               gw[slot][3] * cv[slot][kk][3];
+    };
+    // A fragments: lane (pixel i = lane & 31, kh): quads 2 kh, 2 kh + 1 of the wave's two slabs
+    const int ai = lane & 31;
+    int aoff[2];
+#pragma unroll
+    for (int qq = 0; qq < 2; ++qq) aoff[qq] = ai * 16 + (((2 * kh + qq) ^ ((ai >> 1) & 2)) << 2);
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
+
+    if (nsteps > 0) {
+        int ch, tp;
+        step_ct(0, ch, tp);
+        gather_load(0, ch, tp);
+        step_ct(1, ch, tp);
+        gather_load(1, ch, tp);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk) *reinterpret_cast<f32x4 *>(lds_a + (gk0 + kk * 2) * SLAB + lslot) = blend(0, kk);
+#if defined(CT_DCN_DEEP)
+        step_ct(2, ch, tp);
+        gather_load(0, ch, tp);
+#endif
+        __syncthreads();
+        auto step = [&](auto ptag, int s) {
+            constexpr int P = decltype(ptag)::value;
+            int c1, t1, c2, t2;
+            step_ct(s + 1, c1, t1);
+#if defined(CT_DCN_DEEP)
+            step_ct(s + 3, c2, t2);
+#else
+            step_ct(s + 2, c2, t2);
+#endif
+            f32x4 af[2][2];
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+                    af[sl][qq] = *reinterpret_cast<const f32x4 *>(lds_a + P * BUF + (2 * wk + sl) * SLAB + aoff[qq]);
+            load_b(bq[P ^ 1], c1, t1);
+#if !defined(CT_DCN_DEEP)
+            gather_load(P, c2, t2);
+#endif
+            f32x4 v[2];
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk) v[kk] = blend(P ^ 1, kk);
+#if defined(CT_DCN_DEEP)
+            gather_load(P ^ 1, c2, t2);
+#endif
+            __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+            for (int sl = 0; sl < 2; ++sl)
+#pragma unroll
+                for (int qq = 0; qq < 2; ++qq)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl][qq][e], bq[P][sl][qq][e], acc, 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+                *reinterpret_cast<f32x4 *>(lds_a + (P ^ 1) * BUF + (gk0 + kk * 2) * SLAB + lslot) = v[kk];
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        int s = 0;
+        for (; s + 1 < nsteps; s += 2) {
+            step(std::integral_constant<int, 0>{}, s);
+            step(std::integral_constant<int, 1>{}, s + 1);
+        }
+        if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
+    }
+
+    // ---- K half 1 hands its tile to K half 0 through LDS (16 floats per lane, per n-tile) ----
+    float *red = lds_a + wn * 1024;
+    if (wk == 1) {
+#pragma unroll
+        for (int r4 = 0; r4 < 4; ++r4)
+            *reinterpret_cast<f32x4 *>(red + (r4 * 64 + lane) * 4) = f32x4{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
+    }
+    __syncthreads();
+    if (wk == 1) return;
+#pragma unroll
+    for (int r4 = 0; r4 < 4; ++r4) {
+        const f32x4 o = *reinterpret_cast<const f32x4 *>(red + (r4 * 64 + lane) * 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[4 * r4 + e] += o[e];
+    }
+    // C/D of the 32 x 32 tile: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5) = pixel m of the tile,
+    // column l & 31 = cout
+    const int co = (cb * 2 + wn) * 32 + j;
+    if (a.ws) {
+        float *wsp = a.ws + (size_t)split * ((size_t)a.N * a.H * a.W) * a.wsCout;
+        if (co < a.wsCout) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+                if (oy < a.H && ox < a.W) wsp[(((size_t)n * a.H + oy) * a.W + ox) * a.wsCout + co] = acc[r];
+            }
+        }
+    } else if (co < a.epi.Cout) {
+        const EpiArgs &e = a.epi;
+        const float sc = e.scale ? e.scale[co] : 1.0f;
+        const float sh = e.shift ? e.shift[co] : 0.0f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+            if (oy < a.H && ox < a.W) e.y[(((size_t)n * e.Ho + oy) * e.Wo + ox) * e.ldy + co] = ct_epilogue_value(e, acc[r], co, sc, sh, 0.0f);
+        }
+    }
+}
+
 // Measured and dropped in round 2 (tools/kbench.py, profiles/r02_kbench_dcn_*.txt; every variant was parity-green):
 //   * 8 waves per workgroup, two K groups in phase (same steps, summed through LDS) and in ANTI-phase (one group's
 //     MFMAs beside the other's gather / blend / weight loads per barrier interval): 64->64 @128x128 x 8 streams 142-144
@@ -733,6 +967,7 @@ extern "C" size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d)
 namespace {
 
 struct DcnPlan {
+    int m32;                         // contraction on 32 x 32 x 2 MFMA tiles (algo 53264, dcn32x_kernel)
     int fuse;
     int parts;                       // offset/mask conv K-split into Cin / 64 partial maps (fuse_offset == 2)
     int BM, BN, NKK, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
@@ -778,8 +1013,14 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     // 32-pixel tile stepping through 64 channels (32 * WN MFMAs per barrier); 41664 = 16-pixel tile x 64 couts, 64-channel
     // steps, K split over the waves (dcn16_kernel)
     int algo = d->algo;
-    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128 && algo != 41664)
+    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128 && algo != 41664 &&
+        algo != 53264)
         CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
+    p->m32 = 0;
+    if (algo == 53264) {         // the 43264 tile and steps, contraction on v_mfma_f32_32x32x2_f32
+        if (d->Cin % 64 || d->Cout % 64) CT_FAIL_ARG("ct_dcn_v2: the 32x32x2 shape needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)", d->Cin, d->Cout);
+        p->m32 = 1; p->NKK = 4; algo = 3264;
+    }
     if (algo == 41664) {
         if (d->Cin % 64 || d->Cout % 64) CT_FAIL_ARG("ct_dcn_v2: the 16-pixel shape needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)", d->Cin, d->Cout);
         p->BM = 16; p->BN = 64; p->NKK = 4;
@@ -990,7 +1231,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         if (rc != CT_OK) return rc;
         // (one MAIN launch = one kernel instantiation; the OFFSETS / FINISH launches do not depend on the tile shape, so
         //  layers whose MAIN launches differ -- e.g. in channels per step -- may share them)
-        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK))
+        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK || p.m32 != plans[0].m32))
             CT_FAIL_ARG("ct_dcn_v2_group: layer %d resolves to another tile shape than layer 0", i);
         const size_t need = ws_bytes(d, p);
         if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
@@ -1064,6 +1305,10 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         const size_t lds = lds_bytes16(fuse_any, single_chunk);
         if (fuse_any) hipLaunchKernelGGL((dcn16_kernel<true>), grid, dim3(256), lds, s, g);
         else hipLaunchKernelGGL((dcn16_kernel<false>), grid, dim3(256), lds, s, g);
+    } else if (p0.m32) {
+        const size_t lds = lds_bytes(32, fuse_any, single_chunk, 4);
+        if (fuse_any) hipLaunchKernelGGL((dcn32x_kernel<true>), grid, dim3(256), lds, s, g);
+        else hipLaunchKernelGGL((dcn32x_kernel<false>), grid, dim3(256), lds, s, g);
     } else if (p0.NKK == 4) {
         if (p0.BM != 32) CT_FAIL_ARG("ct_dcn_v2: the 64-channel-step shapes run on 32-pixel tiles");
         const size_t lds = lds_bytes(32, fuse_any, single_chunk, 4);

@@ -28,6 +28,8 @@ FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-
 DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
 # (A/B switch, DESIGN.md section 8: MAIN launches with fewer 32-pixel workgroups than this run on 16-pixel tiles, algo 41664)
 DCN_TILE16 = int(os.environ.get('CENTERTRACK_DCN_TILE16', '0'))
+# (A/B switch, DESIGN.md section 8: MAIN launches on v_mfma_f32_32x32x2_f32 tiles, algo 53264, where the shape takes the layers)
+DCN_M32 = os.environ.get('CENTERTRACK_DCN_M32', '0') == '1'
 
 
 def _fold_bn(sd, p):
@@ -615,6 +617,8 @@ class DLASegHIP(torch.nn.Module):
                     arr[j].algo = 43264 if ly.nkk == 4 else 3264
                     if DCN_TILE64 and not any(l2.fused for l2 in part):      # (experiment: 64-pixel tiles, un-fused slots)
                         arr[j].algo = 64
+                    if phases == _lib.CT_DCN_MAIN and DCN_M32 and DLASegHIP._tile16(part, N, below=1 << 60):
+                        arr[j].algo = 53264       # (same admissible layers as the 16-pixel shape: 64-channel steps, whole cout blocks)
                     if phases == _lib.CT_DCN_MAIN and DLASegHIP._tile16(part, N):
                         arr[j].algo = 41664
                     keep.append(ly.desc[1])

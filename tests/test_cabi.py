@@ -163,6 +163,11 @@ def test_group_plan_query_reports_errors_instead_of_zero(lib):
     d.Cout, d.ldy = 96, 96
     assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == _lib.CT_ERR_ARG
     assert b'16-pixel' in l.ct_last_error()
+    d.Cout, d.ldy, d.algo, d.split_k = 64, 64, 53264, 4         # 32x32x2 MFMA shape: the split rule of the 64-channel steps
+    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), ctypes.byref(splits)) == 0
+    assert splits.value == 4 and need.value == 4 * 8 * 8 * 64 * 4
+    d.Cout, d.ldy = 80, 80
+    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == _lib.CT_ERR_ARG and b'32x32x2' in l.ct_last_error()
     d.Cout, d.ldy, d.algo, d.split_k = 64, 64, 3264, 1
     d.Cin = 48                                                 # rejected: the size query says 0, the plan query says why
     assert l.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d)) == 0

@@ -152,3 +152,113 @@ def test_emulated_16_pixel_workgroups_equal_the_oracle(H, W, Cin, Cout, splits, 
                     if tx * 16 + m < W:
                         got[0, cb * 64:(cb + 1) * 64, ty, tx * 16 + m] = tile[m]
     np.testing.assert_allclose(got, want, atol=2e-5, rtol=2e-5)
+
+
+# ---- dcn32x_kernel (algo 53264): 32 pixels x 64 couts, contraction on v_mfma_f32_32x32x2_f32 ----------------------------
+
+def mfma_32x32x2(a_lane, b_lane, acc):
+    """v_mfma_f32_32x32x2_f32: lane l supplies A[i = l & 31][k = l >> 5] and B[k = l >> 5][j = l & 31]; register r of lane
+    l holds D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5)][l & 31]   (guide: cdna_hip_programming.md, fragment layouts)"""
+    A = a_lane.reshape(2, 32).T                # [i][k]
+    B = b_lane.reshape(2, 32)                  # [k][j]
+    D = A.astype(np.float32) @ B.astype(np.float32)
+    for l in range(64):
+        for r in range(16):
+            acc[l, r] += D[(r & 3) + 8 * (r >> 2) + 4 * (l >> 5), l & 31]
+
+
+def build_table32(om, n, oy0, ox0, H, W, ldx):
+    """dcn_build_table<32>: pixel m of the tile is (row m >> 4, column m & 15)"""
+    off = np.zeros((32 * 9, 4), np.int64)
+    wgt = np.zeros((32 * 9, 4), np.float32)
+    for row in range(2):
+        if oy0 + row < H:
+            o, w = build_table(om, n, oy0 + row, ox0, H, W, ldx)
+            off[row * 144:(row + 1) * 144], wgt[row * 144:(row + 1) * 144] = o, w
+    return off, wgt
+
+
+def workgroup32x(x_nhwc, om, wp, NT, N, H, W, Cin, n, ty, tx, cb, split, chunks_per_split):
+    BM32, SLAB32 = 32, 32 * 16
+    BUF32 = 4 * SLAB32
+    ldx = Cin
+    oy0, ox0 = ty * 2, tx * 16
+    nunits = (Cin // 32) >> 1
+    c_begin = split * (chunks_per_split >> 1)
+    c_end = min(nunits, c_begin + (chunks_per_split >> 1))
+    xin = x_nhwc[n].reshape(-1)
+    tab_off, tab_w = build_table32(om, n, oy0, ox0, H, W, ldx)
+    NCH16 = Cin >> 4
+    slab_stride = NT << 8
+    acc = np.zeros((4, 64, 16), np.float32)             # [wave][lane][r]
+    lds = np.zeros(2 * BUF32, np.float32)
+    for s in range((c_end - c_begin) * 9):
+        chunk, tap = c_begin + s // 9, s % 9
+        buf = s & 1
+        for tid in range(256):
+            gm, gq, gk0 = tid >> 3, tid & 3, (tid >> 2) & 1
+            lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2)
+            base = chunk * 64 + gk0 * 16 + gq * 4
+            for kk in range(2):
+                v = np.zeros(4, np.float32)
+                for c in range(4):
+                    o = base + tab_off[gm * 9 + tap, c] + kk * 32
+                    v = v + tab_w[gm * 9 + tap, c] * xin[o:o + 4]
+                d = buf * BUF32 + (gk0 + kk * 2) * SLAB32 + lslot
+                lds[d:d + 4] = v
+        for wave in range(4):
+            wn, wk = wave & 1, wave >> 1
+            af = np.zeros((2, 2, 64, 4), np.float32)
+            bq = np.zeros((2, 2, 64, 4), np.float32)
+            for lane in range(64):
+                j, kh = lane & 31, lane >> 5
+                nt16 = cb * 4 + wn * 2 + (j >> 4)
+                bbase = (nt16 << 8) + kh * 128 + ((j & 15) << 2)
+                for sl in range(2):
+                    bp = bbase + (tap * NCH16 + chunk * 4 + 2 * wk + sl) * slab_stride
+                    bq[sl, 0, lane] = wp[bp:bp + 4]
+                    bq[sl, 1, lane] = wp[bp + 64:bp + 68]
+                    for qq in range(2):
+                        aoff = j * 16 + (((2 * kh + qq) ^ ((j >> 1) & 2)) << 2)
+                        a0 = buf * BUF32 + (2 * wk + sl) * SLAB32 + aoff
+                        af[sl, qq, lane] = lds[a0:a0 + 4]
+            for sl in range(2):
+                for qq in range(2):
+                    for e in range(4):
+                        mfma_32x32x2(af[sl, qq, :, e], bq[sl, qq, :, e], acc[wave])
+    tile = np.zeros((32, 64), np.float32)
+    for wn in range(2):
+        sm = acc[wn] + acc[2 + wn]                      # K half 0 + K half 1
+        for lane in range(64):
+            for r in range(16):
+                m = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+                tile[m, wn * 32 + (lane & 31)] = sm[lane, r]
+    return tile
+
+
+@pytest.mark.parametrize('H,W,Cin,Cout,splits,osc', [(3, 20, 64, 64, 1, 1.5), (4, 16, 128, 128, 2, 0.7)])
+def test_emulated_32x32x2_workgroups_equal_the_oracle(H, W, Cin, Cout, splits, osc):
+    from oracle import dcn_v2 as odcn
+    g = torch.Generator().manual_seed(6)
+    x = torch.randn(1, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * (Cin * 9) ** -0.5
+    off = torch.randn(1, 18, H, W, generator=g) * osc
+    mask = torch.sigmoid(torch.randn(1, 9, H, W, generator=g))
+    want = odcn.dcn_v2_conv(x, off, mask, w, None).numpy()
+    om = np.zeros((1, H, W, 32), np.float32)
+    om[..., :18] = off.permute(0, 2, 3, 1).numpy()
+    om[..., 18:27] = mask.permute(0, 2, 3, 1).numpy()
+    x_nhwc = np.ascontiguousarray(x.permute(0, 2, 3, 1).numpy())
+    wp, NT = pack_weight(w.numpy())
+    nunits = Cin // 64
+    cps = -(-nunits // splits) * 2
+    got = np.zeros((1, Cout, H, W), np.float32)
+    for ty in range((H + 1) // 2):
+        for tx in range((W + 15) // 16):
+            for cb in range(Cout // 64):
+                tile = sum(workgroup32x(x_nhwc, om, wp, NT, 1, H, W, Cin, 0, ty, tx, cb, sp, cps) for sp in range(splits))
+                for m in range(32):
+                    oy, ox = ty * 2 + (m >> 4), tx * 16 + (m & 15)
+                    if oy < H and ox < W:
+                        got[0, cb * 64:(cb + 1) * 64, oy, ox] = tile[m]
+    np.testing.assert_allclose(got, want, atol=2e-5, rtol=2e-5)

@@ -3,7 +3,9 @@ CENTERTRACK_EXPERIMENTAL=1 -- the first GPU call of the next round runs them; a 
 moves into tests/test_hip_ops.py and the tuner's candidate list.
 
   * algo 41664: DCNv2 on 16-pixel x 64-cout tiles, K split over the waves (`dcn16_kernel`, csrc/dcn_mfma.hip)
-  * CENTERTRACK_DCN_TILE16: the frame plan with its small MAIN launches on that shape"""
+  * CENTERTRACK_DCN_TILE16: the frame plan with its small MAIN launches on that shape
+  * algo 53264: the 32-pixel / 64-channel-step shape with the contraction on v_mfma_f32_32x32x2_f32 (`dcn32x_kernel`),
+    CENTERTRACK_DCN_M32 in the frame plan"""
 import ctypes
 import os
 
@@ -27,7 +29,8 @@ def device():
 @pytest.mark.parametrize('N,H,W,Cin,Cout,osc,split_k', [(1, 8, 16, 64, 64, 0.5, 1), (2, 7, 19, 128, 64, 3.0, 1),
                                                         (1, 6, 16, 256, 256, 1.0, 2), (1, 4, 4, 512, 256, 1.0, 0),
                                                         (1, 5, 33, 128, 128, 1.0, 2)])
-def test_dcn16_matches_oracle(device, N, H, W, Cin, Cout, osc, split_k):
+@pytest.mark.parametrize('algo', [41664, 53264])
+def test_dcn16_matches_oracle(device, N, H, W, Cin, Cout, osc, split_k, algo):
     """offset/mask map read from HBM; ragged widths, out-of-range taps, several cout blocks, split-K"""
     from centertrack_amd import ops
     from oracle import dcn_v2 as odcn
@@ -42,14 +45,15 @@ def test_dcn16_matches_oracle(device, N, H, W, Cin, Cout, osc, split_k):
     om[..., :18] = off.permute(0, 2, 3, 1)
     om[..., 18:27] = mask.permute(0, 2, 3, 1)
     out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), ops.View(om.to(device), 0, 27), ops.pack_weight(w.to(device)),
-                     Cout, scale.to(device), shift.to(device), relu=True, split_k=split_k, algo=41664)
-    _close(out.to_nchw(), y, msg='dcn16')
+                     Cout, scale.to(device), shift.to(device), relu=True, split_k=split_k, algo=algo)
+    _close(out.to_nchw(), y, msg='dcn %d' % algo)
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,split_k,split_offsets', [(1, 12, 20, 64, 64, 1, False), (2, 9, 21, 128, 64, 2, False),
                                                                   (1, 8, 8, 256, 256, 4, False), (2, 9, 21, 128, 64, 2, True),
                                                                   (1, 7, 33, 256, 128, 1, True)])
-def test_dcn16_with_its_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, split_k, split_offsets):
+@pytest.mark.parametrize('algo', [41664, 53264])
+def test_dcn16_with_its_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, split_k, split_offsets, algo):
     """conv_offset_mask inside the launch (one-row K-split tile) or K-split by the OFFSETS launch == upstream DCN.forward;
     and the sampling points are those of the 32-pixel shape: outputs agree to summation order"""
     from centertrack_amd import ops
@@ -61,10 +65,10 @@ def test_dcn16_with_its_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, sp
     kw = dict(shift=b.to(device), split_k=split_k, w_off=ops.pack_weight(wo.to(device)), b_off=bo.to(device),
               split_offsets=split_offsets)
     xv, wp = ops.view_from_nchw(x.to(device)), ops.pack_weight(w.to(device))
-    out = ops.dcn_v2(xv, None, wp, Cout, algo=41664, **kw)
-    _close(out.to_nchw(), y, msg='DCN module on 16-pixel tiles')
+    out = ops.dcn_v2(xv, None, wp, Cout, algo=algo, **kw)
+    _close(out.to_nchw(), y, msg='DCN module, algo %d' % algo)
     ref = ops.dcn_v2(xv, None, wp, Cout, algo=43264, **kw)
-    _close(out.to_nchw(), ref.to_nchw().cpu(), atol=2e-5, rtol=2e-5, msg='16- vs 32-pixel tiles')
+    _close(out.to_nchw(), ref.to_nchw().cpu(), atol=2e-5, rtol=2e-5, msg='algo %d vs 43264' % algo)
 
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,algo', [(2, 9, 21, 128, 64, 43264), (1, 7, 33, 256, 128, 41664)])
@@ -89,8 +93,9 @@ def test_offsets_launch_on_one_row_tiles_is_bit_identical(device, N, H, W, Cin, 
     assert torch.equal(got, base)
 
 
+@pytest.mark.parametrize('xalgo', [41664, 53264])
 @pytest.mark.parametrize('f,split_k', [(2, 2), (4, 1)])
-def test_dcn16_group_with_idaup_step(device, f, split_k):
+def test_dcn16_group_with_idaup_step(device, f, split_k, xalgo):
     """two layers in one MAIN launch on 16-pixel tiles + one FINISH launch (split-K reduction, BN, ReLU, IDAUp step) ==
     the same group on 32-pixel tiles to summation order, == oracle"""
     from centertrack_amd import _lib, ops
@@ -98,7 +103,7 @@ def test_dcn16_group_with_idaup_step(device, f, split_k):
     lib = _lib.load()
     outs = {}
     want = []
-    for galgo in (41664, 43264):
+    for galgo in (xalgo, 43264):
         descs, keep, res = [], [], []
         for i, (N, H, W, Cin, Cout, ff, sk, fuse) in enumerate([(1, 6, 10, 128, 64, f, split_k, True),
                                                                  (2, 5, 17, 256, 128, 0, 2, False)]):
@@ -112,15 +117,15 @@ def test_dcn16_group_with_idaup_step(device, f, split_k):
             om = None if fuse else ops.conv2d(xv, wop, 27, 3, 1, shift=bo_d, sig=(18, 27), out=ops.new_view(N, H, W, 32, device))
             out = ops.new_view(N, H, W, Cout, device)
             up = None
-            if galgo == 41664:
+            if galgo == xalgo:
                 y = F.relu(odcn.dcn_forward(x, w, None, wo, bo) * scale.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
             if ff:
                 wup, skip = _rand(Cout, 1, 2 * ff, 2 * ff, seed=120 + i), _rand(N, Cout, H * ff, W * ff, seed=130 + i)
-                if galgo == 41664:
+                if galgo == xalgo:
                     y = F.conv_transpose2d(y, wup, None, stride=ff, padding=ff // 2, groups=Cout) + skip
                 up = (ops.upsample_weight(wup.to(device)), ff, ops.view_from_nchw(skip.to(device)),
                       ops.new_view(N, H * ff, W * ff, Cout, device))
-            if galgo == 41664:
+            if galgo == xalgo:
                 want.append(y)
             d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sk, algo=galgo, up=up,
                                   **(dict(w_off=wop, b_off=bo_d) if fuse else {}))
@@ -136,19 +141,20 @@ def test_dcn16_group_with_idaup_step(device, f, split_k):
         _lib.check(lib.ct_dcn_v2_group(arr, 2, _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'finish')
         torch.cuda.synchronize()
         outs[galgo] = [r.to_nchw().cpu() for r in res]
-    for got, ref, y in zip(outs[41664], outs[43264], want):
+    for got, ref, y in zip(outs[xalgo], outs[43264], want):
         _close(got, y, msg='16-pixel group vs oracle')
         _close(got, ref, atol=2e-5, rtol=2e-5, msg='16- vs 32-pixel group')
 
 
-def test_frame_plan_on_16_pixel_tiles_matches_the_oracle(device, monkeypatch):
+@pytest.mark.parametrize('switch,value,code', [('DCN_TILE16', 600, '41664'), ('DCN_M32', True, '53264')])
+def test_frame_plan_on_16_pixel_tiles_matches_the_oracle(device, monkeypatch, switch, value, code):
     """the headline configuration, one stream, with every MAIN launch below 600 workgroups on 16-pixel tiles: three frames
     through the whole path (forward, decode, association) against the CPU oracle at the full-size bar, and the plan
     really uses the shape"""
     from _parity import run_config
     from centertrack_amd import model as M
-    monkeypatch.setattr(M, 'DCN_TILE16', 600)
+    monkeypatch.setattr(M, switch, value)
     checks, swaps, det = run_config('mot17_512', 1, 3, on_threshold_tie='stop')
     sigs = [M.DLASegHIP.plan_signature(p) for p in det.model._plans.values()]
-    assert sigs and all('41664' in g for g in sigs)
+    assert sigs and all(code in g for g in sigs)
     assert checks[0].frames >= 2

@@ -2,6 +2,7 @@
 # First GPU call of round 4: the experiments prepared (blind) at the end of round 3, as A/B pairs inside ONE call.
 #   0. parity of the 16-pixel DCN shape (algo 41664) -- tests/test_hip_experimental.py; its lines below count only if green
 #   1. base | CENTERTRACK_DCN_TILE16=600 (MAIN launches below 600 workgroups on 16-pixel tiles) | =1100 (all of them)
+#      | CENTERTRACK_DCN_M32=1 (MAIN launches on 32 x 32 x 2 MFMA tiles)
 #   2. variant builds (bit-identical kernels, other resource use / staging order):
 #        w4      -DCT_DCN_WAVES=4     DCN kernels capped at 128 VGPRs (148 -> 128, no spills): 4 workgroups per CU
 #        deep    -DCT_DCN_DEEP        two steps of gather flight on the same two register slots
@@ -40,6 +41,7 @@ line() {  # tag, then env assignments
 line base A=0
 line tile16_600 CENTERTRACK_DCN_TILE16=600
 line tile16_all CENTERTRACK_DCN_TILE16=1100
+line m32 CENTERTRACK_DCN_M32=1                              # MAIN launches on v_mfma_f32_32x32x2_f32 tiles (algo 53264)
 for v in w4 deep stemw4 stemco all; do
     if [ -f $V/libcentertrack_hip_$v.so ]; then
         line base A=0
@@ -63,6 +65,8 @@ for B in 8; do
         CENTERTRACK_DCN_TILE16=$v python bench.py --streams $B --steps 10 --warmup 3 --no-cpu-baseline 2>> $OUT/err.log | tail -1 | \
             python -c "import json,sys; j=json.loads(sys.stdin.read()); print(json.dumps(dict(tag='b$B tile16=$v', fps=j['value'], ms=j['ms_per_step'])))" | tee -a $OUT/ab.jsonl
     done
+    CENTERTRACK_DCN_M32=1 python bench.py --streams $B --steps 10 --warmup 3 --no-cpu-baseline 2>> $OUT/err.log | tail -1 | \
+        python -c "import json,sys; j=json.loads(sys.stdin.read()); print(json.dumps(dict(tag='b$B m32', fps=j['value'], ms=j['ms_per_step'])))" | tee -a $OUT/ab.jsonl
     if [ -f $V/libcentertrack_hip_w4.so ]; then
         CENTERTRACK_LIB=$V/libcentertrack_hip_w4.so python bench.py --streams $B --steps 10 --warmup 3 --no-cpu-baseline 2>> $OUT/err.log | tail -1 | \
             python -c "import json,sys; j=json.loads(sys.stdin.read()); print(json.dumps(dict(tag='b$B w4', fps=j['value'], ms=j['ms_per_step'])))" | tee -a $OUT/ab.jsonl
