@@ -41,7 +41,9 @@ int ct_version(void);
  * "conv_small_tiles" (below this many workgroups pick the smaller tile), "splitk_target"
  * (workgroups aimed at when splitting K), "dcn_bn" (0 auto, 64, 128), "conv_ks" (-1 auto, -2 never,
  * 0..4 force a K-split-in-workgroup tile), "conv_ks_below" / "conv_ks_waves" (K-split kernel is
- * used below this many 64x64 tiles / sized to reach this many waves). */
+ * used below this many 64x64 tiles / sized to reach this many waves), "xcd_remap" (0/1 XCD-aware workgroup order of
+ * the wide layers), "heads_order" (1 = head-major workgroup order of ct_heads_fused), "dcn_offs16" (1 = the
+ * CT_DCN_OFFSETS launch on one-row tiles; experimental). */
 int ct_set_tuning(const char *key, int value);
 
 /* ---- weight packing ---------------------------------------------------------------
@@ -137,7 +139,10 @@ typedef struct ct_dcn_desc {
     int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
                                                    workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts;
                                                    43264 / 432128 = the same stepping through 64 instead of 32
-                                                   channels per barrier (Cin % 64 == 0) */
+                                                   channels per barrier (Cin % 64 == 0); experimental, selected by no
+                                                   plan (Cin % 64 == 0 and Cout % 64 == 0): 41664 = 16-pixel tile x 64
+                                                   couts, K split over the waves; 53264 = the 43264 tile contracted on
+                                                   v_mfma_f32_32x32x2_f32 */
     int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
                                                    unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile.
