@@ -526,6 +526,10 @@ class DLASegHIP(torch.nn.Module):
         split_offsets = knobs[3] if len(knobs) > 3 else 1
         cps_small = knobs[4] if len(knobs) > 4 else 0
         small_unfuse = knobs[5] if len(knobs) > 5 else 0      # small slots: offset convs out of the MAIN launch too
+        # experimental tile shapes of the MAIN launches: knobs[6] = workgroup threshold below which a
+        # launch runs on 16-pixel tiles, knobs[7] = 1: 32 x 32 x 2 MFMA tiles elsewhere; absent -> the A/B environment switches
+        tile16_below = knobs[6] if len(knobs) > 6 else DCN_TILE16
+        m32 = bool(knobs[7]) if len(knobs) > 7 else DCN_M32
         slot_cps = {}
         sizes, mains = self._dcn_slot_sizes(layers, produced0, N, cps, with_mains=True)
         if cps_small and cps_small < cps:
@@ -617,9 +621,9 @@ class DLASegHIP(torch.nn.Module):
                     arr[j].algo = 43264 if ly.nkk == 4 else 3264
                     if DCN_TILE64 and not any(l2.fused for l2 in part):      # (experiment: 64-pixel tiles, un-fused slots)
                         arr[j].algo = 64
-                    if phases == _lib.CT_DCN_MAIN and DCN_M32 and DLASegHIP._tile16(part, N, below=1 << 60):
+                    if phases == _lib.CT_DCN_MAIN and m32 and DLASegHIP._tile16(part, N, below=1 << 60):
                         arr[j].algo = 53264       # (same admissible layers as the 16-pixel shape: 64-channel steps, whole cout blocks)
-                    if phases == _lib.CT_DCN_MAIN and DLASegHIP._tile16(part, N):
+                    if phases == _lib.CT_DCN_MAIN and DLASegHIP._tile16(part, N, below=tile16_below):
                         arr[j].algo = 41664
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
