@@ -91,12 +91,7 @@ extern "C" int ct_dcn_clear_stamps(void)
 #define CT_STAMP_VAL(i, v)
 #endif
 
-// (variant build -DCT_DCN_WAVES=4, tools/build_variant.py: at 148 VGPRs three workgroups share a CU, 768 on the chip, and
-//  the second MAIN launch of the one-stream plan has 1024 -- a full round and a third of one)
 template <int BM, int WN, bool FUSE, int NKK = 2>
-#if defined(CT_DCN_WAVES)
-__attribute__((amdgpu_waves_per_eu(CT_DCN_WAVES)))
-#endif
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 {
     CT_STAMP_RT(0);
@@ -331,10 +326,6 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         step_ct(1, ch, tp);
         gather_load(1, ch, tp);
         gather_store(0, 0);
-#if defined(CT_DCN_DEEP)      // (variant build: the slot tile 0 frees takes tile 2 at once, see the step below)
-        step_ct(2, ch, tp);
-        gather_load(0, ch, tp);
-#endif
         __syncthreads();
         CT_STAMP(4);
         // one step (P = s & 1 is static, two steps per loop iteration): A fragments of step s (LDS -> VGPR, all of them
@@ -351,10 +342,8 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                 for (int mt = 0; mt < WM; ++mt)
                     af[kk][mt] = *reinterpret_cast<const f32x4 *>(lds_g + P * BUF + kk * SLAB + aoff[mt]);
             load_b(bq[P ^ 1], c1, t1);
-#if !defined(CT_DCN_DEEP)
             // slot P held step s, already blended into LDS buffer P by the previous iteration
             gather_load(P, c2, t2);
-#endif
             // step s+1's A tile (corners loaded one step ago); past the last step this blends the clamped re-fetch
             // into a buffer nobody reads
             f32x4 v[GK];
@@ -362,21 +351,9 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
             for (int kk = 0; kk < GK; ++kk)
                 v[kk] = gw[P ^ 1][0] * cv[P ^ 1][kk][0] + gw[P ^ 1][1] * cv[P ^ 1][kk][1] +
                         gw[P ^ 1][2] * cv[P ^ 1][kk][2] + gw[P ^ 1][3] * cv[P ^ 1][kk][3];
-#if defined(CT_DCN_DEEP)
-            // (variant build, tools/build_variant.py: blend s+1 FIRST, then issue the corners of s+3 into the slot that
-            //  frees -- slot P keeps s+2 in flight: the same two register slots, two steps of flight instead of one)
-            {
-                int c3, t3;
-                step_ct(s + 3, c3, t3);
-                gather_load(P ^ 1, c3, t3);
-            }
-#endif
             // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
             // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
-#if defined(CT_DCN_PRIO)      // (variant build, tools/build_variant.py: the MFMA block of a wave issues ahead of other waves' work)
-            __builtin_amdgcn_s_setprio(CT_DCN_PRIO);
-#endif
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
@@ -387,9 +364,6 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                         for (int nt = 0; nt < WN; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][mt][e], bq[P][kk][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
-#if defined(CT_DCN_PRIO)
-            __builtin_amdgcn_s_setprio(0);
-#endif
             __builtin_amdgcn_sched_barrier(0x386);
 #pragma unroll
             for (int kk = 0; kk < GK; ++kk)
@@ -440,505 +414,6 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     CT_STAMP_RT(7);
 }
 
-// ---- 16-pixel tiles (algo 41664; written at the end of round 3 WITHOUT a GPU at hand: not selected by any pinned plan,
-// `CENTERTRACK_DCN_TILE16` in model.py is the A/B switch, tests/test_hip_ops.py covers it under CENTERTRACK_EXPERIMENTAL=1)
-// Why: at one stream a MAIN launch of the IDAUp tree is 256 .. 512 workgroups of 32 pixels on 256 CUs -- one or two waves
-// per SIMD, all of them in the same phase (offset conv, table, gather loop) at the same time, so nothing hides a global
-// round trip.  Splitting K finer doubles the workgroups but repeats the fused offset conv and adds partials (round 3,
-// experiment 1: -13 % on the MAIN launch, +0 overall).  Halving the PIXEL tile doubles the workgroups without either:
-// one row of 16 pixels x 64 couts, the four waves split K (wave w contracts the w-th 16-channel slab of every 64-channel
-// step for all 4 n-tiles: 16 MFMAs on 4 independent accumulators per barrier, A fragments read once instead of once per
-// cout group), partial tiles summed through LDS in wave order.  One float4 x 4 corners per thread and step.
-// Gather ring: the tile of step s+1 is blended BEFORE the corners of s+3 are issued into the slot it frees, so two tiles
-// are in flight for two steps on the two register slots the 32-pixel kernel keeps in flight for one.
-template <int BM>
-__device__ __forceinline__ void dcn_build_table(const DcnArgs &a, int n, int oy0, int ox0, bool fuse, bool parts,
-                                                const float *om_lds, const float *omn, int *tab_off, float *tab_w)
-{
-    // (same expressions, in the same order, as the table stage of dcn_mfma_kernel: the two kernels sample the same points)
-    constexpr int NTHR = 256;
-    constexpr int TI = (BM * 9 + NTHR - 1) / NTHR;
-    const int tid = threadIdx.x;
-    float tdy[TI], tdx[TI], tmk[TI];
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int it = tid + NTHR * i;
-        const int m = it / 9, k = it - m * 9;
-        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-        const bool in = it < BM * 9 && oy < a.H && ox < a.W;
-        if (parts) {
-            const size_t plane = (size_t)a.N * a.H * a.W * 32;
-            const float *pp = a.omPart + (in ? (((size_t)n * a.H + oy) * a.W + ox) * 32 : 0);
-            const int kk = in ? k : 0;
-            float dy = pp[2 * kk], dx = pp[2 * kk + 1], mk = pp[18 + kk];
-            for (int sp = 1; sp < a.omSplits; ++sp) {
-                dy += pp[sp * plane + 2 * kk];
-                dx += pp[sp * plane + 2 * kk + 1];
-                mk += pp[sp * plane + 18 + kk];
-            }
-            tdy[i] = dy + a.b_off[2 * kk];
-            tdx[i] = dx + a.b_off[2 * kk + 1];
-            tmk[i] = 1.0f / (1.0f + expf(-(mk + a.b_off[18 + kk])));
-            continue;
-        }
-        const float *omp = fuse ? om_lds + (in ? m * 32 : 0) : omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
-        tdy[i] = omp[in ? 2 * k : 0];
-        tdx[i] = omp[in ? 2 * k + 1 : 0];
-        tmk[i] = omp[in ? 18 + k : 0];
-    }
-#pragma unroll
-    for (int i = 0; i < TI; ++i) {
-        const int it = tid + NTHR * i;
-        if (it >= BM * 9) continue;
-        const int m = it / 9, k = it - m * 9;
-        const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-        int o[4] = {0, 0, 0, 0};
-        float wgt[4] = {0.f, 0.f, 0.f, 0.f};
-        if (oy < a.H && ox < a.W) {
-            const float dy = tdy[i], dx = tdx[i], mk = tmk[i];
-            const float ys = (float)(oy - 1 + k / 3) + dy;
-            const float xs = (float)(ox - 1 + k % 3) + dx;
-            if (ys > -1.0f && xs > -1.0f && ys < (float)a.H && xs < (float)a.W) {
-                const float yf = floorf(ys), xf = floorf(xs);
-                const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
-                const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
-                const bool vy0 = y0 >= 0, vy1 = y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
-                if (vy0 && vx0) { o[0] = (y0 * a.W + x0) * a.ldx; wgt[0] = hy * hx * mk; }
-                if (vy0 && vx1) { o[1] = (y0 * a.W + x1) * a.ldx; wgt[1] = hy * lx * mk; }
-                if (vy1 && vx0) { o[2] = (y1 * a.W + x0) * a.ldx; wgt[2] = ly * hx * mk; }
-                if (vy1 && vx1) { o[3] = (y1 * a.W + x1) * a.ldx; wgt[3] = ly * lx * mk; }
-            }
-        }
-        *reinterpret_cast<int4 *>(tab_off + it * 4) = make_int4(o[0], o[1], o[2], o[3]);
-        *reinterpret_cast<f32x4 *>(tab_w + it * 4) = f32x4{wgt[0], wgt[1], wgt[2], wgt[3]};
-    }
-}
-
-template <bool FUSE>
-__global__ __launch_bounds__(256) void dcn16_kernel(DcnGroup g)
-{
-    constexpr int BM = 16, NKK = 4, WN = 4;
-    constexpr int SLAB = BM * 16;            // floats: 16 pixels x 16 channels
-    constexpr int BUF = NKK * SLAB;          // one A tile: 16 pixels x 64 channels
-    // dynamic LDS: [ om tile float[16*32] (FUSE) ] | A tile double buffer | table offsets int4[16*9] | table weights
-    // float4[16*9]; the offset-conv scratch and the cross-wave reduction (4 waves x 4 tiles x 256 floats) alias
-    // everything after the om tile
-    extern __shared__ __attribute__((aligned(16))) float dlds[];
-    float *om_lds = dlds;
-    float *lds_a = dlds + (FUSE ? BM * 32 : 0);
-    int *tab_off = reinterpret_cast<int *>(lds_a + 2 * BUF);
-    float *tab_w = lds_a + 2 * BUF + BM * 9 * 4;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = K slab inside a step (uniform: SGPR)
-
-    int bid = blockIdx.x;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < DCN_MAX_GROUP; ++i)
-        if (i < g.n && bid >= g.first[i]) pi = i;
-    const DcnArgs &a = g.p[pi];
-    bid -= g.first[pi];
-    const int split = bid / a.tiles;
-    bid -= split * a.tiles;
-    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
-    const int tx = bid % a.tilesX; bid /= a.tilesX;
-    const int ty = bid % a.tilesY; bid /= a.tilesY;
-    const int n = bid;
-    const int oy0 = ty, ox0 = tx * 16;
-    const int nunits = a.nchunks >> 1;                           // units of 64 channels
-    const int c_begin = split * (a.chunksPerSplit >> 1);
-    const int c_end = min(nunits, c_begin + (a.chunksPerSplit >> 1));
-
-    const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
-    if (FUSE && a.offsOnly) {
-        // CT_DCN_OFFSETS on one-row tiles (knob `dcn_offs16`): chunk `split` (64 input channels) of the offset/mask conv
-        // of this row of 16 pixels, raw -- the sums of the 32-pixel launch, pixel by pixel, from twice the workgroups
-        float *part = a.omPart + ((size_t)split * a.N + n) * a.H * a.W * 32;
-        auto fin = [&](int, int nt, f32x4 sum) {
-            const int co = nt * 16 + (lane & 15);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ox = ox0 + (lane >> 4) * 4 + e;
-                if (ox < a.W) part[((size_t)oy0 * a.W + ox) * 32 + co] = sum[e];
-            }
-        };
-        ksplit_conv_tile<3, 1, 1, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, split, split + 1, lds_a, fin);
-        return;
-    }
-    const bool fuse = FUSE && a.w_off != nullptr;                // (uniform)
-    const bool parts = a.omSplits > 0;                           // (uniform)
-    const float *omn = (fuse || parts) ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
-
-    if (fuse) {
-        // offset / mask conv of this row of 16 pixels (the K-split tile of ksplit_core.h with ONE m-tile: every pixel's
-        // sums are formed in the order the 32-pixel kernel forms them)
-        auto fin = [&](int, int nt, f32x4 sum) {
-            const int co = nt * 16 + (lane & 15);
-            const float b = (co < 27) ? a.b_off[co] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = sum[e] + b;
-                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
-                om_lds[((lane >> 4) * 4 + e) * 32 + co] = v;
-            }
-        };
-        ksplit_conv_tile<3, 1, 1, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
-        __syncthreads();
-    }
-
-    // ---- B fragments: this wave's 16-channel slab of a (64-channel unit, tap) step, the 4 n-tiles of the cout block
-    //      (the host admits Cout % 64 == 0 only: one base address, the n-tiles at immediate offsets) ----
-    const int li = lane & 15, lg = lane >> 4;
-    const int nt0 = cb * WN;
-    const int NCH16 = a.Cin >> 4;
-    const float *bbase = a.wp + ((size_t)nt0 << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;
-    auto load_b = [&](f32x4 (&b)[WN], int chunk, int tap) {
-        const float *bp = bbase + ((size_t)tap * NCH16 + (size_t)chunk * NKK + wave) * slab_stride;
-#pragma unroll
-        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bp + (nt << 8));
-    };
-    const int nsteps = (c_end - c_begin) * 9;
-    auto step_ct = [&](int st, int &chunk, int &tap) {
-        const int u = min(max(st, 0), max(nsteps - 1, 0));
-        const int c = u / 9;
-        chunk = min(c_begin + c, nunits - 1);
-        tap = u - c * 9;
-    };
-    f32x4 bq[2][WN];
-    {
-        int ch, tp;
-        step_ct(0, ch, tp);
-        load_b(bq[0], ch, tp);
-    }
-
-    dcn_build_table<BM>(a, n, oy0, ox0, fuse, parts, om_lds, omn, tab_off, tab_w);
-    __syncthreads();
-
-    // ---- gather assignment: thread -> (pixel tid >> 4, slab (tid >> 2) & 3, channel quad tid & 3): 16 consecutive
-    //      lanes read the 256 contiguous bytes of one corner of one pixel ----
-    const int gm = tid >> 4, gk = (tid >> 2) & 3, gq = tid & 3;
-    const int lslot = gk * SLAB + gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);
-    f32x4 cv[2][4];
-    f32x4 gw[2];
-    auto gather_load = [&](int slot, int chunk, int tap) {
-        const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
-        gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
-        const float *base = xin + chunk * (16 * NKK) + gk * 16 + gq * 4;
-        cv[slot][0] = *reinterpret_cast<const f32x4 *>(base + o.x);
-        cv[slot][1] = *reinterpret_cast<const f32x4 *>(base + o.y);
-        cv[slot][2] = *reinterpret_cast<const f32x4 *>(base + o.z);
-        cv[slot][3] = *reinterpret_cast<const f32x4 *>(base + o.w);
-    };
-    auto blend = [&](int slot) {
-        return gw[slot][0] * cv[slot][0] + gw[slot][1] * cv[slot][1] + gw[slot][2] * cv[slot][2] + gw[slot][3] * cv[slot][3];
-    };
-    const int aoff = wave * SLAB + li * 16 + ((lg ^ ((li >> 1) & 2)) << 2);
-
-    f32x4 acc[WN];
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt) acc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-    if (nsteps > 0) {
-        int ch, tp;
-        step_ct(0, ch, tp);
-        gather_load(0, ch, tp);
-        step_ct(1, ch, tp);
-        gather_load(1, ch, tp);
-        *reinterpret_cast<f32x4 *>(lds_a + lslot) = blend(0);
-        step_ct(2, ch, tp);
-        gather_load(0, ch, tp);
-        __syncthreads();
-        // one step (P = s & 1 static): A fragment of step s | weights of s+1 | blend of s+1's corners (in flight since
-        // step s-2), corners of s+3 into the slot that frees | MFMAs of s | LDS store of s+1's tile | barrier
-        auto step = [&](auto ptag, int s) {
-            constexpr int P = decltype(ptag)::value;
-            int c1, t1, c3, t3;
-            step_ct(s + 1, c1, t1);
-            step_ct(s + 3, c3, t3);
-            const f32x4 af = *reinterpret_cast<const f32x4 *>(lds_a + P * BUF + aoff);
-            load_b(bq[P ^ 1], c1, t1);
-            const f32x4 v = blend(P ^ 1);
-            gather_load(P ^ 1, c3, t3);
-            __builtin_amdgcn_sched_barrier(0x386);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-#pragma unroll
-                for (int nt = 0; nt < WN; ++nt)
-                    acc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[P][nt][e], acc[nt], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0x386);
-            *reinterpret_cast<f32x4 *>(lds_a + (P ^ 1) * BUF + lslot) = v;
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        int s = 0;
-        for (; s + 1 < nsteps; s += 2) {
-            step(std::integral_constant<int, 0>{}, s);
-            step(std::integral_constant<int, 1>{}, s + 1);
-        }
-        if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
-    }
-
-    // ---- the four K partials of every n-tile, summed in wave order; wave w finishes n-tile w ----
-    float *red = lds_a;
-#pragma unroll
-    for (int nt = 0; nt < WN; ++nt)
-        *reinterpret_cast<f32x4 *>(red + ((wave * WN + nt) * 64 + lane) * 4) = acc[nt];
-    __syncthreads();
-    f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (wave * 64 + lane) * 4);
-#pragma unroll
-    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * WN + wave) * 64 + lane) * 4);
-    if (a.ws) {
-        float *wsp = a.ws + (size_t)split * ((size_t)a.N * a.H * a.W) * a.wsCout;
-        const int co = (nt0 + wave) * 16 + li;
-        if (oy0 < a.H && co < a.wsCout) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int ox = ox0 + lg * 4 + e;
-                if (ox < a.W) wsp[(((size_t)n * a.H + oy0) * a.W + ox) * a.wsCout + co] = sum[e];
-            }
-        }
-    } else {
-        ct_store_tile(a.epi, sum, n, oy0, ox0, (nt0 + wave) * 16, lane);
-    }
-}
-
-// ---- 32 x 32 x 2 MFMA tiles (algo 53264; VERDICT r2 item 2 (ii), written at the end of round 3 without a GPU at hand:
-// `CENTERTRACK_DCN_M32` in model.py is the A/B switch, tests/test_hip_experimental.py covers it, no pinned plan selects it)
-// Same workgroup tile as the 64-channel-step shape (32 pixels = 2 rows x 16, 64 couts, 64 channels per step), same
-// gather, same table; the contraction runs on `v_mfma_f32_32x32x2_f32`: the four waves are 2 n-tiles of 32 couts x 2
-// K halves (slabs {0,1} / {2,3} of a step), every wave owns ONE 32 x 32 accumulator.  Per step and wave: 16 MFMAs of 64
-// cycles (the matrix time of today's 32 MFMAs of 32 cycles), but 4 `ds_read_b128` of A fragments instead of 8 -- half the LDS
-// fragment traffic per flop -- and 16 accumulator + 16 fragment registers instead of 8 + 32.  MFMA t = (slab s, quad
-// pair qq, e) contracts channel 16 s + 4 qq + e (lanes 0..31) and 16 s + 8 + 4 qq + e (lanes 32..63): any pairing
-// works as long as A and B agree, and this one keeps both operands 16-byte loads in the existing layouts.  The two K
-// halves are summed through LDS (half 0 + half 1).
-template <bool FUSE>
-__attribute__((amdgpu_waves_per_eu(3)))      // (unconstrained the fused instantiation takes 184 VGPRs: two workgroups per CU)
-__global__ __launch_bounds__(256) void dcn32x_kernel(DcnGroup g)
-{
-    typedef float f32x16 __attribute__((ext_vector_type(16)));
-    constexpr int BM = 32, NKK = 4;
-    constexpr int SLAB = BM * 16;
-    constexpr int BUF = NKK * SLAB;
-    extern __shared__ __attribute__((aligned(16))) float dlds[];
-    float *om_lds = dlds;
-    float *lds_a = dlds + (FUSE ? BM * 32 : 0);
-    int *tab_off = reinterpret_cast<int *>(lds_a + 2 * BUF);
-    float *tab_w = lds_a + 2 * BUF + BM * 9 * 4;
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wn = wave & 1, wk = wave >> 1;                     // n-tile of 32 couts, K half of a step
-
-    int bid = blockIdx.x;
-    int pi = 0;
-#pragma unroll
-    for (int i = 1; i < DCN_MAX_GROUP; ++i)
-        if (i < g.n && bid >= g.first[i]) pi = i;
-    const DcnArgs &a = g.p[pi];
-    bid -= g.first[pi];
-    const int split = bid / a.tiles;
-    bid -= split * a.tiles;
-    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
-    const int tx = bid % a.tilesX; bid /= a.tilesX;
-    const int ty = bid % a.tilesY; bid /= a.tilesY;
-    const int n = bid;
-    const int oy0 = ty * 2, ox0 = tx * 16;
-    const int nunits = a.nchunks >> 1;
-    const int c_begin = split * (a.chunksPerSplit >> 1);
-    const int c_end = min(nunits, c_begin + (a.chunksPerSplit >> 1));
-
-    const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
-    const bool fuse = FUSE && a.w_off != nullptr;
-    const bool parts = a.omSplits > 0;
-    const float *omn = (fuse || parts) ? nullptr : a.om + (size_t)n * a.H * a.W * a.ldom;
-
-    if (fuse) {
-        // (the offset / mask conv stage of dcn_mfma_kernel, unchanged: 16 x 16 x 4 K-split tile)
-        auto fin = [&](int mt, int nt, f32x4 sum) {
-            const int co = nt * 16 + (lane & 15);
-            const float b = (co < 27) ? a.b_off[co] : 0.0f;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                float v = sum[e] + b;
-                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
-                om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
-            }
-        };
-        ksplit_conv_tile<3, 1, 2, 2, 4, CT_OFF_PD>(xin, a.H, a.W, a.ldx, a.Cin, a.w_off, 2, 0, oy0, ox0, 0, a.Cin >> 6, lds_a, fin);
-        __syncthreads();
-    }
-
-    // ---- B fragments from the 16 x 16 x 4 packing: lane (j = lane & 31, kh = lane >> 5) takes, per slab and quad pair
-    //      qq, the float4 of cout j, channels 16 s + 8 kh + 4 qq .. + 3:  ((tap * C16 + slab) * NT + nt16) * 256 +
-    //      (2 kh + qq) * 64 + (j & 15) * 4 ----
-    const int j = lane & 31, kh = lane >> 5;
-    const int NCH16 = a.Cin >> 4;
-    const int nt16 = cb * 4 + wn * 2 + (j >> 4);
-    const float *bbase = a.wp + ((size_t)nt16 << 8) + kh * 128 + ((j & 15) << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;
-    auto load_b = [&](f32x4 (&b)[2][2], int chunk, int tap) {
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const float *bp = bbase + ((size_t)tap * NCH16 + (size_t)chunk * NKK + 2 * wk + sl) * slab_stride;
-            b[sl][0] = *reinterpret_cast<const f32x4 *>(bp);
-            b[sl][1] = *reinterpret_cast<const f32x4 *>(bp + 64);
-        }
-    };
-    const int nsteps = (c_end - c_begin) * 9;
-    auto step_ct = [&](int st, int &chunk, int &tap) {
-        const int u = min(max(st, 0), max(nsteps - 1, 0));
-        const int c = u / 9;
-        chunk = min(c_begin + c, nunits - 1);
-        tap = u - c * 9;
-    };
-    f32x4 bq[2][2][2];
-    {
-        int ch, tp;
-        step_ct(0, ch, tp);
-        load_b(bq[0], ch, tp);
-    }
-
-    dcn_build_table<BM>(a, n, oy0, ox0, fuse, parts, om_lds, omn, tab_off, tab_w);
-    __syncthreads();
-
-    // ---- gather: the assignment of dcn_mfma_kernel<32, ., ., 4> (pixel tid >> 3, quad tid & 3, slabs (tid >> 2) & 1, + 2) ----
-    const int gm = tid >> 3, gq = tid & 3, gk0 = (tid >> 2) & 1;
-    const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);
-    f32x4 cv[2][2][4];
-    f32x4 gw[2];
-    auto gather_load = [&](int slot, int chunk, int tap) {
-        const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
-        gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
-        const float *base = xin + chunk * (16 * NKK) + gk0 * 16 + gq * 4;
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-            cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * 32);
-            cv[slot][kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * 32);
-            cv[slot][kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * 32);
-            cv[slot][kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * 32);
-        }
-    };
-    auto blend = [&](int slot, int kk) {
-        return gw[slot][0] * cv[slot][kk][0] + gw[slot][1] * cv[slot][kk][1] + gw[slot][2] * cv[slot][kk][2] +
-               gw[slot][3] * cv[slot][kk][3];
-    };
-    // A fragments: lane (pixel i = lane & 31, kh): quads 2 kh, 2 kh + 1 of the wave's two slabs
-    const int ai = lane & 31;
-    int aoff[2];
-#pragma unroll
-    for (int qq = 0; qq < 2; ++qq) aoff[qq] = ai * 16 + (((2 * kh + qq) ^ ((ai >> 1) & 2)) << 2);
-
-    f32x16 acc;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) acc[r] = 0.0f;
-
-    if (nsteps > 0) {
-        int ch, tp;
-        step_ct(0, ch, tp);
-        gather_load(0, ch, tp);
-        step_ct(1, ch, tp);
-        gather_load(1, ch, tp);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) *reinterpret_cast<f32x4 *>(lds_a + (gk0 + kk * 2) * SLAB + lslot) = blend(0, kk);
-#if defined(CT_DCN_DEEP)
-        step_ct(2, ch, tp);
-        gather_load(0, ch, tp);
-#endif
-        __syncthreads();
-        auto step = [&](auto ptag, int s) {
-            constexpr int P = decltype(ptag)::value;
-            int c1, t1, c2, t2;
-            step_ct(s + 1, c1, t1);
-#if defined(CT_DCN_DEEP)
-            step_ct(s + 3, c2, t2);
-#else
-            step_ct(s + 2, c2, t2);
-#endif
-            f32x4 af[2][2];
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-                    af[sl][qq] = *reinterpret_cast<const f32x4 *>(lds_a + P * BUF + (2 * wk + sl) * SLAB + aoff[qq]);
-            load_b(bq[P ^ 1], c1, t1);
-#if !defined(CT_DCN_DEEP)
-            gather_load(P, c2, t2);
-#endif
-            f32x4 v[2];
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk) v[kk] = blend(P ^ 1, kk);
-#if defined(CT_DCN_DEEP)
-            gather_load(P ^ 1, c2, t2);
-#endif
-            __builtin_amdgcn_sched_barrier(0x386);
-#pragma unroll
-            for (int sl = 0; sl < 2; ++sl)
-#pragma unroll
-                for (int qq = 0; qq < 2; ++qq)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(af[sl][qq][e], bq[P][sl][qq][e], acc, 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0x386);
-#pragma unroll
-            for (int kk = 0; kk < 2; ++kk)
-                *reinterpret_cast<f32x4 *>(lds_a + (P ^ 1) * BUF + (gk0 + kk * 2) * SLAB + lslot) = v[kk];
-            __syncthreads();
-            __builtin_amdgcn_sched_barrier(0);
-        };
-        int s = 0;
-        for (; s + 1 < nsteps; s += 2) {
-            step(std::integral_constant<int, 0>{}, s);
-            step(std::integral_constant<int, 1>{}, s + 1);
-        }
-        if (s < nsteps) step(std::integral_constant<int, 0>{}, s);
-    }
-
-    // ---- K half 1 hands its tile to K half 0 through LDS (16 floats per lane, per n-tile) ----
-    float *red = lds_a + wn * 1024;
-    if (wk == 1) {
-#pragma unroll
-        for (int r4 = 0; r4 < 4; ++r4)
-            *reinterpret_cast<f32x4 *>(red + (r4 * 64 + lane) * 4) = f32x4{acc[4 * r4], acc[4 * r4 + 1], acc[4 * r4 + 2], acc[4 * r4 + 3]};
-    }
-    __syncthreads();
-    if (wk == 1) return;
-#pragma unroll
-    for (int r4 = 0; r4 < 4; ++r4) {
-        const f32x4 o = *reinterpret_cast<const f32x4 *>(red + (r4 * 64 + lane) * 4);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) acc[4 * r4 + e] += o[e];
-    }
-    // C/D of the 32 x 32 tile: register r of lane l holds row (r & 3) + 8 (r >> 2) + 4 (l >> 5) = pixel m of the tile,
-    // column l & 31 = cout
-    const int co = (cb * 2 + wn) * 32 + j;
-    if (a.ws) {
-        float *wsp = a.ws + (size_t)split * ((size_t)a.N * a.H * a.W) * a.wsCout;
-        if (co < a.wsCout) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-                if (oy < a.H && ox < a.W) wsp[(((size_t)n * a.H + oy) * a.W + ox) * a.wsCout + co] = acc[r];
-            }
-        }
-    } else if (co < a.epi.Cout) {
-        const EpiArgs &e = a.epi;
-        const float sc = e.scale ? e.scale[co] : 1.0f;
-        const float sh = e.shift ? e.shift[co] : 0.0f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = (r & 3) + 8 * (r >> 2) + 4 * kh;
-            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-            if (oy < a.H && ox < a.W) e.y[(((size_t)n * e.Ho + oy) * e.Wo + ox) * e.ldy + co] = ct_epilogue_value(e, acc[r], co, sc, sh, 0.0f);
-        }
-    }
-}
-
 // Measured and dropped in round 2 (tools/kbench.py, profiles/r02_kbench_dcn_*.txt; every variant was parity-green):
 //   * 8 waves per workgroup, two K groups in phase (same steps, summed through LDS) and in ANTI-phase (one group's
 //     MFMAs beside the other's gather / blend / weight loads per barrier interval): 64->64 @128x128 x 8 streams 142-144
@@ -967,7 +442,6 @@ extern "C" size_t ct_dcn_v2_offsets_bytes(const ct_dcn_desc *d)
 namespace {
 
 struct DcnPlan {
-    int m32;                         // contraction on 32 x 32 x 2 MFMA tiles (algo 53264, dcn32x_kernel)
     int fuse;
     int parts;                       // offset/mask conv K-split into Cin / 64 partial maps (fuse_offset == 2)
     int BM, BN, NKK, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
@@ -1010,32 +484,20 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     p->BN = 64;
     p->NKK = 2;
     // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile; 43264 / 432128 =
-    // 32-pixel tile stepping through 64 channels (32 * WN MFMAs per barrier); 41664 = 16-pixel tile x 64 couts, 64-channel
-    // steps, K split over the waves (dcn16_kernel)
+    // 32-pixel tile stepping through 64 channels (32 * WN MFMAs per barrier)
     int algo = d->algo;
-    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128 && algo != 41664 &&
-        algo != 53264)
+    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128)
         CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
-    p->m32 = 0;
-    if (algo == 53264) {         // the 43264 tile and steps, contraction on v_mfma_f32_32x32x2_f32
-        if (d->Cin % 64 || d->Cout % 64) CT_FAIL_ARG("ct_dcn_v2: the 32x32x2 shape needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)", d->Cin, d->Cout);
-        p->m32 = 1; p->NKK = 4; algo = 3264;
-    }
-    if (algo == 41664) {
-        if (d->Cin % 64 || d->Cout % 64) CT_FAIL_ARG("ct_dcn_v2: the 16-pixel shape needs Cin %% 64 == 0 and Cout %% 64 == 0 (got %d, %d)", d->Cin, d->Cout);
-        p->BM = 16; p->BN = 64; p->NKK = 4;
-    }
     if (algo == 43264) { p->NKK = 4; algo = 3264; }
     else if (algo == 432128) { p->NKK = 4; algo = 32128; }
     if (grouped) {
         // (64-pixel tiles -- half the weight-fragment traffic per flop -- only without a fused offset conv: that stage
         //  works on 32-pixel tiles)
-        if (algo != 0 && algo != 3264 && algo != 32128 && algo != 41664 && !((algo == 64 || algo == 128) && d->fuse_offset != 1))
-            CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128), on 16-pixel tiles (41664), or on 64-pixel tiles (64 / 128) when no offset conv is fused");
+        if (algo != 0 && algo != 3264 && algo != 32128 && !((algo == 64 || algo == 128) && d->fuse_offset != 1))
+            CT_FAIL_ARG("ct_dcn_v2_group: the layers of a group run on 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128), or on 64-pixel tiles (64 / 128) when no offset conv is fused");
         if (algo == 0) algo = 3264;
     }
-    if (algo == 41664) { /* set above */ }
-    else if (algo == 3264) { p->BM = 32; p->BN = 64; }
+    if (algo == 3264) { p->BM = 32; p->BN = 64; }
     else if (algo == 32128) { p->BM = 32; p->BN = 128; }
     else if (algo == 128) p->BN = 128;
     else if (algo == 64) p->BN = 64;
@@ -1044,7 +506,7 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     else if (d->Cout >= 128 && (long)d->N * p->tilesX * ct_cdiv(d->H, 4) * ct_cdiv(d->Cout, 128) >= 512) p->BN = 128;
     if (p->fuse) {
         if (algo == 64 || algo == 128) CT_FAIL_ARG("ct_dcn_v2: fuse_offset runs on the 32-pixel tiles (algo 3264 / 32128 / 43264 / 432128)");
-        if (p->BM != 32 && p->BM != 16) { p->BM = 32; p->BN = 64; }
+        if (p->BM != 32) { p->BM = 32; p->BN = 64; }
     }
     if (p->NKK == 4 && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: the 64-channel-step shapes need Cin %% 64 == 0 (got %d)", d->Cin);
     p->tilesY = ct_cdiv(d->H, p->BM / 16);
@@ -1200,19 +662,6 @@ size_t lds_bytes(int BM, bool fuse_any, bool single_chunk, int NKK = 2)
     return sizeof(float) * (size_t)(BM * 32) + (scratch > regionA ? scratch : regionA);
 }
 
-// ... of the 16-pixel kernel: A double buffer + tables, or the 16 KB of the cross-wave reduction, or the scratch of the
-// one-row offset conv tile, whichever is largest
-size_t lds_bytes16(bool fuse_any, bool single_chunk)
-{
-    using OffCfg = KsCfg<3, 1, 1, 2, 4>;
-    size_t region = sizeof(float) * (size_t)(2 * 4 * 16 * 16 + 2 * 16 * 9 * 4);
-    const size_t red = sizeof(float) * (size_t)(4 * 4 * 256);
-    if (red > region) region = red;
-    if (!fuse_any) return region;
-    const size_t scratch = single_chunk ? sizeof(float) * (size_t)OffCfg::LDS1_FLOATS : OffCfg::LDS_BYTES;
-    return sizeof(float) * (size_t)(16 * 32) + (scratch > region ? scratch : region);
-}
-
 int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void *stream)
 {
     if (!descs || n < 1 || n > DCN_MAX_GROUP) CT_FAIL_ARG("ct_dcn_v2_group: 1..%d layers per launch", DCN_MAX_GROUP);
@@ -1231,7 +680,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         if (rc != CT_OK) return rc;
         // (one MAIN launch = one kernel instantiation; the OFFSETS / FINISH launches do not depend on the tile shape, so
         //  layers whose MAIN launches differ -- e.g. in channels per step -- may share them)
-        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK || p.m32 != plans[0].m32))
+        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK))
             CT_FAIL_ARG("ct_dcn_v2_group: layer %d resolves to another tile shape than layer 0", i);
         const size_t need = ws_bytes(d, p);
         if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
@@ -1272,7 +721,6 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
     hipStream_t s = (hipStream_t)stream;
     if (phases & CT_DCN_OFFSETS) {
         // the K-split offset/mask convs of the layers that asked for them (fuse_offset == 2), all in one launch
-        const bool offs16 = ct_tune_get(CT_TUNE_DCN_OFFS16) != 0;      // (experiment: one-row tiles, dcn16_kernel)
         DcnGroup og;
         og.n = 0;
         long oblocks = 0;
@@ -1281,7 +729,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
             if (d->fuse_offset != 2) continue;            // (3: another launch wrote the raw sums)
             DcnArgs &a = og.p[og.n];
             a = g.p[i];
-            a.tilesX = ct_cdiv(d->W, 16); a.tilesY = offs16 ? d->H : ct_cdiv(d->H, 2); a.coutBlocks = 1;
+            a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 2); a.coutBlocks = 1;
             a.tiles = d->N * a.tilesX * a.tilesY;
             a.w_off = d->w_off_packed;
             a.offsOnly = 1;
@@ -1293,22 +741,13 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
             if (oblocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
             for (int i = og.n; i <= DCN_MAX_GROUP; ++i) og.first[i] = (int)oblocks;
             for (int i = og.n; i < DCN_MAX_GROUP; ++i) og.p[i] = og.p[0];
-            if (offs16) hipLaunchKernelGGL((dcn16_kernel<true>), dim3((unsigned)oblocks), dim3(256), lds_bytes16(true, true), s, og);
-            else hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), dim3((unsigned)oblocks), dim3(256), lds_bytes(32, true, true), s, og);
+            hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), dim3((unsigned)oblocks), dim3(256), lds_bytes(32, true, true), s, og);
             CT_CHECK_LAUNCH("ct_dcn_v2(offset/mask conv)");
         }
     }
     const dim3 grid((unsigned)blocks);
     if (!(phases & CT_DCN_MAIN)) {
         // finish only: the partials were written by an earlier CT_DCN_MAIN call on the same descriptors
-    } else if (p0.BM == 16) {
-        const size_t lds = lds_bytes16(fuse_any, single_chunk);
-        if (fuse_any) hipLaunchKernelGGL((dcn16_kernel<true>), grid, dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((dcn16_kernel<false>), grid, dim3(256), lds, s, g);
-    } else if (p0.m32) {
-        const size_t lds = lds_bytes(32, fuse_any, single_chunk, 4);
-        if (fuse_any) hipLaunchKernelGGL((dcn32x_kernel<true>), grid, dim3(256), lds, s, g);
-        else hipLaunchKernelGGL((dcn32x_kernel<false>), grid, dim3(256), lds, s, g);
     } else if (p0.NKK == 4) {
         if (p0.BM != 32) CT_FAIL_ARG("ct_dcn_v2: the 64-channel-step shapes run on 32-pixel tiles");
         const size_t lds = lds_bytes(32, fuse_any, single_chunk, 4);

@@ -675,7 +675,9 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         __threadfence_system();
         __syncthreads();
         if (threadIdx.x == 0) {
-            const unsigned prev = atomicAdd(a.done_counter, 1u);
+            // acq_rel at system scope: the last arriver ACQUIRES the other workgroups' host_out stores (released by their
+            // own increments) before it releases the flag to the host, which skips the runtime wait once it sees it
+            const unsigned prev = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
             if (prev == (unsigned)a.B - 1u) {
                 *a.done_counter = 0u;
                 __hip_atomic_store(a.done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -111,15 +111,25 @@ struct AssocJob {
     const ct_frame_loop_desc *d;
     const float *rows, *trans_inv;
     int *counts;
+    // ct_last_error() is thread-local: the message of a failure on a helper thread is copied here (first failure wins)
+    std::atomic<int> failed{-1};
+    char err[256] = {0};
 };
 
 bool assoc_one(void *ctx, int b)
 {
-    const AssocJob &j = *(const AssocJob *)ctx;
+    AssocJob &j = *(AssocJob *)ctx;
     const ct_frame_loop_desc &d = *j.d;
     const int n = ct_tracker_step(d.trackers[b], j.rows + (size_t)b * d.K * d.F, d.K, d.F, &d.layout, d.out_thresh,
                                   j.trans_inv + 6 * b, d.results + (size_t)b * d.results_cap, d.results_cap);
     j.counts[b] = n;
+    if (n < 0) {
+        int none = -1;
+        if (j.failed.compare_exchange_strong(none, b)) {
+            strncpy(j.err, ct_last_error(), sizeof(j.err) - 1);
+            j.err[sizeof(j.err) - 1] = 0;
+        }
+    }
     return n >= 0;
 }
 
@@ -265,6 +275,7 @@ extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
         CT_FAIL_ARG("ct_frame_loop_submit: frame_kind %d", a->frame_kind);
     }
     L->uploaded_slot = -1;
+    if (a->frame_kind != CT_FRAME_UPLOADED && L->pre_done_slot == a->slot) L->pre_done_slot = -1;   // (the slot holds another frame now)
     // 3. the frame: its tracker-independent part unless that ran ahead, then one graph launch
     {
         const int rc = prestage(L, a->slot);
@@ -284,7 +295,8 @@ extern "C" int ct_frame_loop_submit(void *loop, const ct_frame_step_args *a)
         const int ns = (a->slot + 1) % d.nslots;
         e = hipMemcpyAsync(d.frames[ns], a->next_frame, d.frame_bytes, hipMemcpyHostToDevice, L->copy_stream);
         if (e == hipSuccess) e = hipEventRecord(L->frame_ready, L->copy_stream);
-        if (e != hipSuccess) return fail("ct_frame_loop_submit(upload of the next frame)", e);
+        // (from here on a failure leaves the frame IN FLIGHT: the caller drains it with ct_frame_loop_wait / _finish)
+        if (e != hipSuccess) return fail("ct_frame_loop_submit(upload of the next frame; the frame itself is in flight)", e);
         L->uploaded_slot = ns;
         if (d.pre.enabled) {
             // ... and its pre-stage right behind this frame's graph: it runs while the host associates this frame
@@ -355,6 +367,7 @@ extern "C" int ct_frame_loop_finish(void *loop, const ct_frame_step_args *a, int
     if (!L || !a || !counts) CT_FAIL_ARG("ct_frame_loop_finish: null argument");
     const ct_frame_loop_desc &d = L->d;
     if (!a->trans_inv) CT_FAIL_ARG("ct_frame_loop_finish: trans_inv missing");
+    if (!L->in_flight) CT_FAIL_ARG("ct_frame_loop_finish: no frame in flight (finish follows submit exactly once)");
     int rc = ct_frame_loop_wait(loop);
     if (rc != CT_OK) return rc;
     const float *rows = d.host_rows;
@@ -364,7 +377,8 @@ extern "C" int ct_frame_loop_finish(void *loop, const ct_frame_step_args *a, int
     }
     // post-process + association of every stream (post_process.py:21-91, detector.py:371-377, tracker.py:28-138);
     // streams are independent: spread over the helper threads when there are many
-    AssocJob job{&d, rows, a->trans_inv, counts};
+    AssocJob job;
+    job.d = &d; job.rows = rows; job.trans_inv = a->trans_inv; job.counts = counts;
     bool ok = true;
     if (L->pool) {
         ok = L->pool->run(d.B, assoc_one, &job);
@@ -372,7 +386,7 @@ extern "C" int ct_frame_loop_finish(void *loop, const ct_frame_step_args *a, int
         for (int b = 0; b < d.B; ++b) ok = assoc_one(&job, b) && ok;
     }
     if (!ok) {
-        ct_set_error("ct_frame_loop_finish: ct_tracker_step failed for a stream");
+        ct_set_error("ct_frame_loop_finish: ct_tracker_step failed for stream %d: %s", job.failed.load(), job.err);
         return CT_ERR_ARG;
     }
     return CT_OK;

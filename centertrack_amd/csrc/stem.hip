@@ -18,16 +18,7 @@ constexpr int ST_PS = ST_PH * ST_PW;                   // floats per plane
 __host__ __device__ constexpr int st_k4(int s) { return s == 2 ? 52 : 148; }   // K padded to 4
 __host__ __device__ constexpr int st_koff(int s) { return s * 148; }            // offsets into the k tables
 constexpr int ST_KTOT = 348;
-// (variant build -DCT_STEM_COALESCED, tools/build_variant.py -- prepared without a GPU at hand, see DESIGN.md section 8:
-//  the weights are OIHW, 147 / 49 contiguous floats per cout; the default staging map puts the 16 couts of one k in
-//  adjacent lanes, i.e. 16 cache lines per 16 lanes and 5568 single-dword requests per workgroup; the variant reads
-//  consecutive k of one cout in adjacent lanes and pads the LDS pitch to 17 so that the transposing store stays
-//  conflict-free.  Same values in LDS, same MFMA order: bit-identical output)
-#if defined(CT_STEM_COALESCED)
-constexpr int ST_WLP = 17;
-#else
 constexpr int ST_WLP = 16;
-#endif
 
 struct StemArgs {
     const float *in[3];   // nullptr = stem not part of this launch
@@ -42,11 +33,6 @@ struct StemArgs {
 // per-thread staging register counts: plane values (3 planes: 3*14*38/256 -> 7) and weights (148*16/256 -> 10)
 constexpr int ST_NPV = 7, ST_NWV = 10;
 
-// (variant build -DCT_STEM_WAVES=4: 140 VGPRs leave three workgroups per CU for a launch of exactly four per CU at
-//  512x512 x 1 stream -- 768 resident + a second round of 256; capped at 128 the launch is one round)
-#if defined(CT_STEM_WAVES)
-__attribute__((amdgpu_waves_per_eu(CT_STEM_WAVES)))
-#endif
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 {
     __shared__ __attribute__((aligned(16))) float planes[7 * ST_PS];
@@ -100,12 +86,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
         for (int i = 0; i < ST_NWV; ++i) {
             const int it = tid + 256 * i;
-#if defined(CT_STEM_COALESCED)
-            const int j = (s == 2) ? it / st_k4(2) : it / st_k4(0);
-            const int k = it - j * st_k4(s);
-#else
             const int k = it >> 4, j = it & 15;
-#endif
             const bool ok = it < nw && k < K;
             const float v = w[ok ? (j * K + k) : 0];
             wv[i] = ok ? v : 0.0f;
@@ -127,13 +108,7 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 #pragma unroll
         for (int i = 0; i < ST_NWV; ++i) {
             const int it = tid + 256 * i;
-#if defined(CT_STEM_COALESCED)
-            const int j = (s == 2) ? it / st_k4(2) : it / st_k4(0);
-            const int k = it - j * st_k4(s);
-            if (it < nw) wl[(st_koff(s) + k) * ST_WLP + j] = wv[i];
-#else
             if (it < nw) wl[st_koff(s) * 16 + it] = wv[i];
-#endif
         }
     };
 

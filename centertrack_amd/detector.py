@@ -462,7 +462,25 @@ class StreamDetector(object):
 
     def _step_native(self, ctx, images, metas, timers, prefetch, prefetch_metas):
         """steady state of the native tracking path: the frame loop of csrc/frame_loop.hip.  With ``prefetch`` AND
-        ``prefetch_metas`` the next frame is launched by the same native call that finishes this one."""
+        ``prefetch_metas`` the next frame is launched by the same native call that finishes this one.
+
+        The loop launches its graphs on the stream that was current when the context was built (``loop_stream``).  A
+        caller that steps under another ``torch.cuda.stream(...)`` is ordered against it explicitly: the loop stream
+        first waits for whatever the caller's stream has enqueued (the producer of a device-resident ``images``), the
+        torch-side work of the step (slot copy, gather hook) is issued on the loop stream, and the caller's stream
+        waits for the loop stream on the way out."""
+        cs = torch.cuda.current_stream()
+        ls = ctx['loop_stream']
+        if cs != ls:
+            ls.wait_stream(cs)
+            try:
+                with torch.cuda.stream(ls):
+                    return self._step_native_on_loop_stream(ctx, images, metas, timers, prefetch, prefetch_metas)
+            finally:
+                cs.wait_stream(ls)
+        return self._step_native_on_loop_stream(ctx, images, metas, timers, prefetch, prefetch_metas)
+
+    def _step_native_on_loop_stream(self, ctx, images, metas, timers, prefetch, prefetch_metas):
         lib = _lib.load()
         t0 = time.time()
         B, n = self.B, ctx['nslots']
@@ -493,6 +511,9 @@ class StreamDetector(object):
                 cur.frame_kind = _lib.CT_FRAME_DEVICE if images.device.type == 'cuda' else _lib.CT_FRAME_HOST
                 cur.frame = images.data_ptr()
             else:
+                if pf is not None:        # a stale prefetch upload may still target this slot: drain it BEFORE the copy
+                    lib.ct_frame_loop_forget_upload(loop)
+                    pf = None
                 ctx['frames'][slot][:B].copy_(images)
                 cur.frame_kind = _lib.CT_FRAME_IN_PLACE
             if pf is not None and cur.frame_kind != _lib.CT_FRAME_UPLOADED:

@@ -26,10 +26,6 @@ WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
 FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-pools as side outputs of the stride-2 convs
 DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
-# (A/B switch, DESIGN.md section 8: MAIN launches with fewer 32-pixel workgroups than this run on 16-pixel tiles, algo 41664)
-DCN_TILE16 = int(os.environ.get('CENTERTRACK_DCN_TILE16', '0'))
-# (A/B switch, DESIGN.md section 8: MAIN launches on v_mfma_f32_32x32x2_f32 tiles, algo 53264, where the shape takes the layers)
-DCN_M32 = os.environ.get('CENTERTRACK_DCN_M32', '0') == '1'
 
 
 def _fold_bn(sd, p):
@@ -526,10 +522,6 @@ class DLASegHIP(torch.nn.Module):
         split_offsets = knobs[3] if len(knobs) > 3 else 1
         cps_small = knobs[4] if len(knobs) > 4 else 0
         small_unfuse = knobs[5] if len(knobs) > 5 else 0      # small slots: offset convs out of the MAIN launch too
-        # experimental tile shapes of the MAIN launches: knobs[6] = workgroup threshold below which a
-        # launch runs on 16-pixel tiles, knobs[7] = 1: 32 x 32 x 2 MFMA tiles elsewhere; absent -> the A/B environment switches
-        tile16_below = knobs[6] if len(knobs) > 6 else DCN_TILE16
-        m32 = bool(knobs[7]) if len(knobs) > 7 else DCN_M32
         slot_cps = {}
         sizes, mains = self._dcn_slot_sizes(layers, produced0, N, cps, with_mains=True)
         if cps_small and cps_small < cps:
@@ -621,10 +613,6 @@ class DLASegHIP(torch.nn.Module):
                     arr[j].algo = 43264 if ly.nkk == 4 else 3264
                     if DCN_TILE64 and not any(l2.fused for l2 in part):      # (experiment: 64-pixel tiles, un-fused slots)
                         arr[j].algo = 64
-                    if phases == _lib.CT_DCN_MAIN and m32 and DLASegHIP._tile16(part, N, below=1 << 60):
-                        arr[j].algo = 53264       # (same admissible layers as the 16-pixel shape: 64-channel steps, whole cout blocks)
-                    if phases == _lib.CT_DCN_MAIN and DLASegHIP._tile16(part, N, below=tile16_below):
-                        arr[j].algo = 41664
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
@@ -639,17 +627,6 @@ class DLASegHIP(torch.nn.Module):
             if slots[t]['finish']:
                 group(slots[t]['finish'], _lib.CT_DCN_FINISH, 'dcn.finish')
         return out
-
-    @staticmethod
-    def _tile16(part, N, below=None):
-        """experiment (CENTERTRACK_DCN_TILE16 = workgroup threshold): does this MAIN launch run on 16-pixel tiles?  Only
-        launches that leave CUs short of waves on 32-pixel tiles, and only shapes the 16-pixel kernel takes"""
-        below = DCN_TILE16 if below is None else below
-        # (nkk == 4: the FINISH launch of a split layer resolves its split count with the 64-channel-step rule, as this shape does)
-        if below <= 0 or any(ly.x.C % 64 or ly.cout % 64 or ly.nkk != 4 for ly in part):
-            return False
-        wgs = sum(N * ((ly.x.H + 1) // 2) * ((ly.x.W + 15) // 16) * ((ly.cout + 63) // 64) * ly.splits for ly in part)
-        return wgs < below
 
     @staticmethod
     def _dcn_slot_sizes(layers, produced0, N, cps, with_mains=False):

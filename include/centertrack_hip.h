@@ -42,8 +42,7 @@ int ct_version(void);
  * (workgroups aimed at when splitting K), "dcn_bn" (0 auto, 64, 128), "conv_ks" (-1 auto, -2 never,
  * 0..4 force a K-split-in-workgroup tile), "conv_ks_below" / "conv_ks_waves" (K-split kernel is
  * used below this many 64x64 tiles / sized to reach this many waves), "xcd_remap" (0/1 XCD-aware workgroup order of
- * the wide layers), "heads_order" (1 = head-major workgroup order of ct_heads_fused), "dcn_offs16" (1 = the
- * CT_DCN_OFFSETS launch on one-row tiles; experimental). */
+ * the wide layers), "heads_order" (1 = head-major workgroup order of ct_heads_fused). */
 int ct_set_tuning(const char *key, int value);
 
 /* ---- weight packing ---------------------------------------------------------------
@@ -139,10 +138,7 @@ typedef struct ct_dcn_desc {
     int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
                                                    workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts;
                                                    43264 / 432128 = the same stepping through 64 instead of 32
-                                                   channels per barrier (Cin % 64 == 0); experimental, selected by no
-                                                   plan (Cin % 64 == 0 and Cout % 64 == 0): 41664 = 16-pixel tile x 64
-                                                   couts, K split over the waves; 53264 = the 43264 tile contracted on
-                                                   v_mfma_f32_32x32x2_f32 */
+                                                   channels per barrier (Cin % 64 == 0) */
     int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
                                                    unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile.
@@ -402,6 +398,10 @@ int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
  *   ct_frame_loop_wait     block until the frame in flight finished (rows are in host_rows);
  *   ct_frame_loop_finish   wait + post-process / association of every stream: counts[b] tracks in
  *                          results[b * results_cap ..] (n > results_cap: grow and read ct_tracker_get_tracks);
+ *                          CT_ERR_ARG when no frame is in flight (a second association of stale rows would age the
+ *                          tracks); a failure on a helper thread is reported with its own message and stream index;
+ *   (a submit that fails AFTER its graph launch -- upload / pre-stage of the next frame -- leaves the frame in
+ *    flight: drain it with ct_frame_loop_wait or _finish before the next submit)
  *   ct_frame_loop_finish_submit   both, back to back (frame t+1 = the frame uploaded ahead);
  *   ct_frame_loop_upload   the upload alone (when the frame in flight was launched by a finish_submit and the caller
  *                          only now learns the frame after it).

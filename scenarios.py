@@ -18,6 +18,9 @@ CONFIGS = OrderedDict([
     ('kitti_1280x384', dict(heads='kitti', H=384, W=1280, B=4, flip=True, track_thresh=0.4, pre_thresh=0.4)),
     ('coco_512', dict(heads='coco', H=512, W=512, B=32, flip=False, track_thresh=0.3, pre_thresh=0.3)),
     ('nusc_800x448', dict(heads='nusc', H=448, W=800, B=16, flip=False, track_thresh=0.1, pre_thresh=0.1)),
+    # not a BASELINE.json line: the reference's own MOT input size (src/lib/dataset/datasets/mot.py:15, the size
+    # `test.py tracking --dataset mot` runs at and readme/MODEL_ZOO.md:16-20 quotes its time on); deep maps 17 x 30
+    ('mot17_544x960', dict(heads='mot', H=544, W=960, B=1, flip=False, track_thresh=0.4, pre_thresh=0.5)),
 ])
 
 

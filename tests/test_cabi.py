@@ -154,20 +154,11 @@ def test_group_plan_query_reports_errors_instead_of_zero(lib):
     assert splits.value == 2 and need.value == 2 * 8 * 8 * 64 * 4 == l.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d))
     d.split_k = 1
     assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == 0 and need.value == 0
-    # the 16-pixel shape (algo 41664) resolves split counts like the 64-channel-step shapes and needs whole 64-cout blocks
-    d.algo, d.split_k = 41664, 2
-    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), ctypes.byref(splits)) == 0
-    assert splits.value == 2 and need.value == 2 * 8 * 8 * 64 * 4
-    d.split_k = 8                                              # 256 channels = 4 units of 64: at most 4 splits
+    # the 64-channel-step shape resolves split counts in units of 64 channels
+    d.algo, d.split_k = 43264, 8                               # 256 channels = 4 units of 64: at most 4 splits
     assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), ctypes.byref(splits)) == 0 and splits.value == 4
-    d.Cout, d.ldy = 96, 96
-    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == _lib.CT_ERR_ARG
-    assert b'16-pixel' in l.ct_last_error()
-    d.Cout, d.ldy, d.algo, d.split_k = 64, 64, 53264, 4         # 32x32x2 MFMA shape: the split rule of the 64-channel steps
-    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), ctypes.byref(splits)) == 0
-    assert splits.value == 4 and need.value == 4 * 8 * 8 * 64 * 4
-    d.Cout, d.ldy = 80, 80
-    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == _lib.CT_ERR_ARG and b'32x32x2' in l.ct_last_error()
+    d.algo = 41664                                             # (an experimental shape of round 3, removed in round 4)
+    assert l.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None) == _lib.CT_ERR_ARG and b'unknown algo' in l.ct_last_error()
     d.Cout, d.ldy, d.algo, d.split_k = 64, 64, 3264, 1
     d.Cin = 48                                                 # rejected: the size query says 0, the plan query says why
     assert l.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d)) == 0

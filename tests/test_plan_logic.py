@@ -74,15 +74,3 @@ def test_plan_signature_pins_algos_splits_and_knobs():
     assert 'level0:conv:203:1' in sig and 'dcn[x]:dcn:1:43264/2/2' in sig and 'dcn_knobs=(128, 4, 4, 1, 0, 0)' in sig
     conv.algo = 204
     assert DLASegHIP.plan_signature(plan) != sig
-
-
-def test_tile16_rule_takes_small_launches_of_whole_blocks_only():
-    """CENTERTRACK_DCN_TILE16 (experiment): a MAIN launch moves to 16-pixel tiles when it has fewer 32-pixel workgroups
-    than the threshold and every layer is a shape the kernel takes (64-channel steps, whole 64-cout blocks)"""
-    def ly(H, C, cout, splits, nkk=4):
-        return types.SimpleNamespace(x=_view(H, H, C), cout=cout, splits=splits, nkk=nkk)
-    slot1 = [ly(16, 512, 256, 4), ly(32, 256, 128, 2), ly(64, 128, 64, 1)]          # 128 + 128 + 128 workgroups
-    assert DLASegHIP._tile16(slot1, 1, below=600) and not DLASegHIP._tile16(slot1, 1, below=384)
-    assert not DLASegHIP._tile16(slot1, 1, below=0) and not DLASegHIP._tile16(slot1, 2, below=600)
-    assert not DLASegHIP._tile16([ly(64, 128, 64, 4, nkk=2)], 1, below=600)          # 32-channel steps
-    assert not DLASegHIP._tile16([ly(64, 96, 64, 1)], 1, below=600) and not DLASegHIP._tile16([ly(64, 128, 96, 1)], 1, below=600)
