@@ -24,12 +24,18 @@ of streams.
 
 Rank 0 prints ONE JSON line with the contract fields plus
   roofline      the DCNv2 kernel (dcn_mfma_kernel): algorithmic flops (2*9*Cin*Cout*h*w per
-                layer, + the fused offset/mask conv's) and algorithmic bytes (4*(Cin*h*w + 27*h*w
-                + Cout*h*w + 9*Cin*Cout + Cout)) of the 16 DCN layers / their summed launch time,
-                measured with HIP events on the launch stream (graph replay of exactly these
+                layer, + the fused offset/mask conv's) and algorithmic bytes (4*(Cin*h*w
+                + 27*h*w + Cout*h*w + 9*Cin*Cout + Cout)) of the 16 DCN layers / their summed launch
+                time, measured with HIP events on the launch stream (graph replay of exactly these
                 launches) in this process; ``frac_main`` = the same with section 8(d)'s formula
                 (main contraction only); traffic = HBM bytes per launch from the committed
-                rocprofv3 PMC passes (profiles/)
+                rocprofv3 PMC passes (profiles/), against 8(d)'s bytes and against 8(d) + the IDAUp
+                step the finishing launches carry; ``mfma_busy`` / ``waves_per_simd_avg`` of the
+                dominant kernel from the committed SQ counter pass (profiles/pmc_mfma_busy.json)
+  roofline_conv the dense conv launches (backbone + heads): ``frac`` = EXECUTED matrix-core flops
+                (Winograd launches count 16/36 of the direct-convolution flops, the fused heads' 1x1
+                layers -- VALU work -- not at all) / time / peak, never above 1; the
+                direct-convolution rate is reported beside it as ``algorithmic_tflops``
   cpu_baseline  the CPU oracle (oracle/, a port of the reference's CPU path) timed on the host
                 cores: thread sweep, then >= 20 frames after 3 warm-ups at the best thread count
                 (reported baseline only)
@@ -118,7 +124,7 @@ def kernel_pass(model, plan, reps=10):
         e1.record()
         torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
-        flops = flops_main = bytes_ = bytes_up = 0.0
+        flops = flops_main = flops_exec = bytes_ = bytes_up = 0.0
         nlayers = 0
         for l in launches:
             if l.fn == 'dcn_group':
@@ -130,7 +136,7 @@ def kernel_pass(model, plan, reps=10):
                     hw = d.N * d.H * d.W
                     flops_main += 2.0 * 9 * d.Cin * d.Cout * hw
                     flops += 2.0 * 9 * d.Cin * d.Cout * hw + 2.0 * 9 * d.Cin * 27 * hw      # main + offset/mask conv
-                    bytes_ += 4.0 * (d.Cin * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout + 9 * d.Cin * 27 + 27)
+                    bytes_ += 4.0 * (d.Cin * hw + 27 * hw + d.Cout * hw + 9 * d.Cin * d.Cout + d.Cout)
                     if d.up_w:          # the IDAUp step the finishing launch of a `proj` layer carries (dla.py:543-545):
                         bytes_up += 4.0 * 2 * d.Cout * hw * d.up_f * d.up_f        # skip tensor read + result written
             elif l.fn == 'heads':        # conv3x3 64 -> 256 + conv1x1 256 -> c of every fused head
@@ -138,19 +144,24 @@ def kernel_pass(model, plan, reps=10):
                 hw = d.N * d.H * d.W
                 cs = sum(d.cout[i] for i in range(d.nheads))
                 flops += 2.0 * hw * (9 * 64 * 256 * d.nheads + 256 * cs)
+                # executed on the matrix cores: the 3x3 layers in Winograd F(2x2,3x3) form (16 multiplies per 36); the
+                # 1x1 output layers are VALU work in the epilogue
+                flops_exec += 2.0 * hw * 9 * 64 * 256 * d.nheads * 16.0 / 36.0
                 bytes_ += 4.0 * (64 * hw + cs * hw + 9 * 64 * 256 * d.nheads)
             elif kind == 'conv':
                 d = l.args
                 pad = d.ks // 2
                 ho = (d.H + 2 * pad - d.ks) // d.stride + 1
                 wo = (d.W + 2 * pad - d.ks) // d.stride + 1
-                flops += 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
+                f = 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
+                flops += f
+                flops_exec += f * (16.0 / 36.0 if 201 <= int(d.algo) <= 211 else 1.0)      # Winograd launches
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)
         if kind == 'dcn':
             stats[kind] = dict(launches=len(launches), layers=nlayers, flops=flops, flops_main=flops_main, bytes=bytes_,
                                bytes_idaup=bytes_up, ms=ms)
             continue
-        stats[kind] = dict(launches=len(launches), flops=flops, flops_main=flops_main, bytes=bytes_, ms=ms)
+        stats[kind] = dict(launches=len(launches), flops=flops, flops_main=flops_main, flops_exec=flops_exec, bytes=bytes_, ms=ms)
     return stats
 
 
@@ -164,6 +175,16 @@ def pmc_traffic():
         return j['dcn_mfma_kernel']['hbm_bytes_per_layer'], j.get('source', p)
     except Exception:
         return None, None
+
+
+def pmc_busy():
+    """MFMA-busy share and resident waves per SIMD per kernel class from the committed SQ counter pass
+    (profiles/pmc_mfma_busy.json, tools/pmc_busy.py); None if absent."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_mfma_busy.json')) as f:
+            return json.load(f)
+    except Exception:
+        return None
 
 
 def profiled_dcn():
@@ -256,6 +277,8 @@ def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
         torch.set_num_threads(saved)
     return dict(value=round(fps, 4), unit='frames/s', cores=best, kind='port', cpu=cpu_model(), host_cpus=ncpu,
                 thread_sweep_fps=per_thread,
+                note='the sweep times %d frames per thread count and only picks `cores`: its figures scatter by +-25 %% between '
+                     'runs on this host (turbo, page cache); `value` is the %d-frame measurement' % (SWEEP_FRAMES, nframes),
                 sample='%d frames of the N=1 workload (1 stream, %dx%d) through oracle/detector.py after 3 warm-up ' % (nframes, cfg['H'], cfg['W']) +
                        'frames at the best thread count of the sweep (1 warm-up + %d timed frames per count); ' % SWEEP_FRAMES +
                        'pure-PyTorch CPU restatement of the reference path incl. DCNv2')
@@ -314,7 +337,7 @@ def main():
     K, F = parallel.build_plans_consistently(lambda: det_rows_shape(det, cfg))
     # every rank must replay the same fp32 summation orders: compare the plans before anything is timed
     plan_hash = parallel.check_same_plan(DLASegHIP.plan_signature(det._ctx['plan']))
-    if world > 1:
+    if world > 1 or parallel.group_active():        # (a torchrun job of one rank still exchanges through RCCL)
         gatherer = parallel.DetectionGatherer(total_streams, world, rank, K, F, device, overlap=True)
         score_col = [st for name, st, _ in det._ctx['decoder'].layout if name == 'scores'][0]
 
@@ -374,6 +397,7 @@ def main():
                    'mean_detections_per_frame': round(ndet / max(1, nfr * B), 1)},
         'fps_per_gpu': round(fps / world, 2), 'ms_per_frame_batch': round(1000.0 * dt / max(1, nfr), 4),
         'timed_region_s': round(dt, 3), 'h2d_in_timed_region': True, 'h2d_overlaps_previous_frame': True, 'rccl_ranks': rccl_ranks,
+        'process_group': (torch.distributed.get_backend() if parallel.group_active() else None),
         'plan_hash': plan_hash,
     }
     if gathered is not None:
@@ -436,19 +460,22 @@ def main():
                                'avg_launch_us': round(1000.0 * d['ms'] / nl, 2),
                                'hbm': {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': round(gbs / PEAK_HBM_GBS, 4),
+                                       # 4 * (Cin*h*w + 27*h*w + Cout*h*w + 9*Cin*Cout + Cout) per layer
                                        'algorithmic_bytes_per_launch': round(d['bytes'] / nl),
                                        # the finishing launches of the 8 `proj` layers also carry the IDAUp step
-                                       # (skip tensor read + result written, dla.py:543-545): what `traffic` has to
-                                       # be read against
+                                       # (skip tensor read + result written, dla.py:543-545)
                                        'algorithmic_bytes_per_launch_with_idaup': round((d['bytes'] + d['bytes_idaup']) / nl)}}
             prof = profiled_dcn()
             if prof is not None and B == 1 and args.config == 'mot17_512' and not args.height and not args.width:
                 out['roofline']['profiled'] = prof
             c = st['conv']
-            ctf = c['flops'] / (c['ms'] * 1e-3) / 1e12
-            out['roofline_conv'] = {'kernel': 'conv_mfma / wino_conv kernels (%d dense conv launches incl. the fused heads)' % c['launches'], 'bound': 'mfma',
+            ctf = c['flops_exec'] / (c['ms'] * 1e-3) / 1e12        # flops the matrix cores EXECUTE (Winograd: 16/36)
+            out['roofline_conv'] = {'kernel': 'conv_mfma / conv_ksplit / wino_conv kernels (%d dense conv launches incl. the fused heads); achieved = '
+                                              'executed matrix-core flops (Winograd launches: 16/36 of the direct-convolution flops; the fused '
+                                              'heads\' 1x1 layers run on the VALU and are not counted)' % c['launches'], 'bound': 'mfma',
                                     'achieved': round(ctf, 3), 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                                    'frac': round(ctf / PEAK_FP32_TFLOPS, 4), 'total_ms': round(c['ms'], 4)}
+                                    'frac': round(ctf / PEAK_FP32_TFLOPS, 4), 'total_ms': round(c['ms'], 4),
+                                    'algorithmic_tflops': round(c['flops'] / (c['ms'] * 1e-3) / 1e12, 3)}
             out['roofline']['total_ms'] = round(d['ms'], 4)
             if B == 1 and args.config == 'mot17_512' and not args.height and not args.width:
                 tb, src = pmc_traffic()            # measured on this workload only
@@ -456,7 +483,21 @@ def main():
                     out['roofline']['traffic'] = round(tb)
                     out['roofline']['traffic_source'] = src
                     out['roofline']['traffic_over_algorithmic'] = round(
+                        tb / out['roofline']['hbm']['algorithmic_bytes_per_launch'], 2)
+                    out['roofline']['traffic_over_algorithmic_with_idaup'] = round(
                         tb / out['roofline']['hbm']['algorithmic_bytes_per_launch_with_idaup'], 2)
+                busy = pmc_busy()                   # measured on this workload only
+                if busy is not None:
+                    if busy.get('dcn_main'):
+                        out['roofline']['mfma_busy'] = busy['dcn_main']['mfma_busy']
+                        out['roofline']['waves_per_simd_avg'] = busy['dcn_main']['waves_per_simd_avg']
+                        out['roofline']['pmc_kernel'] = busy['dcn_main']['kernel']
+                        out['roofline']['pmc_source'] = busy.get('source')
+                    if busy.get('conv'):
+                        out['roofline_conv']['mfma_busy'] = busy['conv']['mfma_busy']
+                        out['roofline_conv']['waves_per_simd_avg'] = busy['conv']['waves_per_simd_avg']
+                        if busy.get('backbone_3x3'):
+                            out['roofline_conv']['mfma_busy_backbone_3x3'] = busy['backbone_3x3']['mfma_busy']
         if args.raw_u8 and world == 1:
             # raw u8 1080p frames handed to step(): u8 H2D + warp / normalise on the device
             det2 = StreamDetector(opt, model=model, num_streams=B, use_graph=not args.no_graph)

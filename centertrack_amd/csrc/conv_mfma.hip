@@ -20,7 +20,10 @@
 //   * split-K over channel chunks (gridDim.y) writes raw partials to a workspace; a
 //     second kernel reduces them in a fixed order (deterministic) and applies the epilogue.
 #include "ct_common.h"
+#define CT_KS_STAMP(i) CT_STAMP(i)
 #include "ksplit_core.h"
+
+CT_DEFINE_STAMPS(conv)      // (tools/conv_phases.py; expands to nothing in the shipped build)
 
 namespace {
 
@@ -94,6 +97,9 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     static_assert(WGM * WGN == 4, "4 waves per workgroup");
     constexpr int PAD = KS / 2;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
+    CT_STAMP_HW(8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -192,8 +198,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         f32x4 breg[RING][WN];
 #pragma unroll
         for (int p = 0; p < RING - 1; ++p) load_b(breg[p], c_begin, p / (KS * KS), p % (KS * KS));   // S >= RING
+        CT_STAMP(2);
         stage_store(0);
         __syncthreads();
+        CT_STAMP(3);
         for (int c = c_begin; c < c_end; ++c) {
             const int cur = (c - c_begin) & 1;
             const int cnext = min(c + 1, c_end - 1);   // clamped: the last chunk re-fetches itself (unused)
@@ -240,6 +248,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         }
     }
 
+    CT_STAMP(4);
+    CT_STAMP(5);
     // ---- epilogue ----------------------------------------------------------------------
     if (a.ws) {
         // raw partial sums: ws[split][n*Ho*Wo + pixel][wsCout]
@@ -268,6 +278,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             for (int nt = 0; nt < WN; ++nt)
                 ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
     }
+    CT_STAMP(6);
+    CT_STAMP_RT(7);
 }
 
 
@@ -278,6 +290,9 @@ template <int KS, int STRIDE, int WM, int WN, int WK, bool POOL = false>
 __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
+    CT_STAMP_HW(8);
     const int lane = threadIdx.x & 63;
     int bid = blockIdx.x;
     const int cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
@@ -317,6 +332,8 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
                 ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane);
             }
         }, hook);
+    CT_STAMP(6);
+    CT_STAMP_RT(7);
 }
 
 // Deterministic split-K reduction + epilogue: one thread per (pixel, 4 couts).

@@ -57,6 +57,39 @@ __device__ __forceinline__ int ct_block_cout(int &bid, int coutBlocks, int per)
 }
 #endif
 
+// ---- per-workgroup phase stamps (debug builds only: -DCT_STAMPS, tools/conv_phases.py / tools/dcn_phases.py; never part
+// of the shipped library).  Every translation unit that stamps owns a buffer [CT_STAMP_BLOCKS][CT_STAMP_WORDS]; thread 0
+// of a workgroup writes s_memtime (CT_STAMP), s_memrealtime (100 MHz: CT_STAMP_RT) or a value (CT_STAMP_VAL) into word i
+// of its row; CT_DEFINE_STAMPS(name) exports ct_<name>_read_stamps / ct_<name>_clear_stamps for the host tool.
+#if defined(CT_STAMPS) && defined(__HIPCC__)
+#define CT_STAMP_WORDS 12
+#define CT_STAMP_BLOCKS 8192
+static __device__ unsigned long long ct_stamps_buf[CT_STAMP_WORDS * CT_STAMP_BLOCKS];
+#define CT_STAMP_AT(i, v) do { if (threadIdx.x == 0 && blockIdx.x < CT_STAMP_BLOCKS && blockIdx.y == 0) ct_stamps_buf[blockIdx.x * CT_STAMP_WORDS + (i)] = (unsigned long long)(v); } while (0)
+#define CT_STAMP(i) CT_STAMP_AT(i, __builtin_amdgcn_s_memtime())
+#define CT_STAMP_RT(i) CT_STAMP_AT(i, __builtin_amdgcn_s_memrealtime())
+#define CT_STAMP_VAL(i, v) CT_STAMP_AT(i, v)
+// HW_ID (wave / SIMD / CU / SE of the stamping wave) and XCC_ID: where the dispatcher put the workgroup
+#define CT_STAMP_HW(i) CT_STAMP_AT(i, ((unsigned long long)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 20) << 32) | (unsigned)__builtin_amdgcn_s_getreg(((32 - 1) << 11) | 4))
+#define CT_DEFINE_STAMPS(name)                                                                                           \
+    extern "C" int ct_##name##_read_stamps(unsigned long long *host, int nblocks)                                        \
+    {                                                                                                                    \
+        return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ct_stamps_buf), sizeof(unsigned long long) * CT_STAMP_WORDS * nblocks); \
+    }                                                                                                                    \
+    extern "C" int ct_##name##_clear_stamps(void)                                                                        \
+    {                                                                                                                    \
+        void *p = nullptr;                                                                                               \
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(ct_stamps_buf)) != hipSuccess) return 1;                                  \
+        return (int)hipMemset(p, 0, sizeof(unsigned long long) * CT_STAMP_WORDS * CT_STAMP_BLOCKS);                      \
+    }
+#else
+#define CT_STAMP(i)
+#define CT_STAMP_RT(i)
+#define CT_STAMP_VAL(i, v)
+#define CT_STAMP_HW(i)
+#define CT_DEFINE_STAMPS(name)
+#endif
+
 // Epilogue description shared by the conv / dcn / split-K-reduce kernels.
 struct EpiArgs {
     const float *scale;   // [>=Cout] or nullptr

@@ -68,28 +68,7 @@ struct DcnGroup {
 #ifndef CT_OFF_PD
 #define CT_OFF_PD 2       // B prefetch distance of the offset/mask conv tiles (variant builds: tools/build_variant.py)
 #endif
-#if defined(CT_DCN_STAMPS)
-// tools/dcn_phases.py: per-workgroup phase stamps (debug build only, never part of the shipped library)
-#define CT_STAMP_WORDS 10
-__device__ unsigned long long ct_dcn_stamps[CT_STAMP_WORDS * 8192];
-#define CT_STAMP(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ct_dcn_stamps[blockIdx.x * CT_STAMP_WORDS + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
-#define CT_STAMP_RT(i) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ct_dcn_stamps[blockIdx.x * CT_STAMP_WORDS + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
-#define CT_STAMP_VAL(i, v) do { if (threadIdx.x == 0 && blockIdx.x < 8192) ct_dcn_stamps[blockIdx.x * CT_STAMP_WORDS + (i)] = (unsigned long long)(v); } while (0)
-extern "C" int ct_dcn_read_stamps(unsigned long long *host, int nblocks)
-{
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(ct_dcn_stamps), sizeof(unsigned long long) * CT_STAMP_WORDS * nblocks);
-}
-extern "C" int ct_dcn_clear_stamps(void)
-{
-    void *p = nullptr;
-    if (hipGetSymbolAddress(&p, HIP_SYMBOL(ct_dcn_stamps)) != hipSuccess) return 1;
-    return (int)hipMemset(p, 0, sizeof(unsigned long long) * CT_STAMP_WORDS * 8192);
-}
-#else
-#define CT_STAMP(i)
-#define CT_STAMP_RT(i)
-#define CT_STAMP_VAL(i, v)
-#endif
+CT_DEFINE_STAMPS(dcn)       // (tools/dcn_phases.py; expands to nothing in the shipped build)
 
 template <int BM, int WN, bool FUSE, int NKK = 2>
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)

@@ -10,6 +10,10 @@
 #pragma once
 #include "ct_common.h"
 
+#ifndef CT_KS_STAMP
+#define CT_KS_STAMP(i)      // (conv_mfma.hip maps these to CT_STAMP for tools/conv_phases.py; the DCN kernels stamp their own phases)
+#endif
+
 template <int KS, int STRIDE, int WM, int WN, int WK>
 struct KsCfg {
     static constexpr int NTHR = 64 * WK;
@@ -120,8 +124,10 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
         f32x4 breg[R][WN];
 #pragma unroll
         for (int p = 0; p < D; ++p) load_b(breg[p % R], c_begin + p / S, p % S);
+        CT_KS_STAMP(2);
         stage_store(0);
         __syncthreads();
+        CT_KS_STAMP(3);
         for (int c0 = c_begin; c0 < c_end; c0 += U) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
@@ -161,6 +167,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
         }
     }
 
+    CT_KS_STAMP(4);
     // ---- cross-wave reduction through LDS (wave order 0..WK-1), then the finaliser ------------
     constexpr int T = WM * WN;
     float *red = lds;
@@ -170,6 +177,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
         for (int nt = 0; nt < WN; ++nt)
             *reinterpret_cast<f32x4 *>(red + ((wave * T + mt * WN + nt) * 64 + lane) * 4) = acc[mt][nt];
     __syncthreads();
+    CT_KS_STAMP(5);
 #pragma unroll
     for (int t0 = 0; t0 < T; t0 += WK) {
         const int t = t0 + wave;

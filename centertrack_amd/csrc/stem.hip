@@ -20,6 +20,8 @@ __host__ __device__ constexpr int st_koff(int s) { return s * 148; }            
 constexpr int ST_KTOT = 348;
 constexpr int ST_WLP = 16;
 
+CT_DEFINE_STAMPS(stem)      // (tools/conv_phases.py; expands to nothing in the shipped build)
+
 struct StemArgs {
     const float *in[3];   // nullptr = stem not part of this launch
     const float *w[3];
@@ -38,6 +40,9 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     __shared__ __attribute__((aligned(16))) float planes[7 * ST_PS];
     __shared__ __attribute__((aligned(16))) float wl[ST_KTOT * ST_WLP];
     __shared__ int tab[ST_KTOT];
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
+    CT_STAMP_HW(8);
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -138,8 +143,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     // stems of this launch, in order (uniform): first, and for every stem the next active one (3 = none)
     const int first = a.in[0] ? 0 : (a.in[1] ? 1 : 2);
     stage_load(first);
+    CT_STAMP(2);
     stage_store(first);
     __syncthreads();
+    CT_STAMP(3);
 #pragma unroll
     for (int s = 0; s < 3; ++s) {
         if (s < first) continue;
@@ -168,7 +175,10 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
         }
         if (have_next) stage_store(nxt);
         if (s < 2) __syncthreads();
+        if (s == 0) CT_STAMP(4);
+        if (s == 1) CT_STAMP(5);
     }
+    CT_STAMP(9);
 
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt) {
@@ -180,6 +190,8 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
             if (ox < a.W) a.y[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + li] = out[mt][e];
         }
     }
+    CT_STAMP(6);
+    CT_STAMP_RT(7);
 }
 
 }  // namespace

@@ -47,6 +47,7 @@ struct WCfg {
     static constexpr int ITEMS = 4 * PP * 4;                       // float4 items per chunk
     static constexpr int NR = (ITEMS + 255) / 256;
 };
+CT_DEFINE_STAMPS(wino)      // (tools/conv_phases.py; expands to nothing in the shipped build)
 
 // B^T rows as (i1, i2, s2): V = d[i1] + s2 * d[i2]   (r=0: d0-d2, r=1: d1+d2, r=2: d2-d1, r=3: d1-d3)
 __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
@@ -84,6 +85,9 @@ void wino_conv_kernel(WinoArgs a)
     constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS;
     constexpr int W_NR = (W_ITEMS + NTHR - 1) / NTHR;
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
+    CT_STAMP_HW(8);
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);      // wave index: uniform, kept in an SGPR
     const int wave = wv & 3, kp = wv >> 2;
@@ -203,8 +207,10 @@ void wino_conv_kernel(WinoArgs a)
     f32x4 vall[NB > 1 ? 4 : 1][WM][4];             // NB > 1: all four slabs of the (single) chunk, transformed once
     if (NB > 1) {
         stage_load(0);
+        CT_STAMP(2);
         stage_store(0);
         __syncthreads();
+        CT_STAMP(3);
 #pragma unroll
         for (int kk = 0; kk < (NB > 1 ? 4 : 1); ++kk) transform(vall[kk], lds, kk);
         __syncthreads();                            // the patch is dead from here on: its LDS becomes the exchange buffer
@@ -260,8 +266,10 @@ void wino_conv_kernel(WinoArgs a)
         f32x4 breg[R][WN];
 #pragma unroll
         for (int p = 0; p < D; ++p) load_b(breg[p], p / S, p % S);
+        CT_STAMP(2);
         stage_store(0);
         __syncthreads();
+        CT_STAMP(3);
         const int nchunks = MULTI ? a.nchunks : 1;
         for (int ch = 0; ch < nchunks; ++ch) {
             const int cur = ch & 1;
@@ -296,6 +304,7 @@ void wino_conv_kernel(WinoArgs a)
         }
     }
 
+    if (NB == 1) CT_STAMP(4);
     // ---- output transform: columns in registers ... ---------------------------------------------------
     // T[q][nt]: q=0: M0+M1+M2, q=1: M1-M2-M3   (this wave's row r)
 #pragma unroll
@@ -308,6 +317,7 @@ void wino_conv_kernel(WinoArgs a)
             *reinterpret_cast<f32x4 *>(exch + (((wr * 2 + 1) * TN + mt * WN + nt) * 64 + lane) * 4) = t1;
         }
     __syncthreads();
+    if (NB == 1) CT_STAMP(5);
     // ... rows across the waves: Y[0][q] = T0+T1+T2, Y[1][q] = T1-T2-T3; 2*WM*WN (q, mt, nt) jobs over 4 waves
 #pragma unroll
     for (int w0 = 0; w0 < 2 * TN; w0 += 4 * KS) {
@@ -407,6 +417,8 @@ void wino_conv_kernel(WinoArgs a)
     }
     if (NB > 1) __syncthreads();                    // every job has read the exchange buffer: the next block may overwrite it
     }                                               // (cout block nb)
+    if (NB > 1) CT_STAMP(5);
+    if (!HEADS) { CT_STAMP(6); CT_STAMP_RT(7); }
     if (HEADS) {
         // wave wv handled (q = wv & 1, n-tile wv >> 1) of every block; lane: pixels tp = (lane + 64 h2) >> 2, quad lane & 3
         const int q = wv & 1, ntile = wv >> 1;
@@ -446,6 +458,7 @@ void wino_conv_kernel(WinoArgs a)
             }
         }
     }
+    if (HEADS) { CT_STAMP(6); CT_STAMP_RT(7); }
 }
 
 // U[pos][co][ci] = (G g G^T)[r][c], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]

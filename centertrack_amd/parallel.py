@@ -23,8 +23,10 @@ import torch.distributed as dist
 
 def init_from_env(backend=None):
     """Initialise torch.distributed from torchrun's environment; returns (rank, world, local_rank).
-    Single-process runs (no RANK in the environment) return (0, 1, 0) without a process group."""
-    if 'RANK' not in os.environ or int(os.environ.get('WORLD_SIZE', '1')) <= 1:
+    Single-process runs (no RANK in the environment) return (0, 1, 0) without a process group.  A torchrun job of ONE
+    rank (`--nproc-per-node 1`) does get its group: the collectives of the sharded path then really go through RCCL
+    (``group_active``), which is how a single-GPU box exercises them (tests/test_hip_rccl.py)."""
+    if 'RANK' not in os.environ:
         return 0, 1, int(os.environ.get('LOCAL_RANK', 0))
     rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
     local = int(os.environ.get('LOCAL_RANK', rank))
@@ -39,6 +41,11 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
+def group_active():
+    """a torch.distributed process group exists (any world size): the exchange step goes through its collectives"""
+    return dist.is_available() and dist.is_initialized()
+
+
 def shard_streams(num_streams, rank, world):
     """Global stream ids owned by ``rank`` (round-robin, so G=1,2,4,8 all balance)."""
     return [s for s in range(num_streams) if s % world == rank]
@@ -50,7 +57,7 @@ def check_same_plan(signature, what='launch plan'):
     mismatch raises on EVERY rank, naming the ranks that differ from rank 0.  Returns the hex digest."""
     digest = hashlib.sha256(signature.encode()).digest()
     hexd = digest[:8].hex()
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not group_active():
         return hexd
     world = dist.get_world_size()
     dev = 'cuda' if dist.get_backend() == 'nccl' else 'cpu'
@@ -106,6 +113,9 @@ class DetectionGatherer(object):
         self.recv = torch.zeros((world * self.per, K, F), dtype=dtype, device=device)
         self.out = torch.zeros((world * self.per, K, F), dtype=dtype, device=device)
         self.steps = 0
+        # with a process group the exchange is a real collective even for a group of one rank (RCCL on a one-GPU box);
+        # without one (plain `python bench.py`) the rows are only copied
+        self.collective = world > 1 or group_active()
         self.overlap = bool(overlap) and device.type == 'cuda'
         self.consumed_steps = 0
         self.consumed_detections = 0
@@ -129,7 +139,7 @@ class DetectionGatherer(object):
         self.steps += 1
         K, F = self.send.shape[1:]
         if not self.overlap:
-            if self.world == 1:
+            if not self.collective:
                 self.out[:self.n_local].copy_(local_rows)
             else:
                 self.send[:self.n_local].copy_(local_rows)
@@ -142,7 +152,7 @@ class DetectionGatherer(object):
         slot = self.steps & 1
         with torch.cuda.stream(self.side):
             self.side.wait_event(self.rows_ready)
-            if self.world == 1:
+            if not self.collective:
                 self.out[:self.n_local].copy_(local_rows, non_blocking=True)
                 self.rows_free.record(self.side)
             else:
@@ -193,7 +203,7 @@ class DetectionGatherer(object):
         them across ranks (``verify``) to prove that the collective moved the real rows"""
         mine = int(self._bits_sum(local_rows).item())
         K, F = self.send.shape[1:]
-        if self.world == 1:
+        if not self.collective:
             return mine, [int(self._bits_sum(self.out[:self.n_local]).item())]
         return mine, self._bits_sum(self.recv.view(self.world, self.per, K, F), (1, 2, 3)).tolist()
 
@@ -208,7 +218,7 @@ class DetectionGatherer(object):
         ids = shard_streams(self.num_streams, self.rank, self.world)
         if ids and not torch.equal(self.out[ids], local_rows.to(self.out.dtype)):
             raise RuntimeError('rank %d: its own rows are not at their global stream ids in the gathered block' % self.rank)
-        if self.world == 1:
+        if not self.collective:
             if blocks[0] != mine:
                 raise RuntimeError('gathered block differs from the local rows')
             return 1

@@ -7,6 +7,8 @@ is the identity up to enumerated birth ties.
   config 3  kitti_1280x384 384x1280, 2 streams, flip_test (4 images per step), T = 2
   config 4  coco_512       512x512,  2 streams, 80 classes (top-K over 80 x 16384, then 8000), T = 2
   config 5  nusc_800x448   448x800,  1 stream,  3D heads, T = 2
+  (ref)     mot17_544x960  544x960,  1 stream,  T = 8: the reference's own MOT input size (datasets/mot.py:15), odd 17 x 30
+                           deep maps
 plus: two different launch-shape choices (autotuned vs built-in heuristics) give the same ids, and size-independent
 properties of the wide flip config.
 """
@@ -32,6 +34,18 @@ def test_mot17_512_T32_sequence_matches_oracle(device):
     checks, swaps = _run_config('mot17_512', 1, 32, min_tracks=40)
     c = checks[0]
     assert c.frames == 32 and c.detections > 32 * 10
+    assert max(c.id_map) > 60, 'the sequence must keep giving birth to tracks (max id %d)' % max(c.id_map)
+
+
+def test_mot17_544x960_reference_resolution_matches_oracle(device):
+    """The size `test.py tracking --dataset mot` runs at (src/lib/dataset/datasets/mot.py:15: default_resolution =
+    [544, 960]; readme/MODEL_ZOO.md:16-20 quotes the reference's time on it).  Output grid 136 x 240, level-5 maps
+    17 x 30 and level-4 maps 34 x 60: every ragged-tile path of the conv / Winograd / DCN kernels (tile rows of 2 and 4,
+    16-pixel tile columns against widths 30, 60, 120, 240) runs in one frame.  T = 8 scrolled frames, ids compared over
+    the whole sequence."""
+    checks, swaps = _run_config('mot17_544x960', 1, 8, min_tracks=40)
+    c = checks[0]
+    assert c.frames == 8 and c.detections > 8 * 10
     assert max(c.id_map) > 60, 'the sequence must keep giving birth to tracks (max id %d)' % max(c.id_map)
 
 
@@ -117,7 +131,8 @@ def test_pinned_tune_table_covers_the_baseline_configs():
     autotune._LOADED = False
     autotune._load_file()
     before = set(autotune._CACHE)
-    for name, streams in (('mot17_512', 1), ('kitti_1280x384', 8), ('coco_512', 4), ('nusc_800x448', 4)):
+    for name, streams in (('mot17_512', 1), ('kitti_1280x384', 8), ('coco_512', 4), ('nusc_800x448', 4),
+                          ('mot17_544x960', 1)):
         cfg = S.CONFIGS[name]
         model = DLASegHIP(S.HEAD_SETS[cfg['heads']]).to('cuda')
         model.get_plan(streams, cfg['H'], cfg['W'], True, True, True)

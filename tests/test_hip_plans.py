@@ -10,8 +10,10 @@ fused offsets, 8 chunks per split): other fp32 summation orders, so parity has t
   nusc_800x448   x 4 streams (3D heads)                       BASELINE configs[4]: 16 on 4 GPUs
   mot17_512      x 8 / 16 / 32 streams, nusc_800x448 x 8 / 32 streams     north_star's 8x / 16x / 32x sweep
 
-Every stream advances T = 3 frames (ids are handed out in frame 0, carried over twice) through ONE StreamDetector;
-the oracle follows a sample of the streams (first, middle, last: the CPU forward is 0.25-1 s per frame).  Same
+Every stream advances T = 3 frames (ids are handed out in frame 0, carried over twice) through ONE StreamDetector -- T = 8
+on the 16- / 32-stream plans and nusc x 8 (ids carried over seven times; tools/tie_report.py follows the headline plan
+and four more for 16-32 frames) -- and the oracle follows a sample of the streams (first, middle, last: the CPU forward
+is 0.25-1 s per frame).  Same
 assertions as the full-size tests (tests/_parity.py): top-K entries / classes / ranks identical above the threshold up
 to tie groups < 1e-5, values within 1e-3 on the output grid, track ids a bijection that is the identity except for
 enumerated birth ties.  The streams are NOT hand-picked: a stream that runs into a threshold tie (an oracle score within
@@ -24,20 +26,20 @@ from _parity import run_config
 pytestmark = pytest.mark.gpu
 
 CASES = [
-    ('kitti_1280x384', 4, (0, 1, 2, 3)),
-    ('coco_512', 4, (0, 1, 2, 3)),
-    ('nusc_800x448', 4, (0, 1, 2, 3)),
-    ('mot17_512', 8, (0, 4, 7)),
-    ('mot17_512', 16, (0, 8, 15)),
-    ('mot17_512', 32, (0, 16, 31)),
-    ('nusc_800x448', 8, (0, 4, 7)),
-    ('nusc_800x448', 32, (0, 16, 31)),
+    ('kitti_1280x384', 4, (0, 1, 2, 3), 3),
+    ('coco_512', 4, (0, 1, 2, 3), 3),
+    ('nusc_800x448', 4, (0, 1, 2, 3), 3),
+    ('mot17_512', 8, (0, 4, 7), 3),
+    ('mot17_512', 16, (0, 8, 15), 8),
+    ('mot17_512', 32, (0, 16, 31), 8),
+    ('nusc_800x448', 8, (0, 4, 7), 8),
+    ('nusc_800x448', 32, (0, 16, 31), 8),
+    ('mot17_544x960', 8, (0, 7), 3),          # the reference's own MOT size on its 8-stream plan
 ]
-T = 3
 
 
-@pytest.mark.parametrize('name,streams,sample', CASES, ids=['%s_x%d' % (c[0], c[1]) for c in CASES])
-def test_benchmarked_plan_matches_oracle(device, name, streams, sample):
+@pytest.mark.parametrize('name,streams,sample,T', CASES, ids=['%s_x%d' % (c[0], c[1]) for c in CASES])
+def test_benchmarked_plan_matches_oracle(device, name, streams, sample, T):
     import scenarios as S
     from centertrack_amd import autotune
     checks, swaps, det = run_config(name, streams, T, sample=sample, on_threshold_tie='stop', min_tracks=5)

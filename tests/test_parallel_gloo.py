@@ -255,3 +255,32 @@ def test_gathered_block_is_consumed_every_step_and_counts_all_streams():
         assert p.exitcode == 0
     for rank, steps, counted, want, total in got:
         assert steps == 4 and counted == want == total
+
+
+def _worker_one_rank_group(port, q):
+    os.environ.update(RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port))
+    from centertrack_amd import parallel
+    r, w, _ = parallel.init_from_env(backend='gloo')
+    rows = _rows(3, 5, 11)
+    g = parallel.DetectionGatherer(3, 1, 0, 5, 11, 'cpu')
+    out = g(rows).clone()
+    h = parallel.check_same_plan('conv:201:1;dcn_knobs=(128, 4, 4, 1, 0, 0)')
+    q.put((r, w, parallel.group_active(), g.collective, bool(torch.equal(out, rows)), g.verify(rows), len(h)))
+    torch.distributed.destroy_process_group()
+
+
+def test_group_of_one_rank_exchanges_through_the_collective():
+    """a torchrun job of ONE rank gets its process group, and with a group the exchange step is the real collective
+    (send -> all_gather_into_tensor -> reorder), not the copy a plain single process does: how tests/test_hip_rccl.py
+    makes RCCL execute on a one-GPU box"""
+    from centertrack_amd import parallel
+    plain = parallel.DetectionGatherer(3, 1, 0, 5, 11, 'cpu')
+    assert not plain.collective                                # no group in this process: rows are only copied
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    p = ctx.Process(target=_worker_one_rank_group, args=(_free_port(), q))
+    p.start()
+    got = q.get(timeout=180)
+    p.join(timeout=60)
+    assert p.exitcode == 0
+    assert got == (0, 1, True, True, True, 1, 16)

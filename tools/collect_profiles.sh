@@ -29,6 +29,7 @@ python tools/pmc_stats.py $(ls /tmp/pmcA/*counter_collection.csv /tmp/pmcA/*/*co
 python tools/pmc_stats.py $(ls /tmp/pmcB/*counter_collection.csv /tmp/pmcB/*/*counter_collection.csv 2>/dev/null | head -1) 30 > $OUT/${TAG}_pmc_fetch_size.txt
 python tools/pmc_stats.py $(ls /tmp/pmcC/*counter_collection.csv /tmp/pmcC/*/*counter_collection.csv 2>/dev/null | head -1) 30 > $OUT/${TAG}_pmc_write_size.txt
 python tools/pmc_traffic.py $OUT/${TAG}_pmc_fetch_size.txt $OUT/${TAG}_pmc_write_size.txt $TAG > $OUT/pmc_traffic.json
+python tools/pmc_busy.py $OUT/${TAG}_pmc_sq.txt $TAG > $OUT/pmc_mfma_busy.json
 python tools/dcn_profiled.py $OUT/${TAG}_rocprofv3_kernel_stats_bench_steps3.txt | sed "s#$OUT/#profiles/#" > $OUT/dcn_profiled.json
 cat $OUT/${TAG}_bench_n1.json
 tail -12 $OUT/pmc_traffic.json

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Where a DCN workgroup's time goes: builds a debug copy of the library with -DCT_DCN_STAMPS (s_memtime stamps at the
+"""Where a DCN workgroup's time goes: builds a debug copy of the library with -DCT_STAMPS (s_memtime stamps at the
 phase boundaries of dcn_mfma_kernel, per workgroup) and prints, for every MAIN launch of a plan's DCN schedule and every
 layer in it, the mean clocks per phase and the launch's wall span.
     python tools/dcn_phases.py --build          (needs hipcc; the debug library lands in centertrack_amd/build/dbg)
@@ -22,7 +22,7 @@ def build():
     b.build()
     os.makedirs(DBG, exist_ok=True)
     obj = os.path.join(DBG, 'dcn_mfma.o')
-    subprocess.check_call(['/opt/rocm/bin/hipcc'] + b.FLAGS + ['-x', 'hip', '-DCT_DCN_STAMPS', '-c',
+    subprocess.check_call(['/opt/rocm/bin/hipcc'] + b.FLAGS + ['-x', 'hip', '-DCT_STAMPS', '-c',
                                                              os.path.join(b.CSRC, 'dcn_mfma.hip'), '-o', obj])
     objs = [o for o in glob.glob(os.path.join(b.PKG, 'build', '*.o')) if not o.endswith('dcn_mfma.o')]
     subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC', '-o', LIB] + objs + [obj])
@@ -56,7 +56,7 @@ def main():
     torch.cuda.synchronize()
     raw = ctypes.CDLL(LIB)
     print('knobs', plan['dcn_knobs'])
-    NB, WORDS = 8192, 10
+    NB, WORDS = 8192, 12
     host = np.zeros(NB * WORDS, dtype=np.uint64)
     names = ['offset conv', 'table', 'prologue', 'loop', 'epilogue']
     for l in plan['launches']:

@@ -30,6 +30,7 @@ for B in 1 8 16 32; do run mot17_512 $B; done
 for B in 1 4 8 16 32; do run nusc_800x448 $B; done
 run kitti_1280x384 4
 run coco_512 4
+for B in 1 8; do run mot17_544x960 $B; done      # the reference's own MOT input size (datasets/mot.py:15)
 cat $OUT/${TAG}_box.json
 cat $OUT/${TAG}_sweep.jsonl | python -c "
 import json, sys
