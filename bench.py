@@ -154,6 +154,9 @@ def kernel_pass(model, plan, reps=10):
                 ho = (d.H + 2 * pad - d.ks) // d.stride + 1
                 wo = (d.W + 2 * pad - d.ks) // d.stride + 1
                 f = 2.0 * d.ks * d.ks * d.Cin * d.Cout * d.N * ho * wo
+                if d.proj_w_packed:             # Tree.project fused into the stride-2 launch: conv1x1 Cin -> Cout
+                    f += 2.0 * d.Cin * d.Cout * d.N * ho * wo
+                    bytes_ += 4.0 * (d.Cout * d.N * ho * wo + d.Cin * d.Cout)
                 flops += f
                 flops_exec += f * (16.0 / 36.0 if 201 <= int(d.algo) <= 211 else 1.0)      # Winograd launches
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)

@@ -39,7 +39,9 @@ class ConvDesc(ctypes.Structure):
                 ('dep_lo', ctypes.c_int), ('dep_hi', ctypes.c_int), ('depth_scale', ctypes.c_float),
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
                 ('split_k', ctypes.c_int), ('algo', ctypes.c_int), ('w_winograd', ctypes.c_void_p),
-                ('pool_y', ctypes.c_void_p), ('pool_ld', ctypes.c_int)]
+                ('pool_y', ctypes.c_void_p), ('pool_ld', ctypes.c_int),
+                ('proj_w_packed', ctypes.c_void_p), ('proj_scale', ctypes.c_void_p), ('proj_shift', ctypes.c_void_p),
+                ('proj_y', ctypes.c_void_p), ('proj_ldy', ctypes.c_int)]
 
 
 class DcnDesc(ctypes.Structure):

@@ -151,7 +151,8 @@ def _time_graph(fn, reps=REPS, pre=None):
 
 
 def _conv_key(d):
-    return 'conv%s:%d,%d,%d,%d,%d,%d,%d,%d,%d' % ('W' if d.w_winograd else '', d.N, d.H, d.W, d.Cin, d.Cout, d.ks,
+    # ('P': the launch also computes the fused projection -- other register / LDS use, other winners)
+    return 'conv%s%s:%d,%d,%d,%d,%d,%d,%d,%d,%d' % ('W' if d.w_winograd else '', 'P' if d.proj_w_packed else '', d.N, d.H, d.W, d.Cin, d.Cout, d.ks,
                                                    d.stride, 1 if d.res else 0, 1 if (d.flags & _lib.CT_OUT_NCHW) else 0)
 
 

@@ -40,6 +40,13 @@ struct ConvArgs {
     EpiArgs epi;
     float *pool_y;   // 3x3 stride-2 launches: 2x2 max-pool of the input as a side output (NHWC, pitch pool_ld), or nullptr
     int pool_ld;
+    // 3x3 stride-2 launches (round 4): Tree.project (dla.py:196-203,217-218: conv1x1 + BN of the 2x2 max-pooled input, no
+    // ReLU) as a second output of the same workgroups.  The pooled A fragment costs nothing: the 2x2 window of output
+    // pixel (oy, ox) is exactly taps (1,1) (1,2) (2,1) (2,2) of the 3x3 stride-2 window, i.e. the element-wise maximum of
+    // four A fragments the tap loop reads anyway; one more "tap" of MFMAs per 16-channel slab contracts it with the 1x1
+    // weights.  proj_wp: ct_pack_conv_weight of [Cout, Cin, 1, 1] (same n-tiles as wp), or nullptr.
+    const float *proj_wp;
+    EpiArgs epi2;
 };
 
 // 2x2 / stride-2 max-pool of the input from the staged LDS patch of a 3x3 stride-2 conv tile: output pixel (oy, ox) of
@@ -186,6 +193,19 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    // projection of the pooled input (POOL instantiations, when a.proj_wp is set): its own accumulators, the running
+    // maximum of the four window taps and the 1x1 weight fragments of the current slab
+    constexpr bool PROJ = POOL && KS == 3 && STRIDE == 2;
+    const bool proj = PROJ && a.proj_wp != nullptr;              // (uniform)
+    f32x4 accp[PROJ ? WM : 1][PROJ ? WN : 1];
+    f32x4 pmax[PROJ ? WM : 1];
+    f32x4 bproj[PROJ ? WN : 1];
+    if (PROJ) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) accp[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     // Software pipeline over steps (kk, tap): B fragments are fetched RING-1 steps ahead of
     // their MFMAs into a static register ring; the next chunk's patch is fetched into
@@ -209,7 +229,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x386);
             const float *buf = lds + cur * C::BUF;
             if constexpr (POOL && KS == 3 && STRIDE == 2) {
-                if (cb == 0)                    // (uniform) the input's 2x2 max-pool as a side output
+                if (cb == 0 && a.pool_y)        // (uniform) the input's 2x2 max-pool as a side output
                     pool_from_patch<C::TH, C::PW, C::SLAB, NKK, 256>(buf, c * (16 * NKK), a.pool_y, a.pool_ld, n, oy0, ox0,
                                                                      a.epi.Ho, a.epi.Wo);
             }
@@ -227,6 +247,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                 // pin the prefetch loads here (hipcc otherwise sinks them towards their use)
                 if (PIPE == 1) __builtin_amdgcn_sched_barrier(0x386);
                 const int ky = tap / KS, kx = tap % KS;
+                if constexpr (PROJ) {
+                    if (tap == 0 && proj) {     // the slab's 1x1 weights: 8 taps ahead of their MFMAs
+                        const size_t pslab = (size_t)c * NKK + kk;
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            bproj[nt] = *reinterpret_cast<const f32x4 *>(a.proj_wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) +
+                                                                         (lane << 2) + pslab * slab_stride);
+                    }
+                }
                 f32x4 af[WM];
 #pragma unroll
                 for (int mt = 0; mt < WM; ++mt) {
@@ -242,6 +271,27 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                         for (int nt = 0; nt < WN; ++nt)
                             acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], breg[s % RING][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
+                if constexpr (PROJ) {
+                    // taps (1,1) (1,2) (2,1) (2,2) = the 2x2 pooling window of this lane's output pixel
+                    if (tap == 4) {
+#pragma unroll
+                        for (int mt = 0; mt < WM; ++mt) pmax[mt] = af[mt];
+                    } else if (tap == 5 || tap == 7 || tap == 8) {
+#pragma unroll
+                        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) pmax[mt][e] = fmaxf(pmax[mt][e], af[mt][e]);
+                    }
+                    if (tap == 8 && proj) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+#pragma unroll
+                            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                                for (int nt = 0; nt < WN; ++nt)
+                                    accp[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pmax[mt][e], bproj[nt][e], accp[mt][nt], 0, 0, 0);
+                    }
+                }
             }
             if (c + 1 < c_end) stage_store(cur ^ 1);   // (a single-chunk launch allocates one buffer only)
             __syncthreads();
@@ -278,6 +328,15 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             for (int nt = 0; nt < WN; ++nt)
                 ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
     }
+    if constexpr (PROJ) {
+        if (proj) {
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    ct_store_tile(a.epi2, accp[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
+        }
+    }
     CT_STAMP(6);
     CT_STAMP_RT(7);
 }
@@ -308,13 +367,12 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
     using KC = KsCfg<KS, STRIDE, WM, WN, WK>;
     auto hook = [&](int c, const float *buf) {
         if constexpr (POOL && KS == 3 && STRIDE == 2) {
-            if (cb == 0)                        // (uniform) the input's 2x2 max-pool as a side output
+            if (cb == 0 && a.pool_y)            // (uniform) the input's 2x2 max-pool as a side output
                 pool_from_patch<WM, KC::PW, KC::SLAB, WK, 64 * WK>(buf, c * (16 * WK), a.pool_y, a.pool_ld, n, oy0, ox0,
                                                                    a.epi.Ho, a.epi.Wo);
         }
     };
-    ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(
-        xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds, [&](int mt, int nt, f32x4 sum) {
+    auto fin_main = [&](int mt, int nt, f32x4 sum) {
             const int oy = oy0 + mt;
             if (a.ws) {
                 const int li = lane & 15, lg = lane >> 4;
@@ -331,7 +389,16 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
             } else {
                 ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane);
             }
-        }, hook);
+        };
+    if constexpr (POOL && KS == 3 && STRIDE == 2) {
+        // (the POOL instantiations also carry Tree.project of the pooled input, see ConvArgs::proj_wp)
+        auto fin_proj = [&](int mt, int nt, f32x4 sum) { ct_store_tile(a.epi2, sum, n, oy0 + mt, ox0, (nt0 + nt) * 16, lane); };
+        ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds,
+                                                    fin_main, hook, a.proj_wp, fin_proj);
+    } else {
+        ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds,
+                                                    fin_main, hook);
+    }
     CT_STAMP(6);
     CT_STAMP_RT(7);
 }
@@ -509,7 +576,7 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
     const size_t lds = (a.chunksPerSplit == 1) ? C::LDS_BYTES / 2 : C::LDS_BYTES;
     if constexpr (KS == 3 && STRIDE == 2) {
-        if (a.pool_y) {
+        if (a.pool_y || a.proj_wp) {
             auto kp = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE, true>;
             static bool attr_set_p = false;
             if (!attr_set_p && C::LDS_BYTES > 48 * 1024) {
@@ -565,7 +632,7 @@ int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
         lds = sizeof(float) * (size_t)((C::BUF > C::RED) ? C::BUF : C::RED);
     }
     if constexpr (KS == 3 && STRIDE == 2) {
-        if (a.pool_y) {
+        if (a.pool_y || a.proj_wp) {
             auto kp = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK, true>;
             static bool attr_set_p = false;
             if (!attr_set_p && C::LDS_BYTES > 48 * 1024) {
@@ -666,6 +733,18 @@ extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
         if ((d->H & 1) || (d->W & 1) || d->pool_ld % 4 || d->pool_ld < d->Cin || ((uintptr_t)d->pool_y & 15))
             CT_FAIL_ARG("ct_conv2d: pool_y needs even H / W and a 16-byte aligned view of >= Cin channels");
         a.pool_y = d->pool_y; a.pool_ld = d->pool_ld;
+    }
+    a.proj_wp = nullptr;
+    a.epi2 = a.epi;
+    if (d->proj_w_packed) {
+        if (!(d->ks == 3 && d->stride == 2)) CT_FAIL_ARG("ct_conv2d: proj_* is a second output of the 3x3 stride-2 shapes");
+        if (!d->proj_y || (d->H & 1) || (d->W & 1) || d->proj_ldy < d->Cout)
+            CT_FAIL_ARG("ct_conv2d: proj_y needs even H / W and a view of >= Cout channels");
+        if (p.splits > 1) CT_FAIL_ARG("ct_conv2d: the fused projection cannot be combined with split-K (split_k=%d)", p.splits);
+        a.proj_wp = d->proj_w_packed;
+        a.epi2.scale = d->proj_scale; a.epi2.shift = d->proj_shift; a.epi2.res = nullptr; a.epi2.y = d->proj_y;
+        a.epi2.ldr = 0; a.epi2.ldy = d->proj_ldy; a.epi2.flags = 0;
+        a.epi2.sig_lo = a.epi2.sig_hi = a.epi2.dep_lo = a.epi2.dep_hi = 0;
     }
     const long blocks = (long)d->N * p.tilesX * p.tilesY * p.coutBlocks;
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_conv2d: grid too large");

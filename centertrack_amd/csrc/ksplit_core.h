@@ -8,6 +8,8 @@
 // HBM + a second reduce launch) for layers with few output tiles and gives every SIMD >= 1-2 waves
 // even when M x N is only 256 x 512.
 #pragma once
+#include <type_traits>
+
 #include "ct_common.h"
 
 #ifndef CT_KS_STAMP
@@ -42,13 +44,24 @@ struct KsNoHook {
     __device__ __forceinline__ void operator()(int, const float *) const {}
 };
 
+struct KsNoFin2 {
+    __device__ __forceinline__ void operator()(int, int, f32x4) const {}
+};
+
 // hook(chunk, buf): called by all threads at the top of every chunk with the chunk's staged patch in LDS ([WK slabs][PP]
 // [16 ch], swizzled like conv_mfma.hip's) -- lets a caller derive a side output from the input tile (2x2 max-pool)
-template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin, typename Hook = KsNoHook>
+// wp2 / fin2 (3x3 stride-2 tiles only, round 4): a SECOND product on the same tile -- the 1x1 convolution of the 2x2
+// max-pooled input (Tree.project of the pooled tensor, dla.py:196-203,217): the pooling window of output pixel (oy, ox)
+// is taps (1,1) (1,2) (2,1) (2,2) of its 3x3 stride-2 window, so the pooled A fragment is the element-wise maximum of four
+// fragments the tap loop reads anyway; one extra "tap" of MFMAs per chunk contracts it with wp2 (packed [Cout, Cin, 1, 1],
+// same n-tiles).  wp2 == nullptr: off (uniform).  fin2(mt, nt, sum) runs after a second reduction pass.
+template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin, typename Hook = KsNoHook, typename Fin2 = KsNoFin2>
 __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W, int ldx, int Cin, const float *wp, int NT,
                                                  int nt0, int oy0, int ox0, int c_begin, int c_end, float *lds, Fin fin,
-                                                 Hook hook = Hook())
+                                                 Hook hook = Hook(), const float *wp2 = nullptr, Fin2 fin2 = Fin2())
 {
+    constexpr bool SIDE = KS == 3 && STRIDE == 2 && !std::is_same<Fin2, KsNoFin2>::value;
+    const bool side = SIDE && wp2 != nullptr;                    // (uniform)
     using C = KsCfg<KS, STRIDE, WM, WN, WK>;
     constexpr int PAD = KS / 2;
     constexpr int S = KS * KS;                       // steps (taps) per chunk and wave
@@ -117,6 +130,15 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 acc2[SIDE ? WM : 1][SIDE ? WN : 1];
+    f32x4 pmax[SIDE ? WM : 1];
+    f32x4 b2[SIDE ? WN : 1];
+    if (SIDE) {
+#pragma unroll
+        for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < WN; ++nt) acc2[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
 
     if (c_begin < c_end) {
         // all first-use global loads go out together (one memory round trip before the first MFMA)
@@ -145,6 +167,15 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                         load_b(breg[(g + D) % R], c + sp / S, sp % S);
                         __builtin_amdgcn_sched_barrier(0x386);
                         const int ky = s / KS, kx = s % KS;
+                        if constexpr (SIDE) {
+                            if (s == 0 && side) {      // this wave's slab of the 1x1 weights: 8 taps ahead of its MFMAs
+                                const size_t slab2 = (size_t)c * WK + wave;
+#pragma unroll
+                                for (int nt = 0; nt < WN; ++nt)
+                                    b2[nt] = *reinterpret_cast<const f32x4 *>(wp2 + ((size_t)min(nt0 + nt, NT - 1) << 8) + (lane << 2) +
+                                                                              slab2 * slab_stride);
+                            }
+                        }
                         f32x4 af[WM];
 #pragma unroll
                         for (int mt = 0; mt < WM; ++mt) {
@@ -159,6 +190,26 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                                 for (int nt = 0; nt < WN; ++nt)
                                     acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[mt][e], breg[g % R][nt][e],
                                                                                       acc[mt][nt], 0, 0, 0);
+                        if constexpr (SIDE) {
+                            if (s == 4) {
+#pragma unroll
+                                for (int mt = 0; mt < WM; ++mt) pmax[mt] = af[mt];
+                            } else if (s == 5 || s == 7 || s == 8) {
+#pragma unroll
+                                for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                                    for (int e = 0; e < 4; ++e) pmax[mt][e] = fmaxf(pmax[mt][e], af[mt][e]);
+                            }
+                            if (s == 8 && side) {
+#pragma unroll
+                                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                                    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                                        for (int nt = 0; nt < WN; ++nt)
+                                            acc2[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(pmax[mt][e], b2[nt][e], acc2[mt][nt], 0, 0, 0);
+                            }
+                        }
                     }
                     if (c + 1 < c_end) stage_store(cur ^ 1);
                     __syncthreads();
@@ -186,6 +237,27 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
 #pragma unroll
             for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
             fin(t / WN, t % WN, sum);
+        }
+    }
+    if constexpr (SIDE) {
+        if (side) {                                  // second product: same reduction, its own finaliser
+            __syncthreads();
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                for (int nt = 0; nt < WN; ++nt)
+                    *reinterpret_cast<f32x4 *>(red + ((wave * T + mt * WN + nt) * 64 + lane) * 4) = acc2[mt][nt];
+            __syncthreads();
+#pragma unroll
+            for (int t0 = 0; t0 < T; t0 += WK) {
+                const int t = t0 + wave;
+                if (t < T) {
+                    f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (t * 64 + lane) * 4);
+#pragma unroll
+                    for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
+                    fin2(t / WN, t % WN, sum);
+                }
+            }
         }
     }
 }

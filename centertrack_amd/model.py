@@ -25,6 +25,7 @@ FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
 FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-pools as side outputs of the stride-2 convs
+FUSE_PROJ = os.environ.get('CENTERTRACK_FUSE_PROJ', '1') != '0'       # Tree.project computed by the tree1.conv1 launch (round 4)
 DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
 
 
@@ -232,7 +233,7 @@ class DLASegHIP(torch.nn.Module):
             d = ops.make_conv_desc(x, wp, cout, ks, stride, scale=sc, shift=sh, res=res, relu=relu, out=out,
                                    w_wino=(ww if stride == 1 else None), **kw)
             us = autotune.tune_conv(d, dev)[2] if tune else 10.0
-            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw'), kw.get('pool')), reads=(x, res),
+            L.append(_Launch(name, 'conv', d, (x, res, out, pk, kw.get('out_nchw'), kw.get('pool'), kw.get('proj')), reads=(x, res),
                              writes=(out, kw.get('out_nchw')), us=us,
                              ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
             return out
@@ -254,9 +255,17 @@ class DLASegHIP(torch.nn.Module):
             caller owns the buffer and wants it filled here)."""
             h, w = x.H // stride, x.W // stride
             fold = None
+            # round 4: Tree.project (conv1x1 + BN of the pooled input, dla.py:196-203,217-218) is a second output of the
+            # tree1.conv1 launch -- same input patches, the pooling window is four taps of the 3x3 stride-2 window
+            fuse_proj = FUSE_PROJ and stride == 2 and cin != cout
             if stride > 1 and bottom is None:
-                bottom = R.slice(2 * cout, cin) if level_root else alloc(h, w, cin)
-                make_bottom = True
+                if level_root:
+                    bottom = R.slice(2 * cout, cin)
+                    make_bottom = True
+                elif not fuse_proj:
+                    bottom = alloc(h, w, cin)
+                    make_bottom = True
+                # (else: the pooled tensor only feeds the projection and is never materialised)
             elif stride == 1:
                 bottom = x
             if stride > 1 and make_bottom:
@@ -267,11 +276,16 @@ class DLASegHIP(torch.nn.Module):
             t = alloc(h, w, cout)
             x1 = R.slice(cout, cout)
             x2 = R.slice(0, cout)
-            add_conv(name + '.t1.conv1', x, pk['c11'], cout, 3, stride=stride, out=t, pool=fold)
-            if cin != cout:
-                residual = add_conv(name + '.project', bottom, pk['proj'], cout, 1, relu=False, out=alloc(h, w, cout))
+            if fuse_proj:
+                residual = alloc(h, w, cout)
+                add_conv(name + '.t1.conv1+project', x, pk['c11'], cout, 3, stride=stride, out=t, pool=fold,
+                         proj=(pk['proj'][0], pk['proj'][1], pk['proj'][2], residual))
             else:
-                residual = bottom
+                add_conv(name + '.t1.conv1', x, pk['c11'], cout, 3, stride=stride, out=t, pool=fold)
+                if cin != cout:
+                    residual = add_conv(name + '.project', bottom, pk['proj'], cout, 1, relu=False, out=alloc(h, w, cout))
+                else:
+                    residual = bottom
             add_conv(name + '.t1.conv2', t, pk['c12'], cout, 3, res=residual, out=x1)
             add_conv(name + '.t2.conv1', x1, pk['c21'], cout, 3, out=t)
             add_conv(name + '.t2.conv2', t, pk['c22'], cout, 3, res=x1, out=x2)

@@ -87,8 +87,10 @@ def _p(t):
 
 def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, relu=False, out=None,
                    out_nchw=None, sig=(0, 0), dep=(0, 0), depth_scale=1.0, workspace=None, split_k=0, algo=0,
-                   w_wino=None, pool=None):
-    """``pool``: NHWC view [N, H/2, W/2, Cin] that receives the 2x2 max-pool of ``x`` as a side output (3x3 stride-2)"""
+                   w_wino=None, pool=None, proj=None):
+    """``pool``: NHWC view [N, H/2, W/2, Cin] that receives the 2x2 max-pool of ``x`` as a side output (3x3 stride-2);
+    ``proj`` = (packed [Cout, Cin, 1, 1] weight, scale, shift, NHWC output view): Tree.project of the pooled input
+    (conv1x1 + BN, no ReLU) as a second output of the same launch"""
     d = ConvDesc()
     d.x, d.N, d.H, d.W, d.Cin, d.ldx = x.ptr, x.N, x.H, x.W, x.C, x.ld
     d.w_packed, d.Cout, d.ks, d.stride = wp.data_ptr(), Cout, ks, stride
@@ -115,6 +117,11 @@ def make_conv_desc(x, wp, Cout, ks, stride=1, scale=None, shift=None, res=None, 
     if pool is not None:
         assert ks == 3 and stride == 2 and (pool.N, pool.H, pool.W, pool.C) == (x.N, x.H // 2, x.W // 2, x.C)
         d.pool_y, d.pool_ld = pool.ptr, pool.ld
+    if proj is not None:
+        pw, psc, psh, py = proj
+        assert ks == 3 and stride == 2 and (py.N, py.H, py.W, py.C) == (x.N, x.H // 2, x.W // 2, Cout)
+        d.proj_w_packed, d.proj_scale, d.proj_shift = pw.data_ptr(), _p(psc), _p(psh)
+        d.proj_y, d.proj_ldy = py.ptr, py.ld
     return d
 
 

@@ -93,6 +93,15 @@ typedef struct ct_conv_desc {
      * input pixel passes through the workgroups' LDS patches anyway, so the pool costs no launch and no extra read.
      * H and W must be even; NULL = off. */
     float *pool_y; int pool_ld;
+    /* optional second output of a 3x3 stride-2 conv (round 4): Tree.project of the pooled input -- nn.Conv2d(Cin, Cout, 1,
+     * bias=False) + eval-mode BatchNorm, no ReLU, applied to Tree.downsample(x) = max_pool2d(x, 2, 2) (dla.py:196-203,
+     * 207, 217-218: the residual tree1 adds) -- computed by the workgroups of this launch from the input patches they
+     * stage anyway (the 2x2 window of an output pixel is four taps of its 3x3 stride-2 window): one launch and one read
+     * of the input less per DLA level.  proj_w_packed: ct_pack_conv_weight of the [Cout, Cin, 1, 1] weight (the SAME
+     * Cout as this conv); proj_y: NHWC [N, H/2, W/2, Cout] view (pitch proj_ldy); proj_scale / proj_shift NULL => 1 / 0.
+     * H and W must be even, no split-K.  NULL = off. */
+    const float *proj_w_packed; const float *proj_scale; const float *proj_shift;
+    float *proj_y; int proj_ldy;
 } ct_conv_desc;
 int ct_conv2d(const ct_conv_desc *d, void *stream);
 size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);
