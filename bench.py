@@ -158,7 +158,7 @@ def kernel_pass(model, plan, reps=10):
                     f += 2.0 * d.Cin * d.Cout * d.N * ho * wo
                     bytes_ += 4.0 * (d.Cout * d.N * ho * wo + d.Cin * d.Cout)
                 flops += f
-                flops_exec += f * (16.0 / 36.0 if 201 <= int(d.algo) <= 227 else 1.0)      # Winograd launches
+                flops_exec += f * (16.0 / 36.0 if 201 <= int(d.algo) <= 211 else 1.0)      # Winograd launches
                 bytes_ += 4.0 * (d.Cin * d.N * d.H * d.W + d.Cout * d.N * ho * wo + d.ks * d.ks * d.Cin * d.Cout)
         if kind == 'dcn':
             stats[kind] = dict(launches=len(launches), layers=nlayers, flops=flops, flops_main=flops_main, bytes=bytes_,

@@ -173,19 +173,14 @@ def _conv_candidates(d):
             continue
         cands.append((cfg + 1, 0))
         cands.append((cfg + 1, 1))
-        if d.ks == 3:
-            cands.append((cfg + 11, 1))        # latency shape: B ring a whole tap set deep (bit-identical results)
     for i, (wm, wn, wk) in enumerate(_KS):
         if d.Cin % (16 * wk) or (d.stride == 2 and wm == 2 and wk == 8):
             continue
         if 16 * wn > max(32, cout_pad):
             continue
         cands.append((101 + i, 1))
-        cands.append((111 + i, 1))            # latency shape of the same tile
     if d.w_winograd and d.ks == 3 and d.stride == 1 and d.Cin % 64 == 0 and not (d.flags & _lib.CT_OUT_NCHW):
         for algo in (201, 202, 203, 204, 205, 206, 207):   # Winograd F(2x2,3x3) tile / K-split shapes (centertrack_hip.h)
-            cands.append((algo, 1))
-        for algo in (221, 222, 223, 224, 225, 227):        # ... and their latency shapes (deep weight prefetch)
             cands.append((algo, 1))
         if d.Cin == 64 and d.Cout >= 128:                   # 2 / 4 / 5 / 8 cout blocks per workgroup on one input transform
             cands += [(208, 1), (209, 1), (210, 1), (211, 1)]

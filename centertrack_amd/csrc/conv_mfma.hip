@@ -97,10 +97,7 @@ struct ConvCfg {
 
 // POOL: the instantiation that also writes the 2x2 max-pool of its input (3x3 stride-2 only; a separate
 // instantiation because the extra code costs the plain kernels 12-20 VGPRs)
-// DEEP (3x3 only; algo 11..18, the "latency" shapes of round 4): the B ring holds a whole tap set (9 steps, 8 in flight)
-// instead of 3 -- see ksplit_core.h: at one stream every weight fragment is a ~1.1 us round trip into a cold L2 and a
-// step is 128 .. 512 clocks of MFMAs.  Same MFMA order: bit-identical to the shallow shape.
-template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE, bool POOL = false, bool DEEP = false>
+template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE, bool POOL = false>
 __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 {
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
@@ -214,7 +211,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     // their MFMAs into a static register ring; the next chunk's patch is fetched into
     // registers at the top of a chunk and written to the other LDS buffer at its end.
     constexpr int S = NKK * KS * KS;                   // steps per chunk
-    constexpr int RING = (DEEP && KS == 3) ? 9 : ((S % 3 == 0) ? 3 : ((S % 2 == 0) ? 2 : 1));
+    constexpr int RING = (S % 3 == 0) ? 3 : ((S % 2 == 0) ? 2 : 1);
     if (c_begin < c_end) {
         // all first-use global loads go out together (one memory round trip before the first MFMA)
         stage_load(c_begin);
@@ -348,9 +345,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 // ---------------------------------------------------------------------------------------------
 // K-split variant for layers with few output tiles (deep levels: 16x16 .. 64x64 maps with
 // 128..1280 input channels): see ksplit_core.h.
-// DEEP (algo 111..115): B ring 8 steps deep (3x3: a whole chunk of taps; 1x1: 8 chunks) and, for the 1x1 shapes, three
-// chunks of the A patch in flight -- the latency shapes of ksplit_core.h
-template <int KS, int STRIDE, int WM, int WN, int WK, bool POOL = false, bool DEEP = false>
+template <int KS, int STRIDE, int WM, int WN, int WK, bool POOL = false>
 __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];
@@ -398,11 +393,11 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
     if constexpr (POOL && KS == 3 && STRIDE == 2) {
         // (the POOL instantiations also carry Tree.project of the pooled input, see ConvArgs::proj_wp)
         auto fin_proj = [&](int mt, int nt, f32x4 sum) { ct_store_tile(a.epi2, sum, n, oy0 + mt, ox0, (nt0 + nt) * 16, lane); };
-        ksplit_conv_tile<KS, STRIDE, WM, WN, WK, DEEP ? 8 : 2, decltype(fin_main), decltype(hook), decltype(fin_proj)>(
-            xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds, fin_main, hook, a.proj_wp, fin_proj);
+        ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds,
+                                                    fin_main, hook, a.proj_wp, fin_proj);
     } else {
-        ksplit_conv_tile<KS, STRIDE, WM, WN, WK, DEEP ? 8 : 2, decltype(fin_main), decltype(hook), KsNoFin2, (DEEP && KS == 1) ? 3 : 1>(
-            xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds, fin_main, hook);
+        ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds,
+                                                    fin_main, hook);
     }
     CT_STAMP(6);
     CT_STAMP_RT(7);
@@ -457,7 +452,6 @@ __global__ __launch_bounds__(256) void pack_weight_kernel(const float *w, float 
 }
 
 struct Plan {
-    int deep;      // latency shapes (algo 11..18 / 111..115): deep B ring
     int pipe;
     int ks;        // >= 0: K-split kernel configuration (kKs table), -1: regular kernel
     int cfg;       // see launch_tile2
@@ -495,15 +489,8 @@ int make_plan(const ct_conv_desc *d, Plan *p)
         if (tiles_of(2) < ct_tune_get(CT_TUNE_CONV_SMALL_TILES) || tiles_of(2) >= 2048) p->cfg = 4;
     }
     if (ct_tune_get(CT_TUNE_CONV_CFG) >= 0) p->cfg = ct_tune_get(CT_TUNE_CONV_CFG);
-    p->deep = 0;
-    int algo = d->algo;
-    if ((algo >= 11 && algo <= 18) || (algo >= 111 && algo < 111 + kNumKs)) {
-        if (algo < 100 && d->ks != 3) CT_FAIL_ARG("ct_conv2d: the row-tiled latency shapes (algo 11..18) are for 3x3 convolutions");
-        p->deep = 1;
-        algo -= 10;
-    }
-    if (algo >= 1 && algo <= 8) p->cfg = algo - 1;
-    else if (algo != 0 && !(algo >= 101 && algo < 101 + kNumKs)) CT_FAIL_ARG("ct_conv2d: unknown algo %d", d->algo);
+    if (d->algo >= 1 && d->algo <= 8) p->cfg = d->algo - 1;
+    else if (d->algo != 0 && !(d->algo >= 101 && d->algo < 101 + kNumKs)) CT_FAIL_ARG("ct_conv2d: unknown algo %d", d->algo);
     p->pipe = ct_tune_get(CT_TUNE_CONV_PIPE);
     p->TH = kTH[p->cfg];
     p->BN = kBN[p->cfg];
@@ -531,10 +518,10 @@ int make_plan(const ct_conv_desc *d, Plan *p)
             return (long)d->N * p->tilesX * ct_cdiv(p->Ho, kKs[id][0]) * ct_cdiv(d->Cout, 16 * kKs[id][1]);
         };
         int want = ct_tune_get(CT_TUNE_CONV_KS);
-        if (algo >= 101) {
-            want = algo - 101;
+        if (d->algo >= 101) {
+            want = d->algo - 101;
             if (!ks_ok(want)) CT_FAIL_ARG("ct_conv2d: algo %d cannot run Cin=%d stride=%d", d->algo, d->Cin, d->stride);
-        } else if (algo >= 1) want = -2;
+        } else if (d->algo >= 1) want = -2;
         if (want >= 0) {
             if (ks_ok(want)) p->ks = want;
         } else if (want == -1 && d->split_k <= 0 && tiles_of(2) < ct_tune_get(CT_TUNE_CONV_KS_BELOW)) {
@@ -583,14 +570,14 @@ size_t ws_bytes(const ct_conv_desc *d, const Plan &p)
     return (size_t)p.splits * d->N * p.Ho * p.Wo * (size_t)(p.NT * 16) * sizeof(float);
 }
 
-template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE, bool DEEP = false>
+template <int KS, int STRIDE, int WGM, int WGN, int WM, int WN, int NKK, int PIPE>
 int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     using C = ConvCfg<KS, STRIDE, WGM, WGN, WM, WN, NKK>;
     const size_t lds = (a.chunksPerSplit == 1) ? C::LDS_BYTES / 2 : C::LDS_BYTES;
     if constexpr (KS == 3 && STRIDE == 2) {
         if (a.pool_y || a.proj_wp) {
-            auto kp = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE, true, DEEP>;
+            auto kp = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE, true>;
             static bool attr_set_p = false;
             if (!attr_set_p && C::LDS_BYTES > 48 * 1024) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -601,7 +588,7 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
             return CT_OK;
         }
     }
-    auto k = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE, false, DEEP>;
+    auto k = conv_mfma_kernel<KS, STRIDE, WGM, WGN, WM, WN, NKK, PIPE>;
     static bool attr_set = false;   // > 64 KiB dynamic LDS needs the opt-in attribute
     if (!attr_set && C::LDS_BYTES > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -615,30 +602,27 @@ int launch_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 // tile configurations: {WGM, WGN, WM, WN} -> TH = WGM*WM rows x 16 px, BN = 16*WGN*WN couts
 //   0: 256 px x 16   1: 128 px x 32   2: 64 px x 64   3: 64 px x 128   4: 32 px x 64   5: 64 px x 32
 //   6: 128 px x 16   7: 64 px x 16
-template <int KS, int STRIDE, int NKK, int PIPE, bool DEEP = false>
+template <int KS, int STRIDE, int NKK, int PIPE>
 int launch_tile2(int cfg, const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     switch (cfg) {
-    case 0: return launch_cfg<KS, STRIDE, 4, 1, 4, 1, NKK, PIPE, DEEP>(a, grid, s);
-    case 1: return launch_cfg<KS, STRIDE, 4, 1, 2, 2, NKK, PIPE, DEEP>(a, grid, s);
-    case 2: return launch_cfg<KS, STRIDE, 2, 2, 2, 2, NKK, PIPE, DEEP>(a, grid, s);
-    case 3: return launch_cfg<KS, STRIDE, 2, 2, 2, 4, NKK, PIPE, DEEP>(a, grid, s);
-    case 4: return launch_cfg<KS, STRIDE, 1, 4, 2, 1, NKK, PIPE, DEEP>(a, grid, s);
-    case 6: return launch_cfg<KS, STRIDE, 4, 1, 2, 1, NKK, PIPE, DEEP>(a, grid, s);
-    case 7: return launch_cfg<KS, STRIDE, 4, 1, 1, 1, NKK, PIPE, DEEP>(a, grid, s);
-    default: return launch_cfg<KS, STRIDE, 2, 2, 2, 1, NKK, PIPE, DEEP>(a, grid, s);
+    case 0: return launch_cfg<KS, STRIDE, 4, 1, 4, 1, NKK, PIPE>(a, grid, s);
+    case 1: return launch_cfg<KS, STRIDE, 4, 1, 2, 2, NKK, PIPE>(a, grid, s);
+    case 2: return launch_cfg<KS, STRIDE, 2, 2, 2, 2, NKK, PIPE>(a, grid, s);
+    case 3: return launch_cfg<KS, STRIDE, 2, 2, 2, 4, NKK, PIPE>(a, grid, s);
+    case 4: return launch_cfg<KS, STRIDE, 1, 4, 2, 1, NKK, PIPE>(a, grid, s);
+    case 6: return launch_cfg<KS, STRIDE, 4, 1, 2, 1, NKK, PIPE>(a, grid, s);
+    case 7: return launch_cfg<KS, STRIDE, 4, 1, 1, 1, NKK, PIPE>(a, grid, s);
+    default: return launch_cfg<KS, STRIDE, 2, 2, 2, 1, NKK, PIPE>(a, grid, s);
     }
 }
 template <int KS, int STRIDE, int NKK>
-int launch_tile(int cfg, int pipe, int deep, const ConvArgs &a, dim3 grid, hipStream_t s)
+int launch_tile(int cfg, int pipe, const ConvArgs &a, dim3 grid, hipStream_t s)
 {
-    if constexpr (KS == 3) {
-        if (deep) return launch_tile2<KS, STRIDE, NKK, 1, true>(cfg, a, grid, s);      // (the latency shapes pin their prefetches)
-    }
     return pipe ? launch_tile2<KS, STRIDE, NKK, 1>(cfg, a, grid, s) : launch_tile2<KS, STRIDE, NKK, 0>(cfg, a, grid, s);
 }
 
-template <int KS, int STRIDE, int WM, int WN, int WK, bool DEEP = false>
+template <int KS, int STRIDE, int WM, int WN, int WK>
 int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     using C = KsCfg<KS, STRIDE, WM, WN, WK>;
@@ -649,7 +633,7 @@ int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
     }
     if constexpr (KS == 3 && STRIDE == 2) {
         if (a.pool_y || a.proj_wp) {
-            auto kp = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK, true, DEEP>;
+            auto kp = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK, true>;
             static bool attr_set_p = false;
             if (!attr_set_p && C::LDS_BYTES > 48 * 1024) {
                 (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kp), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -660,7 +644,7 @@ int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
             return CT_OK;
         }
     }
-    auto k = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK, false, DEEP>;
+    auto k = conv_ksplit_kernel<KS, STRIDE, WM, WN, WK>;
     static bool attr_set = false;
     if (!attr_set && C::LDS_BYTES > 48 * 1024) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -670,16 +654,16 @@ int launch_ks_cfg(const ConvArgs &a, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL(k, grid, dim3(64 * WK), lds, s, a);
     return CT_OK;
 }
-template <int KS, int STRIDE, bool DEEP = false>
+template <int KS, int STRIDE>
 int launch_ks(int id, const ConvArgs &a, dim3 grid, hipStream_t s)
 {
     switch (id) {
-    case 0: return launch_ks_cfg<KS, STRIDE, 2, 2, 4, DEEP>(a, grid, s);
-    case 1: return launch_ks_cfg<KS, STRIDE, 1, 2, 4, DEEP>(a, grid, s);
-    case 2: return launch_ks_cfg<KS, STRIDE, 1, 2, 8, DEEP>(a, grid, s);
-    case 3: return launch_ks_cfg<KS, STRIDE, 2, 4, 4, DEEP>(a, grid, s);
+    case 0: return launch_ks_cfg<KS, STRIDE, 2, 2, 4>(a, grid, s);
+    case 1: return launch_ks_cfg<KS, STRIDE, 1, 2, 4>(a, grid, s);
+    case 2: return launch_ks_cfg<KS, STRIDE, 1, 2, 8>(a, grid, s);
+    case 3: return launch_ks_cfg<KS, STRIDE, 2, 4, 4>(a, grid, s);
     default:
-        if constexpr (STRIDE == 1) return launch_ks_cfg<KS, STRIDE, 2, 2, 8, DEEP>(a, grid, s);
+        if constexpr (STRIDE == 1) return launch_ks_cfg<KS, STRIDE, 2, 2, 8>(a, grid, s);
         else return CT_ERR_ARG;
     }
 }
@@ -704,7 +688,7 @@ extern "C" int ct_pack_conv_weight(const float *w_oihw, float *packed, int Cout,
 
 extern "C" size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d)
 {
-    if (d && d->algo >= 201 && d->algo <= 227) return 0;
+    if (d && d->algo >= 201 && d->algo <= 211) return 0;
     Plan p;
     ct_conv_desc t = *d;
     float dummy;
@@ -718,7 +702,7 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream);       // wino_mfma.
 
 extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
 {
-    if (d && d->algo >= 201 && d->algo <= 227 && !(d->algo >= 212 && d->algo <= 220)) {
+    if (d && d->algo >= 201 && d->algo <= 211) {
         if (!d->x || !d->y) CT_FAIL_ARG("ct_conv2d: null pointer");
         if (d->ldx % 4 || ((uintptr_t)d->x & 15)) CT_FAIL_ARG("ct_conv2d: input view must be 16-byte aligned (ld %% 4 == 0)");
         return ct_conv2d_winograd(d, stream);
@@ -766,23 +750,19 @@ extern "C" int ct_conv2d(const ct_conv_desc *d, void *stream)
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_conv2d: grid too large");
     dim3 grid((unsigned)blocks, (unsigned)p.splits);
     hipStream_t s = (hipStream_t)stream;
-    if (p.ks >= 0 && p.deep) {
-        if (d->ks == 1) rc = launch_ks<1, 1, true>(p.ks, a, grid, s);
-        else if (d->stride == 2) rc = launch_ks<3, 2, true>(p.ks, a, grid, s);
-        else rc = launch_ks<3, 1, true>(p.ks, a, grid, s);
-    } else if (p.ks >= 0) {
+    if (p.ks >= 0) {
         if (d->ks == 1) rc = launch_ks<1, 1>(p.ks, a, grid, s);
         else if (d->stride == 2) rc = launch_ks<3, 2>(p.ks, a, grid, s);
         else rc = launch_ks<3, 1>(p.ks, a, grid, s);
     } else if (d->ks == 1) {
-        if (p.nkk == 4) rc = launch_tile<1, 1, 4>(p.cfg, p.pipe, 0, a, grid, s);
-        else if (p.nkk == 2) rc = launch_tile<1, 1, 2>(p.cfg, p.pipe, 0, a, grid, s);
-        else rc = launch_tile<1, 1, 1>(p.cfg, p.pipe, 0, a, grid, s);
+        if (p.nkk == 4) rc = launch_tile<1, 1, 4>(p.cfg, p.pipe, a, grid, s);
+        else if (p.nkk == 2) rc = launch_tile<1, 1, 2>(p.cfg, p.pipe, a, grid, s);
+        else rc = launch_tile<1, 1, 1>(p.cfg, p.pipe, a, grid, s);
     } else if (d->stride == 2) {
-        rc = launch_tile<3, 2, 1>(p.cfg, p.pipe, p.deep, a, grid, s);
+        rc = launch_tile<3, 2, 1>(p.cfg, p.pipe, a, grid, s);
     } else {
-        if (p.nkk == 2) rc = launch_tile<3, 1, 2>(p.cfg, p.pipe, p.deep, a, grid, s);
-        else rc = launch_tile<3, 1, 1>(p.cfg, p.pipe, p.deep, a, grid, s);
+        if (p.nkk == 2) rc = launch_tile<3, 1, 2>(p.cfg, p.pipe, a, grid, s);
+        else rc = launch_tile<3, 1, 1>(p.cfg, p.pipe, a, grid, s);
     }
     CT_CHECK_LAUNCH("ct_conv2d");
     if (p.splits > 1) {

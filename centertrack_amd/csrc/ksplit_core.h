@@ -55,14 +55,7 @@ struct KsNoFin2 {
 // is taps (1,1) (1,2) (2,1) (2,2) of its 3x3 stride-2 window, so the pooled A fragment is the element-wise maximum of four
 // fragments the tap loop reads anyway; one extra "tap" of MFMAs per chunk contracts it with wp2 (packed [Cout, Cin, 1, 1],
 // same n-tiles).  wp2 == nullptr: off (uniform).  fin2(mt, nt, sum) runs after a second reduction pass.
-// PD / AD (round 4, the "latency" shapes): at one stream a deep layer is 128 .. 512 workgroups, ONE per CU, all of them
-// in the same phase at the same time, and every kernel starts with a cold L2 (per-XCD L2s are invalidated at kernel
-// boundaries): a weight fragment takes ~1.1 us (~2300 clocks) to arrive, a tap of MFMAs 256 .. 512 clocks.  With the B ring
-// two taps deep the tap loop of a 512-channel 3x3 layer paid that round trip every third tap -- 13.0 of its 17.4 us
-// (s_memtime stamps, profiles/r04_b_conv_phases_b1.txt).  PD = KS*KS - 1 keeps a whole chunk of taps in flight (same MFMA
-// order, bit-identical results); AD > 1 keeps AD chunks of the A patch in flight in registers (1x1 layers: a chunk is a
-// single tap, shorter than the round trip).
-template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin, typename Hook = KsNoHook, typename Fin2 = KsNoFin2, int AD = 1>
+template <int KS, int STRIDE, int WM, int WN, int WK, int PD = 2, typename Fin, typename Hook = KsNoHook, typename Fin2 = KsNoFin2>
 __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W, int ldx, int Cin, const float *wp, int NT,
                                                  int nt0, int oy0, int ox0, int c_begin, int c_end, float *lds, Fin fin,
                                                  Hook hook = Hook(), const float *wp2 = nullptr, Fin2 fin2 = Fin2())
@@ -74,8 +67,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
     constexpr int S = KS * KS;                       // steps (taps) per chunk and wave
     constexpr int D = PD;                            // B prefetch distance (steps)
     constexpr int R = D + 1;                         // register ring
-    constexpr int U0 = (S % R == 0) ? 1 : R;         // chunk unroll so that the B ring slots stay static ...
-    constexpr int U = (U0 % AD == 0) ? U0 : U0 * AD; // ... and the A ring slots too
+    constexpr int U = (S % R == 0) ? 1 : R;          // chunk unroll so that ring slots stay static
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -100,21 +92,21 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
             goff[r] = -1;
         }
     }
-    f32x4 stage[AD][C::NR];                          // A ring: chunk c sits in slot (c - c_begin) % AD until it is stored
-    auto stage_load = [&](int slot, int chunk) {
+    f32x4 stage[C::NR];
+    auto stage_load = [&](int chunk) {
         const int coff = chunk * (16 * WK);
 #pragma unroll
         for (int r = 0; r < C::NR; ++r) {
             const bool ok = goff[r] >= 0;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
-            stage[slot][r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
     };
-    auto stage_store = [&](int slot, int buf) {
+    auto stage_store = [&](int buf) {
         float *dst = lds + buf * C::BUF;
 #pragma unroll
         for (int r = 0; r < C::NR; ++r)
-            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[slot][r];
+            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
     };
 
     const int li = lane & 15, lg = lane >> 4;
@@ -150,13 +142,12 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
 
     if (c_begin < c_end) {
         // all first-use global loads go out together (one memory round trip before the first MFMA)
-#pragma unroll
-        for (int k = 0; k < AD; ++k) stage_load(k, min(c_begin + k, c_end - 1));
+        stage_load(c_begin);
         f32x4 breg[R][WN];
 #pragma unroll
         for (int p = 0; p < D; ++p) load_b(breg[p % R], c_begin + p / S, p % S);
         CT_KS_STAMP(2);
-        stage_store(0, 0);
+        stage_store(0);
         __syncthreads();
         CT_KS_STAMP(3);
         for (int c0 = c_begin; c0 < c_end; c0 += U) {
@@ -165,8 +156,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                 const int c = c0 + u;
                 if (c < c_end) {
                     const int cur = (c - c_begin) & 1;
-                    // (slot u % AD held chunk c, stored to LDS at the end of the previous chunk: free again)
-                    stage_load(u % AD, min(c + AD, c_end - 1));
+                    stage_load(min(c + 1, c_end - 1));
                     __builtin_amdgcn_sched_barrier(0x386);
                     hook(c, lds + cur * C::BUF);
                     const float *buf = lds + cur * C::BUF + wave * C::SLAB;
@@ -221,7 +211,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                             }
                         }
                     }
-                    if (c + 1 < c_end) stage_store((u + 1) % AD, cur ^ 1);
+                    if (c + 1 < c_end) stage_store(cur ^ 1);
                     __syncthreads();
                 }
             }

@@ -72,19 +72,13 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 // pixel over the 8 blocks; the partial sums of the 4 channel quads (lanes) and the 2 n-tiles (waves) are added in a
 // fixed order, then bias, sigmoid / depth transform (detector.py:300-308) and ONE NCHW store per output value.  The
 // 256-channel intermediate (84 MB per frame at 512x512 with 5 heads) is neither written nor read back.
-// DEEP (algo 221..227, the latency shapes of round 4, see ksplit_core.h): the B ring is 8 steps deep (7 in flight)
-// instead of 4 (3 in flight).  At one stream the deep levels are 256 workgroups of 8 / 16 waves, one per CU, and a
-// step is 4 * WM * WN MFMAs = 128 .. 256 clocks against a ~2300-clock round trip for a weight fragment into the cold L2:
-// the chunk loops of the 64x64 / 32x32 layers took 6.4 / 7.8 us for 3.9 us of matrix time (s_memtime stamps,
-// profiles/r04_b_conv_phases_b1.txt).  Same MFMA order, bit-identical results.
-template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false, bool DEEP = false>
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 // (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
 __global__ __launch_bounds__(256 * KS)
-__attribute__((amdgpu_waves_per_eu(NB > 1 ? 3 : (DEEP ? KS : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS)))))
+__attribute__((amdgpu_waves_per_eu(NB > 1 ? 3 : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
 void wino_conv_kernel(WinoArgs a)
 {
     static_assert(NB == 1 || (!MULTI && KS == 1), "NB > 1 is a single-chunk, unsplit shape");
-    static_assert(!DEEP || NB == 1, "the latency shapes are the NB == 1 ones");
     static_assert(!HEADS || (NB == 8 && WM == 1 && WN == 2), "the fused heads run on 64 px x 8 blocks of 32 couts");
     using C = WCfg<WM>;
     constexpr int NTHR = 256 * KS;
@@ -175,10 +169,7 @@ void wino_conv_kernel(WinoArgs a)
     const int NCH16 = a.Cin >> 4;
     const size_t slab_stride = (size_t)a.NT << 8;
     constexpr int SPK = 4 / KS;                     // slabs of a chunk per K part
-    constexpr int S = 16 / KS;                      // steps per chunk and wave
-    constexpr int D = DEEP ? 7 : 3, R = D + 1;      // B prefetched D steps ahead into a ring of R
-    constexpr int U = (S % R == 0) ? 1 : R / S;     // chunk unroll that keeps the ring slots static (S = 4, R = 8: 2)
-    static_assert((S % R == 0) || (R % S == 0), "ring / steps per chunk");
+    constexpr int S = 16 / KS, D = 3, R = 4;       // steps per chunk and wave, B prefetched 3 steps ahead, ring of 4
     float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
     constexpr int TN = WM * WN;
     float *ybuf = lds + KS * 4 * 2 * TN * 256;      // per-wave 32 x 16 transpose slabs behind the exchange buffer
@@ -280,11 +271,7 @@ void wino_conv_kernel(WinoArgs a)
         __syncthreads();
         CT_STAMP(3);
         const int nchunks = MULTI ? a.nchunks : 1;
-        for (int ch0 = 0; ch0 < nchunks; ch0 += U) {
-#pragma unroll
-          for (int u = 0; u < U; ++u) {
-            const int ch = ch0 + u;
-            if (ch >= nchunks) break;                 // (uniform)
+        for (int ch = 0; ch < nchunks; ++ch) {
             const int cur = ch & 1;
             if (MULTI) {
                 stage_load(min(ch + 1, a.nchunks - 1));
@@ -299,9 +286,8 @@ void wino_conv_kernel(WinoArgs a)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int s = ks * 4 + c;
-                    const int g = u * S + s;          // static position in the unrolled body: ring slots g % R
                     const int sp = s + D;
-                    load_b(breg[(g + D) % R], ch + sp / S, sp % S);
+                    load_b(breg[(s + D) % R], ch + sp / S, sp % S);
                     __builtin_amdgcn_sched_barrier(0x386);
 #pragma unroll
                     for (int ee = 0; ee < 4; ++ee)
@@ -309,13 +295,12 @@ void wino_conv_kernel(WinoArgs a)
                         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
                             for (int nt = 0; nt < WN; ++nt)
-                                acc[mt][c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[mt][c][ee], breg[g % R][nt][ee],
+                                acc[mt][c][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[mt][c][ee], breg[s % R][nt][ee],
                                                                                      acc[mt][c][nt], 0, 0, 0);
                 }
             }
             if (MULTI && ch + 1 < a.nchunks) stage_store(cur ^ 1);
             __syncthreads();
-          }
         }
     }
 
@@ -499,11 +484,11 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, floa
     p[idx] = u;
 }
 
-template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false, bool DEEP = false>
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
     using C = WCfg<WM>;
-    auto k = wino_conv_kernel<WM, WN, KS, MULTI, NB, HEADS, DEEP>;
+    auto k = wino_conv_kernel<WM, WN, KS, MULTI, NB, HEADS>;
     const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
     const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256 + 4 * KS * 32 * 16 + (HEADS ? 8 * 256 + 2 * 64 * 2 * 8 : 0));
     const size_t lds = patch > exch ? patch : exch;
@@ -515,11 +500,11 @@ int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
     hipLaunchKernelGGL(k, grid, dim3(256 * KS), lds, s, a);
     return CT_OK;
 }
-template <int WM, int WN, int KS, bool DEEP = false>
+template <int WM, int WN, int KS>
 int launch_wino(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
-    if (KS > 1) return launch_wino2<WM, WN, KS, true, 1, false, DEEP>(a, grid, s);      // (K-split instances are for the deep levels)
-    return a.nchunks > 1 ? launch_wino2<WM, WN, KS, true, 1, false, DEEP>(a, grid, s) : launch_wino2<WM, WN, KS, false, 1, false, DEEP>(a, grid, s);
+    if (KS > 1) return launch_wino2<WM, WN, KS, true>(a, grid, s);      // (K-split instances are for the deep levels)
+    return a.nchunks > 1 ? launch_wino2<WM, WN, KS, true>(a, grid, s) : launch_wino2<WM, WN, KS, false>(a, grid, s);
 }
 
 }  // namespace
@@ -548,14 +533,9 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     // algo 201: 64 px x 64 couts, 202: 64 x 32, 203: 128 x 32, 204: 128 x 16 per workgroup of 4 waves;
     // 205 / 206: 64 x 32 with K split over 2 / 4 wave groups (8 / 16 waves), 207: 64 x 16 with K split 4;
     // 208..211: 64 x 32 walking 2 / 4 / 5 / 8 cout blocks per workgroup on one input transform (Cin == 64 only)
-    // 221..227: the latency shapes (deep weight prefetch, bit-identical results) of 201..207
-    const bool deep = d->algo >= 221 && d->algo <= 227;
-    // (64 x 32 with K split over 4 wave groups: 1024 threads cap a wave at 128 VGPRs, the deep ring would spill)
-    if (d->algo == 226) CT_FAIL_ARG("ct_conv2d: algo 206 has no latency shape (226)");
-    const int algo = deep ? d->algo - 20 : d->algo;
-    const int WM = (algo == 203 || algo == 204) ? 2 : 1;
-    const int WN = (algo == 201) ? 4 : ((algo == 204 || algo == 207) ? 1 : 2);
-    const int NB = algo == 208 ? 2 : (algo == 209 ? 4 : (algo == 210 ? 5 : (algo == 211 ? 8 : 1)));
+    const int WM = (d->algo == 203 || d->algo == 204) ? 2 : 1;
+    const int WN = (d->algo == 201) ? 4 : ((d->algo == 204 || d->algo == 207) ? 1 : 2);
+    const int NB = d->algo == 208 ? 2 : (d->algo == 209 ? 4 : (d->algo == 210 ? 5 : (d->algo == 211 ? 8 : 1)));
     if (NB > 1 && d->Cin != 64) CT_FAIL_ARG("ct_conv2d: algo %d is for Cin == 64 (got %d)", d->algo, d->Cin);
     WinoArgs a;
     a.x = d->x; a.up = d->w_winograd;
@@ -570,19 +550,6 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     const dim3 grid((unsigned)blocks);
     hipStream_t st = (hipStream_t)stream;
     int rc;
-    if (deep) {
-        switch (algo) {
-        case 201: rc = launch_wino<1, 4, 1, true>(a, grid, st); break;
-        case 202: rc = launch_wino<1, 2, 1, true>(a, grid, st); break;
-        case 203: rc = launch_wino<2, 2, 1, true>(a, grid, st); break;
-        case 204: rc = launch_wino<2, 1, 1, true>(a, grid, st); break;
-        case 205: rc = launch_wino<1, 2, 2, true>(a, grid, st); break;
-        case 206: rc = launch_wino<1, 2, 4, true>(a, grid, st); break;
-        default: rc = launch_wino<1, 1, 4, true>(a, grid, st); break;
-        }
-        CT_CHECK_LAUNCH("ct_conv2d(winograd, latency shape)");
-        return rc;
-    }
     switch (d->algo) {
     case 201: rc = launch_wino<1, 4, 1>(a, grid, st); break;
     case 202: rc = launch_wino<1, 2, 1>(a, grid, st); break;

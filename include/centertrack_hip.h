@@ -86,12 +86,6 @@ typedef struct ct_conv_desc {
                                                    208..211: 64 x 32 walking 2 / 4 / 5 / 8 cout blocks per workgroup
                                                    on one input transform (Cin == 64)
                                                    (3x3 stride 1, Cin % 64 == 0, NHWC output, needs w_winograd);
-                                                   round 4, the "latency" shapes -- the same tiles with the weight
-                                                   fragments prefetched 8 steps ahead instead of 2-3, for launches
-                                                   of one workgroup per CU whose every weight fetch is a round trip
-                                                   into a cold L2; same MFMA order, bit-identical results: 11..18
-                                                   (3x3 only) = 1..8, 111..115 = 101..105 (the 1x1 shapes also keep
-                                                   three chunks of input in flight), 221..225, 227 = 201..205, 207;
                                                    picked per layer by the host-side autotuner */
     const float *w_winograd;                    /* ct_pack_winograd_weight() of the same OIHW weight, or NULL */
     /* optional side output of a 3x3 stride-2 conv (round 3): the 2x2 / stride-2 max-pool of its INPUT, NHWC [N, H/2, W/2,

@@ -215,61 +215,16 @@ def test_conv2d_winograd_matches_torch(device, algo, N, H, W, Cin, Cout):
     _close(out.to_nchw(), y, atol=5e-4, msg='winograd conv')
 
 
-LATENCY_CASES = [
-    # (shallow algo, latency algo, N, H, W, Cin, Cout, ks, stride)
-    (3, 13, 1, 12, 20, 64, 64, 3, 1), (5, 15, 2, 9, 21, 32, 80, 3, 1), (1, 11, 1, 20, 20, 16, 16, 3, 1),
-    (2, 12, 1, 16, 32, 16, 32, 3, 2), (8, 18, 1, 8, 8, 64, 27, 3, 1), (6, 16, 1, 17, 30, 48, 64, 3, 2),
-    (101, 111, 1, 9, 21, 128, 128, 3, 1), (102, 112, 2, 5, 16, 256, 96, 3, 1), (103, 113, 1, 4, 4, 512, 512, 3, 1),
-    (104, 114, 1, 16, 16, 64, 64, 3, 1), (105, 115, 1, 8, 8, 256, 256, 3, 1), (103, 113, 1, 17, 30, 512, 512, 3, 1),
-    (101, 111, 1, 8, 12, 448, 128, 1, 1), (103, 113, 1, 4, 4, 1280, 512, 1, 1), (102, 112, 1, 8, 8, 64, 128, 1, 1),
-    (102, 112, 1, 17, 30, 192, 64, 1, 1), (105, 115, 2, 6, 10, 896, 256, 1, 1), (104, 114, 1, 9, 17, 128, 64, 1, 1),
-    (101, 111, 1, 16, 16, 64, 128, 3, 2), (102, 112, 1, 8, 8, 128, 256, 3, 2), (104, 114, 1, 10, 18, 128, 64, 3, 2),
-    (103, 113, 1, 34, 60, 256, 512, 3, 2),
-    (201, 221, 1, 16, 32, 64, 64, 3, 1), (202, 222, 2, 9, 21, 64, 48, 3, 1), (201, 221, 1, 8, 16, 128, 256, 3, 1),
-    (203, 223, 1, 8, 16, 128, 64, 3, 1), (204, 224, 1, 10, 18, 192, 40, 3, 1), (205, 225, 1, 9, 17, 128, 96, 3, 1),
-    (207, 227, 2, 4, 4, 512, 48, 3, 1), (205, 225, 1, 34, 60, 256, 256, 3, 1), (207, 227, 1, 17, 30, 512, 512, 3, 1),
-    (207, 227, 1, 8, 8, 64, 32, 3, 1), (202, 222, 1, 12, 20, 192, 64, 3, 1),
-]
-
-
-@pytest.mark.parametrize('case', LATENCY_CASES, ids=lambda c: 'a%d_a%d_N%d_%dx%d_%d-%d_k%ds%d' % c)
-def test_latency_shapes_are_bit_identical_to_their_shallow_twins(device, case):
-    """round 4: algo 11..18 / 111..115 / 221..227 are the row-tiled / K-split / Winograd tiles with the weight fragments
-    prefetched 8 steps ahead (and, 1x1 K-split shapes, three chunks of input in flight): a scheduling change only -- the
-    MFMA order is the same, so the outputs are BIT-identical to the shallow shapes' (which the other tests pin to torch);
-    ragged maps (17 x 30, 9 x 21), one to twenty chunks, Cout not a multiple of the tile"""
-    from centertrack_amd import ops
-    a0, a1, N, H, W, Cin, Cout, ks, stride = case
-    x = F.relu(_rand(N, Cin, H, W, seed=160))
-    w = _rand(Cout, Cin, ks, ks, seed=161, scale=(Cin * ks * ks) ** -0.5)
-    scale = torch.rand(Cout, generator=torch.Generator().manual_seed(162)) + 0.5
-    shift = _rand(Cout, seed=163)
-    Ho, Wo = (H + 2 * (ks // 2) - ks) // stride + 1, (W + 2 * (ks // 2) - ks) // stride + 1
-    res = _rand(N, Cout, Ho, Wo, seed=164)
-    wd = w.to(device)
-    wino = ops.pack_winograd(wd) if a0 >= 201 else None
-    outs = []
-    for algo in (a0, a1):
-        o = ops.conv2d(ops.view_from_nchw(x.to(device)), ops.pack_weight(wd), Cout, ks, stride, scale=scale.to(device),
-                       shift=shift.to(device), res=ops.view_from_nchw(res.to(device)), relu=True, split_k=1, algo=algo,
-                       w_wino=wino)
-        torch.cuda.synchronize()
-        outs.append(o.to_nchw().cpu())
-    y = F.relu(F.conv2d(x, w, None, stride=stride, padding=ks // 2) * scale.view(1, -1, 1, 1) + shift.view(1, -1, 1, 1) + res)
-    _close(outs[0], y, atol=5e-4, msg='algo %d' % a0)
-    assert torch.equal(outs[0], outs[1]), 'algo %d differs from algo %d by up to %g' % (a1, a0, float((outs[0] - outs[1]).abs().max()))
-
-
 @pytest.mark.parametrize('algo,N,H,W,Cin,Cout', [
     (1, 1, 32, 64, 16, 16), (2, 2, 16, 32, 16, 32), (3, 1, 32, 32, 32, 64), (4, 1, 16, 32, 64, 160), (5, 1, 8, 16, 64, 64),
-    (6, 1, 34, 60, 32, 64), (7, 1, 32, 64, 16, 32), (8, 2, 16, 16, 48, 16), (13, 1, 32, 32, 32, 64), (15, 1, 34, 60, 64, 128),
+    (6, 1, 34, 60, 32, 64), (7, 1, 32, 64, 16, 32), (8, 2, 16, 16, 48, 16), (3, 1, 34, 60, 64, 128),
     (101, 1, 16, 16, 64, 128), (102, 1, 8, 8, 128, 256), (103, 1, 4, 4, 256, 512), (104, 1, 12, 20, 128, 64),
-    (102, 2, 6, 10, 256, 96), (111, 1, 34, 60, 64, 128), (112, 1, 8, 8, 128, 256), (113, 1, 34, 60, 256, 512), (114, 1, 12, 20, 128, 64),
+    (102, 2, 6, 10, 256, 96), (101, 1, 34, 60, 64, 128), (103, 1, 34, 60, 256, 512),
 ])
 def test_conv2d_stride2_fused_projection(device, algo, N, H, W, Cin, Cout):
     """round 4: Tree.project of the pooled input (dla.py:196-203,207,217-218: conv1x1 + BN of max_pool2d(x, 2, 2), no
-    ReLU -- the residual tree1 adds) as a SECOND output of the 3x3 stride-2 launch, every row-tiled / K-split shape and
-    their latency twins: equal to torch's pool -> conv1x1 -> affine, the main output and the pool side output unchanged
+    ReLU -- the residual tree1 adds) as a SECOND output of the 3x3 stride-2 launch, every row-tiled / K-split shape:
+    equal to torch's pool -> conv1x1 -> affine, the main output and the pool side output unchanged
     (bit for bit), with and without the pool side output"""
     from centertrack_amd import ops
     x = _rand(N, Cin, H, W, seed=190 + algo)

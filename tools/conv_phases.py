@@ -49,6 +49,9 @@ def main():
     ap.add_argument('--config', default='mot17_512')
     ap.add_argument('--streams', type=int, default=1)
     ap.add_argument('--only', default='stem,conv,wino')
+    ap.add_argument('--force', default='', help="launch-name substring=algo[,..]: run those launches with another algo code, e.g. "
+                                                 "'level3.tree2=225,level5.t2=113' (3x3 stride-1 launches only keep their weights)")
+    ap.add_argument('--reps', type=int, default=1, help='print the mean over this many stamped runs')
     args = ap.parse_args()
     if args.build:
         return build()
@@ -69,6 +72,13 @@ def main():
     model.forward_plan(plan, x, x, torch.zeros(B, 1, H, Wd, device='cuda'))
     torch.cuda.synchronize()
     raw = ctypes.CDLL(LIB)
+    forced = [f.split('=') for f in args.force.split(',') if f]
+    for l in plan['launches']:
+        if l.fn == 'conv':
+            for sub, algo in forced:
+                if sub in l.name:
+                    l.args.algo, l.args.split_k = int(algo), 1
+                    l.name = '%s @%s' % (l.name, algo)
     NB, WORDS = 8192, 12
     host = np.zeros(NB * WORDS, dtype=np.uint64)
     kinds = [k for k in args.only.split(',') if k]
