@@ -24,14 +24,21 @@ north_star's bar, as asserted here:
 import numpy as np
 
 TIE = 1e-5
+# rank-tie width of the streams NOBODY PICKED (tests/test_hip_plans.py): tools/tie_report.py measured, over 1664 full-size
+# frames with nothing re-seeded, 14 rank swaps between detections whose oracle scores lie up to 4e-5 apart
+# (profiles/r03_tie_report.json, `rank_swaps.max_oracle_score_gap`) -- fp32 noise of a 50-layer network on a sigmoid
+# score is ~1e-5 (|dscore| max 1.4e-5 in tests/test_hip_tie_policy.py), so two scores 2-4e-5 apart can land either way
+# round.  The hand-picked streams of the full-size tests keep the 1e-5 width.
+RANK_TIE_UNPICKED = 5e-5
 ATOL = 1e-3
 GRID_FIELDS = ('bboxes', 'bboxes_amodal', 'tracking', 'rot', 'dim', 'amodel_offset', 'nuscenes_att', 'velocity')
 
 
 class StreamParity(object):
-    def __init__(self, tag, strict=False, on_threshold_tie='refuse'):
+    def __init__(self, tag, strict=False, on_threshold_tie='refuse', rank_tie=TIE):
         self.tag = tag
         self.strict = strict
+        self.rank_tie = rank_tie    # consecutive oracle ranks closer than this form one tie group (may swap among themselves)
         # 'refuse': a threshold tie is a defect of the TEST DATA (hand-picked streams); 'stop': the stream is compared
         # up to the frame before the tie and the event is recorded in ``stopped`` (streams nobody picked: the plans
         # that are benchmarked, tools/tie_report.py measures how often this happens and what the HIP path does then)
@@ -67,7 +74,7 @@ class StreamParity(object):
         np.testing.assert_allclose(gd['scores'][gb, :n], sc[:n], atol=ATOL, err_msg=tag + ' scores')
         groups, a = [], 0
         for i in range(1, n + 1):
-            if i == n or sc[i - 1] - sc[i] >= TIE:
+            if i == n or sc[i - 1] - sc[i] >= self.rank_tie:
                 groups.append((a, i))
                 a = i
         assert len(groups) >= 0.75 * n, '%s: degenerate stream (mostly near-ties): %d groups of %d' % (tag, len(groups), n)
@@ -194,7 +201,8 @@ def setup_config(name, streams, **optkw):
     return cfg, opt, oopt, model, det, oracles, meta, px_per_cell
 
 
-def run_config(name, streams, T, strict=False, min_tracks=5, seed0=317 + 7, sample=None, on_threshold_tie='refuse', **kw):
+def run_config(name, streams, T, strict=False, min_tracks=5, seed0=317 + 7, sample=None, on_threshold_tie='refuse',
+               rank_tie=TIE, **kw):
     """``streams`` streams advance T frames through ONE StreamDetector (the launch plan of that stream count); the
     streams in ``sample`` (default: all) are compared with the CPU oracle frame by frame.  Returns (checks, swaps, det)."""
     import torch
@@ -202,7 +210,8 @@ def run_config(name, streams, T, strict=False, min_tracks=5, seed0=317 + 7, samp
     H, W = cfg['H'], cfg['W']
     sample = list(range(streams)) if sample is None else list(sample)
     frames = [scrolled_stream(H, W, T, seed0 + 100 * s) for s in range(streams)]
-    checks = {s: StreamParity('%s x%d stream %d' % (name, streams, s), strict=strict, on_threshold_tie=on_threshold_tie)
+    checks = {s: StreamParity('%s x%d stream %d' % (name, streams, s), strict=strict, on_threshold_tie=on_threshold_tie,
+                              rank_tie=rank_tie)
               for s in sample}
     for t in range(T):
         res = det.step(torch.cat([frames[s][t] for s in range(streams)], 0), [dict(meta) for _ in range(streams)])

@@ -15,13 +15,13 @@ on the 16- / 32-stream plans and nusc x 8 (ids carried over seven times; tools/t
 and four more for 16-32 frames) -- and the oracle follows a sample of the streams (first, middle, last: the CPU forward
 is 0.25-1 s per frame).  Same
 assertions as the full-size tests (tests/_parity.py): top-K entries / classes / ranks identical above the threshold up
-to tie groups < 1e-5, values within 1e-3 on the output grid, track ids a bijection that is the identity except for
+to tie groups (consecutive oracle ranks < 5e-5 apart: the measured width of fp32 rank noise, tests/_parity.py), values within 1e-3 on the output grid, track ids a bijection that is the identity except for
 enumerated birth ties.  The streams are NOT hand-picked: a stream that runs into a threshold tie (an oracle score within
 1e-5 of a threshold) is compared up to that frame, and at least two thirds of all sampled frames must have been compared.
 """
 import pytest
 
-from _parity import run_config
+from _parity import RANK_TIE_UNPICKED, run_config
 
 pytestmark = pytest.mark.gpu
 
@@ -42,7 +42,8 @@ CASES = [
 def test_benchmarked_plan_matches_oracle(device, name, streams, sample, T):
     import scenarios as S
     from centertrack_amd import autotune
-    checks, swaps, det = run_config(name, streams, T, sample=sample, on_threshold_tie='stop', min_tracks=5)
+    checks, swaps, det = run_config(name, streams, T, sample=sample, on_threshold_tie='stop', min_tracks=5,
+                                    rank_tie=RANK_TIE_UNPICKED)
     # the plan under test is the one the pinned table prescribes for this (batch, size): the benchmarked one
     cfg = S.CONFIGS[name]
     NB = streams * (2 if cfg['flip'] else 1)
