@@ -71,9 +71,7 @@ class HeadsDesc(ctypes.Structure):
                 ('cout', ctypes.c_int * CT_MAX_FUSED_HEADS), ('coff', ctypes.c_int * CT_MAX_FUSED_HEADS),
                 ('out', ctypes.c_void_p), ('ctot', ctypes.c_int),
                 ('sig_lo', ctypes.c_int), ('sig_hi', ctypes.c_int), ('dep_lo', ctypes.c_int), ('dep_hi', ctypes.c_int),
-                ('depth_scale', ctypes.c_float),
-                ('w2_wide', ctypes.c_void_p * CT_MAX_FUSED_HEADS), ('b2_wide', ctypes.c_void_p * CT_MAX_FUSED_HEADS),
-                ('sig_wide', ctypes.c_int * CT_MAX_FUSED_HEADS)]
+                ('depth_scale', ctypes.c_float)]
 
 
 class DecodeDesc(ctypes.Structure):

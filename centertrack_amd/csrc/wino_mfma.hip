@@ -36,13 +36,6 @@ struct WinoArgs {
     float *hout;              // [N, hctot, H, W]
     int hctot;
     int hcout[CT_MAX_FUSED_HEADS], hcoff[CT_MAX_FUSED_HEADS];
-    // head of the cb-th workgroup group of this launch (a launch takes the narrow or the wide heads of a descriptor)
-    int hmap[CT_MAX_FUSED_HEADS];
-    // wide heads (HEADS == 2, round 4): per head the packed [c, 256, 1, 1] output-layer weight (ct_pack_conv_weight) and
-    // whether its outputs get a sigmoid (hm of a many-class model, hm_hp)
-    const float *hw2p[CT_MAX_FUSED_HEADS];
-    const float *hb2w[CT_MAX_FUSED_HEADS];
-    int hsig[CT_MAX_FUSED_HEADS];
 };
 
 // WM = m-tiles (blocks of 4 x 16 output pixels = 16 Winograd tiles) stacked vertically per workgroup
@@ -79,21 +72,14 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 // pixel over the 8 blocks; the partial sums of the 4 channel quads (lanes) and the 2 n-tiles (waves) are added in a
 // fixed order, then bias, sigmoid / depth transform (detector.py:300-308) and ONE NCHW store per output value.  The
 // 256-channel intermediate (84 MB per frame at 512x512 with 5 heads) is neither written nor read back.
-// HEADS == 2 (round 4): heads with MORE than 8 output channels (80-class hm, hps, hm_hp).  Same workgroup -- 64 pixels x
-// the 256 hidden channels of one head in 8 blocks of 32 -- but the 1x1 output layer runs on the matrix cores: after the
-// output transform of a block the 64 x 32 tile of hidden activations (bias, ReLU) is laid out pixel-major in LDS, wave w
-// takes the w-th row of 16 pixels as its M tile and contracts the block's 32 channels with the head's packed 1x1
-// weights into <= 5 accumulators (80 couts) that live across the 8 blocks: 8 MFMAs per n-tile and block, 40 for 80
-// classes next to the 128 of the 3x3 part.  The 16.8 MB hidden map per head and frame (written by a conv3x3 launch,
-// re-read by a conv1x1 launch until round 3) never exists.
-template <int WM, int WN, int KS, bool MULTI, int NB = 1, int HEADS = 0>
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 // (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
 __global__ __launch_bounds__(256 * KS)
 __attribute__((amdgpu_waves_per_eu(NB > 1 ? 3 : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
 void wino_conv_kernel(WinoArgs a)
 {
     static_assert(NB == 1 || (!MULTI && KS == 1), "NB > 1 is a single-chunk, unsplit shape");
-    static_assert(!HEADS || (NB == 8 && WM == 1 && WN == 2 && KS == 1), "the fused heads run on 64 px x 8 blocks of 32 couts");
+    static_assert(!HEADS || (NB == 8 && WM == 1 && WN == 2), "the fused heads run on 64 px x 8 blocks of 32 couts");
     using C = WCfg<WM>;
     constexpr int NTHR = 256 * KS;
     constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS;
@@ -107,9 +93,6 @@ void wino_conv_kernel(WinoArgs a)
     const int wave = wv & 3, kp = wv >> 2;
     const int li = lane & 15, lg = lane >> 4;
 
-    constexpr bool NARROW = HEADS == 1, WIDE = HEADS == 2;
-    constexpr int NTW = 5;                          // n-tiles of a wide head's output layer (<= 80 channels)
-    constexpr int HP = 36;                          // pitch of the hidden-activation tile [64 px][32 ch] (16-byte aligned rows)
     int bid = blockIdx.x;
     int cb;
     if (HEADS && a.headMajor) {
@@ -122,8 +105,6 @@ void wino_conv_kernel(WinoArgs a)
     } else {
         cb = ct_block_cout(bid, a.coutBlocks, a.xcdPer);
     }
-    const int head = HEADS ? a.hmap[cb] : 0;        // (uniform) head of the descriptor this workgroup works on
-    if (HEADS) cb = head;                           // ... whose 256 hidden channels are cout blocks head*NB .. of `up`
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
@@ -194,15 +175,8 @@ void wino_conv_kernel(WinoArgs a)
     float *ybuf = lds + KS * 4 * 2 * TN * 256;      // per-wave 32 x 16 transpose slabs behind the exchange buffer
     float *w2l = ybuf + 4 * KS * 32 * 16;           // HEADS: the head's [8][256] output-layer weights ...
     float *hred = w2l + 8 * 256;                    // ... and the n-tile-1 waves' partial sums [2][64][2][8]
-    float hacc[NARROW ? 2 : 1][NARROW ? 8 : 1];     // HEADS == 1: output channels of this lane's two pixels, its 4-channel quads
-    f32x4 wacc[WIDE ? NTW : 1];                     // HEADS == 2: this wave's 16 pixels x 16 couts per n-tile of the output layer
-    float *htile = ybuf;                            // HEADS == 2: hidden activations of a block, [64 px][HP] (aliases ybuf + w2l)
-    const int ntw = WIDE ? (a.hcout[cb] + 15) >> 4 : 0;          // (uniform)
-    if (WIDE) {
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) wacc[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    }
-    if (NARROW) {
+    float hacc[HEADS ? 2 : 1][HEADS ? 8 : 1];       // HEADS: output channels of this lane's two pixels, its 4-channel quads
+    if (HEADS) {
 #pragma unroll
         for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll
@@ -240,7 +214,7 @@ void wino_conv_kernel(WinoArgs a)
 #pragma unroll
         for (int kk = 0; kk < (NB > 1 ? 4 : 1); ++kk) transform(vall[kk], lds, kk);
         __syncthreads();                            // the patch is dead from here on: its LDS becomes the exchange buffer
-        if (NARROW) {                               // (visible to every wave after the first block's exchange barrier)
+        if (HEADS) {                                // (visible to every wave after the first block's exchange barrier)
             const float *src = a.hw2 + (size_t)cb * 2048;
             *reinterpret_cast<f32x4 *>(w2l + tid * 4) = *reinterpret_cast<const f32x4 *>(src + tid * 4);
             *reinterpret_cast<f32x4 *>(w2l + 1024 + tid * 4) = *reinterpret_cast<const f32x4 *>(src + 1024 + tid * 4);
@@ -362,18 +336,7 @@ void wino_conv_kernel(WinoArgs a)
             const f32x4 y0 = t[0] + t[1] + t[2];
             const f32x4 y1 = t[1] - t[2] - t[3];
             const int co = (nt0 + nt) * 16 + li;
-            if (WIDE) {
-                // hidden activations of this job (pixels of x-parity q, channels of n-tile nt) into the pixel-major tile:
-                // pixel (row 2*trow + p, column 2*tcol + q) of the 4 x 16 block -> row (2*trow + p) * 16 + 2*tcol + q
-                const float sh = a.epi.shift[co];
-#pragma unroll
-                for (int ee = 0; ee < 4; ++ee) {
-                    const int tile = lg * 4 + ee;
-                    const int pix = (2 * (tile >> 3)) * 16 + 2 * (tile & 7) + q;
-                    htile[pix * HP + nt * 16 + li] = fmaxf(y0[ee] + sh, 0.0f);
-                    htile[(pix + 16) * HP + nt * 16 + li] = fmaxf(y1[ee] + sh, 0.0f);
-                }
-            } else if (NARROW) {
+            if (HEADS) {
                 float *yb = ybuf + wv * (32 * 16);
 #pragma unroll
                 for (int ee = 0; ee < 4; ++ee) {
@@ -452,57 +415,11 @@ void wino_conv_kernel(WinoArgs a)
             }
         }
     }
-    if (WIDE) {
-        __syncthreads();                            // the block's 64 x 32 hidden tile is complete
-        // output layer on the matrix cores: M tile = pixel row wv of the block, K = the block's 32 hidden channels
-        const float *w2p = a.hw2p[cb] + ((size_t)(nb * 2) * ntw << 8) + (lane << 2);
-#pragma unroll
-        for (int sl = 0; sl < 2; ++sl) {
-            const f32x4 av = *reinterpret_cast<const f32x4 *>(htile + (wv * 16 + li) * HP + sl * 16 + lg * 4);
-#pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) {
-                if (nt < ntw) {                     // (uniform)
-                    const f32x4 bv = *reinterpret_cast<const f32x4 *>(w2p + ((size_t)(sl * ntw + nt) << 8));
-#pragma unroll
-                    for (int ee = 0; ee < 4; ++ee)
-                        wacc[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ee], bv[ee], wacc[nt], 0, 0, 0);
-                }
-            }
-        }
-    }
     if (NB > 1) __syncthreads();                    // every job has read the exchange buffer: the next block may overwrite it
     }                                               // (cout block nb)
     if (NB > 1) CT_STAMP(5);
     if (!HEADS) { CT_STAMP(6); CT_STAMP_RT(7); }
-    if (WIDE) {
-        // wave wv: pixel row oy0 + wv; lane: couts nt*16 + li, pixels ox0 + 4*lg .. +3 (C / D layout of the 16 x 16 tile)
-        const int hc = a.hcout[cb], g0 = a.hcoff[cb];
-        const bool sig = a.hsig[cb] != 0;
-        const int oy = oy0 + wv, oxb = ox0 + lg * 4;
-        const size_t plane = (size_t)a.epi.Ho * a.epi.Wo;
-#pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) {
-            const int c = nt * 16 + li;
-            if (nt < ntw && c < hc && oy < a.epi.Ho) {
-                const float b = a.hb2w[cb][c];
-                float v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    v[e] = wacc[nt][e] + b;
-                    if (sig) v[e] = 1.0f / (1.0f + expf(-v[e]));
-                }
-                float *dst = a.hout + ((size_t)n * a.hctot + g0 + c) * plane + (size_t)oy * a.epi.Wo + oxb;
-                if (oxb + 3 < a.epi.Wo && (a.epi.Wo & 3) == 0) {
-                    *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
-                } else {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (oxb + e < a.epi.Wo) dst[e] = v[e];
-                }
-            }
-        }
-    }
-    if (NARROW) {
+    if (HEADS) {
         // wave wv handled (q = wv & 1, n-tile wv >> 1) of every block; lane: pixels tp = (lane + 64 h2) >> 2, quad lane & 3
         const int q = wv & 1, ntile = wv >> 1;
 #pragma unroll
@@ -567,7 +484,7 @@ __global__ __launch_bounds__(256) void pack_winograd_kernel(const float *w, floa
     p[idx] = u;
 }
 
-template <int WM, int WN, int KS, bool MULTI, int NB = 1, int HEADS = 0>
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
 {
     using C = WCfg<WM>;
@@ -575,7 +492,6 @@ int launch_wino2(const WinoArgs &a, dim3 grid, hipStream_t s)
     const size_t patch = sizeof(float) * (size_t)C::BUF * (a.nchunks > 1 ? 2 : 1);
     const size_t exch = sizeof(float) * (size_t)(KS * 4 * 2 * WM * WN * 256 + 4 * KS * 32 * 16 + (HEADS ? 8 * 256 + 2 * 64 * 2 * 8 : 0));
     const size_t lds = patch > exch ? patch : exch;
-    static_assert(HEADS != 2 || 64 * 36 <= 4 * KS * 32 * 16 + 8 * 256, "the hidden tile of the wide heads aliases ybuf + w2l");
     static bool attr_set = false;
     if (!attr_set) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
@@ -664,7 +580,7 @@ extern "C" int ct_heads_fused(const ct_heads_desc *d, void *stream)
     WinoArgs a;
     a.x = d->x; a.up = d->w0_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = 64; a.ldx = d->ldx;
-    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.xcdPer = 0;
+    a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.coutBlocks = d->nheads; a.xcdPer = 0;
     a.headMajor = ct_tune_get(CT_TUNE_HEADS_ORDER) ? 1 : 0;
     a.NT = d->nheads * 16; a.nchunks = 1;
     a.epi.scale = nullptr; a.epi.shift = d->b0; a.epi.res = nullptr; a.epi.y = nullptr;
@@ -672,41 +588,15 @@ extern "C" int ct_heads_fused(const ct_heads_desc *d, void *stream)
     a.epi.flags = 0; a.epi.sig_lo = d->sig_lo; a.epi.sig_hi = d->sig_hi; a.epi.dep_lo = d->dep_lo; a.epi.dep_hi = d->dep_hi;
     a.epi.depth_scale = d->depth_scale;
     a.hw2 = d->w2; a.hb2 = d->b2; a.hout = d->out; a.hctot = d->ctot;
-    int narrow[CT_MAX_FUSED_HEADS], wide[CT_MAX_FUSED_HEADS], nn = 0, nw = 0;
-    for (int i = 0; i < CT_MAX_FUSED_HEADS; ++i) { a.hcout[i] = 0; a.hcoff[i] = 0; a.hmap[i] = 0; a.hw2p[i] = nullptr; a.hb2w[i] = nullptr; a.hsig[i] = 0; }
+    for (int i = 0; i < CT_MAX_FUSED_HEADS; ++i) { a.hcout[i] = 0; a.hcoff[i] = 0; }
     for (int i = 0; i < d->nheads; ++i) {
-        if (d->cout[i] < 1 || d->coff[i] < 0 || d->coff[i] + d->cout[i] > d->ctot)
-            CT_FAIL_ARG("ct_heads_fused: head %d: channels outside [0, ctot)", i);
-        if (d->cout[i] > 8) {
-            // the output layer of a wide head runs on the matrix cores (<= 5 n-tiles of 16 couts)
-            if (d->cout[i] > 80) CT_FAIL_ARG("ct_heads_fused: head %d: at most 80 output channels (got %d)", i, d->cout[i]);
-            if (!d->w2_wide[i] || !d->b2_wide[i] || ((uintptr_t)d->w2_wide[i] & 15))
-                CT_FAIL_ARG("ct_heads_fused: head %d has %d > 8 output channels: w2_wide / b2_wide (ct_pack_conv_weight of its [c, 256, 1, 1] weight, 16-byte aligned) required", i, d->cout[i]);
-            if ((d->coff[i] < d->sig_hi && d->coff[i] + d->cout[i] > d->sig_lo) || (d->coff[i] < d->dep_hi && d->coff[i] + d->cout[i] > d->dep_lo))
-                CT_FAIL_ARG("ct_heads_fused: head %d: a wide head takes its sigmoid from sig_wide, not from the sig / dep ranges", i);
-            a.hw2p[i] = d->w2_wide[i]; a.hb2w[i] = d->b2_wide[i]; a.hsig[i] = d->sig_wide[i];
-            wide[nw++] = i;
-        } else {
-            narrow[nn++] = i;
-        }
+        if (d->cout[i] < 1 || d->cout[i] > 8 || d->coff[i] < 0 || d->coff[i] + d->cout[i] > d->ctot)
+            CT_FAIL_ARG("ct_heads_fused: head %d: 1..8 channels inside [0, ctot)", i);
         a.hcout[i] = d->cout[i]; a.hcoff[i] = d->coff[i];
     }
-    int rc = CT_OK;
-    if (nn > 0) {
-        for (int i = 0; i < nn; ++i) a.hmap[i] = narrow[i];
-        a.coutBlocks = nn;
-        const long blocks = (long)d->N * a.tilesX * a.tilesY * nn;
-        if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_heads_fused: grid too large");
-        rc = launch_wino2<1, 2, 1, false, 8, 1>(a, dim3((unsigned)blocks), (hipStream_t)stream);
-        CT_CHECK_LAUNCH("ct_heads_fused");
-    }
-    if (nw > 0 && rc == CT_OK) {
-        for (int i = 0; i < CT_MAX_FUSED_HEADS; ++i) a.hmap[i] = i < nw ? wide[i] : 0;
-        a.coutBlocks = nw;
-        const long blocks = (long)d->N * a.tilesX * a.tilesY * nw;
-        if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_heads_fused: grid too large");
-        rc = launch_wino2<1, 2, 1, false, 8, 2>(a, dim3((unsigned)blocks), (hipStream_t)stream);
-        CT_CHECK_LAUNCH("ct_heads_fused(wide heads)");
-    }
+    const long blocks = (long)d->N * a.tilesX * a.tilesY * a.coutBlocks;
+    if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_heads_fused: grid too large");
+    const int rc = launch_wino2<1, 2, 1, false, 8, true>(a, dim3((unsigned)blocks), (hipStream_t)stream);
+    CT_CHECK_LAUNCH("ct_heads_fused");
     return rc;
 }

@@ -24,8 +24,6 @@ SMALL_SLOT_WGS = 600      # a MAIN slot with fewer workgroups than this (of 768 
 FUSE_OFFSET = os.environ.get('CENTERTRACK_FUSE_OFFSET', '1') != '0'
 WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
-# heads with more than 8 output channels (80-class hm, hps, hm_hp) in the fused launch too, their 1x1 layer on the matrix cores
-FUSE_WIDE_HEADS = os.environ.get('CENTERTRACK_FUSE_WIDE_HEADS', '1') != '0'
 FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-pools as side outputs of the stride-2 convs
 FUSE_PROJ = os.environ.get('CENTERTRACK_FUSE_PROJ', '1') != '0'       # Tree.project computed by the tree1.conv1 launch (round 4)
 DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
@@ -172,29 +170,18 @@ class DLASegHIP(torch.nn.Module):
                 P['%s.up_%d' % (p, k)] = ops.upsample_weight(sd['%s.up_%d.weight' % (p, k)])
         # heads with <= 8 output channels: ONE launch for conv3x3 + ReLU + conv1x1 of all of them (ct_heads_fused)
         hc = self.head_conv
-        # Round 4: wider heads (<= 80 channels: 80-class hm, hps, hm_hp) join the fused launch with their 1x1 layer on the
-        # matrix cores (ct_heads_desc.w2_wide) and their own sigmoid flag; until then 'hm_hp' stayed out whatever its
-        # width (ONE sigmoid range per launch, taken by 'hm'; detector.py:300-304)
-        def fusable(h, c):
-            if c <= 8:
-                return h != 'hm_hp'                  # (a narrow head takes its sigmoid from the one range 'hm' owns)
-            return FUSE_WIDE_HEADS and c <= 80
-        small = ([h for h, c in self.heads.items() if fusable(h, c)]
+        # ('hm_hp' stays out whatever its width: ct_heads_fused has ONE sigmoid range, taken by 'hm'; the per-head 1x1
+        # tail applies hm_hp's sigmoid, detector.py:300-304)
+        small = ([h for h, c in self.heads.items() if c <= 8 and h != 'hm_hp']
                  if (FUSE_HEADS and WINOGRAD and hc == 256) else [])
         small = small[:_lib.CT_MAX_FUSED_HEADS]
         P['heads_small'] = small
-        P['heads_wide'] = [h for h in small if self.heads[h] > 8]      # output layer on the matrix cores, own sigmoid flag
         if small:
             w0s = torch.cat([sd[h + '.0.weight'] for h in small], 0)
             w2s = torch.zeros((len(small), 8, hc), device=dev)
             b2s = torch.zeros((len(small), 8), device=dev)
-            P['hs_w2_wide'], P['hs_b2_wide'] = {}, {}
             for i, h in enumerate(small):
                 c = self.heads[h]
-                if h in P['heads_wide']:
-                    P['hs_w2_wide'][h] = ops.pack_weight(sd[h + '.2.weight'])
-                    P['hs_b2_wide'][h] = sd[h + '.2.bias'].contiguous()
-                    continue
                 w2s[i, :c] = sd[h + '.2.weight'].reshape(c, hc)
                 b2s[i, :c] = sd[h + '.2.bias']
             P['hs_w0'] = ops.pack_winograd(w0s)
@@ -436,17 +423,14 @@ class DLASegHIP(torch.nn.Module):
         for i, h in enumerate(small):
             c = self.heads[h]
             hd.cout[i], hd.coff[i] = c, c0
-            if h in P['heads_wide']:
-                hd.w2_wide[i], hd.b2_wide[i] = P['hs_w2_wide'][h].data_ptr(), P['hs_b2_wide'][h].data_ptr()
-                hd.sig_wide[i] = 1 if (fuse_sigmoid and h in ('hm', 'hm_hp')) else 0         # detector.py:300-304
-            elif fuse_sigmoid and h == 'hm':
+            if fuse_sigmoid and h == 'hm':
                 hd.sig_lo, hd.sig_hi = c0, c0 + c
             if fuse_sigmoid and h == 'dep':
                 hd.dep_lo, hd.dep_hi = c0, c0 + c
             outputs[h] = comb[:, c0:c0 + c]
             c0 += c
-        L.append(_Launch('heads.fused[%s]' % ' + '.join(small), 'heads', hd, (feat, comb, P['hs_w0'], P['hs_b0'], P['hs_w2'], P['hs_b2'],
-                                                                               P['hs_w2_wide'], P['hs_b2_wide']), us=100.0))
+        L.append(_Launch('heads.fused[%s]' % ' + '.join(small), 'heads', hd, (feat, comb, P['hs_w0'], P['hs_b0'], P['hs_w2'], P['hs_b2']),
+                         us=100.0))
         if big:
             mid = ops.new_view(N, feat.H, feat.W, hc * len(big), dev)
             d = ops.make_conv_desc(feat, P['hb_w'], hc * len(big), 3, 1, shift=P['hb_b'], relu=True, out=mid, w_wino=P['hb_ww'])

@@ -113,12 +113,8 @@ size_t ct_conv2d_workspace_bytes(const ct_conv_desc *d);
  * 256-channel hidden maps (16.8 MB per head and frame at 512x512) stay inside the workgroups.  x: NHWC feature map
  * (64 channels, pitch ldx); w0_winograd: ct_pack_winograd_weight() of the heads' first-layer weights concatenated
  * along Cout ([nheads*256, 64, 3, 3]); b0 [nheads*256]; w2 [nheads][8][256] = the heads' 1x1 weights, rows >= cout[i]
- * zero; b2 [nheads][8]; head i writes channels coff[i] .. coff[i]+cout[i]-1 of out (NCHW [N, ctot, H, W]).
- * Round 4: a head with MORE than 8 output channels (hm of an 80-class model, hps, hm_hp; <= 80) is given as
- * w2_wide[i] = ct_pack_conv_weight() of its [cout, 256, 1, 1] output-layer weight and b2_wide[i] = its bias [cout]
- * (its rows of w2 / b2 are ignored); sig_wide[i] != 0 applies the sigmoid of Detector._sigmoid_output to its
- * outputs.  The wide heads of a descriptor run as a second launch of the same kernel family whose output layer is
- * contracted on the matrix cores -- their hidden maps stay inside the workgroups too. */
+ * zero; b2 [nheads][8]; head i writes channels coff[i] .. coff[i]+cout[i]-1 of out (NCHW [N, ctot, H, W]).  Heads
+ * with more than 8 output channels (hm of an 80-class model, hps, hm_hp) go through ct_conv2d. */
 #define CT_MAX_FUSED_HEADS 8
 typedef struct ct_heads_desc {
     const float *x; int N, H, W, Cin, ldx;
@@ -128,8 +124,6 @@ typedef struct ct_heads_desc {
     int cout[CT_MAX_FUSED_HEADS], coff[CT_MAX_FUSED_HEADS];
     float *out; int ctot;
     int sig_lo, sig_hi, dep_lo, dep_hi; float depth_scale;
-    const float *w2_wide[CT_MAX_FUSED_HEADS]; const float *b2_wide[CT_MAX_FUSED_HEADS];
-    int sig_wide[CT_MAX_FUSED_HEADS];
 } ct_heads_desc;
 int ct_heads_fused(const ct_heads_desc *d, void *stream);
 

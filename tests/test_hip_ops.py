@@ -1000,12 +1000,7 @@ def test_flip_images_mirrors_rows(device, W):
 @pytest.mark.parametrize('N,H,W,heads,sig,dep', [
     (1, 12, 24, [('hm', 1), ('reg', 2), ('wh', 2), ('tracking', 2), ('ltrb_amodal', 4)], 'hm', None),
     (2, 9, 19, [('hm', 3), ('dep', 1), ('rot', 8), ('dim', 3)], 'hm', 'dep'),        # ragged tiles, an 8-channel head
-    (1, 16, 16, [('wh', 2)], None, None),
-    # round 4: heads with more than 8 output channels, their 1x1 layer on the matrix cores (ct_heads_desc.w2_wide):
-    (1, 12, 24, [('hm', 80), ('reg', 2), ('wh', 2), ('tracking', 2)], 'hm', None),   # COCO: 80 classes = 5 n-tiles
-    (2, 9, 19, [('hm', 1), ('reg', 2), ('wh', 2), ('hps', 34), ('hm_hp', 17), ('hp_offset', 2), ('tracking', 2)], 'hm+hm_hp', None),
-    (1, 7, 33, [('hm', 80)], None, None),                                            # wide heads only, no sigmoid
-    (1, 8, 16, [('a', 9), ('b', 16), ('c', 33), ('d', 8)], 'b', None)])             # n-tile boundaries
+    (1, 16, 16, [('wh', 2)], None, None)])
 def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
     """ct_heads_fused: conv3x3 64 -> 256 + bias + ReLU + conv1x1 256 -> c + bias (+ sigmoid / depth transform) of several
     heads in one launch == the torch fp32 reference of base_model.py:24-65 + detector.py:300-308"""
@@ -1020,7 +1015,7 @@ def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
     want = []
     for i, (name, c) in enumerate(heads):
         y = F.conv2d(F.relu(F.conv2d(x, w0[i], b0[i], padding=1)), w2[i], b2[i])
-        if sig is not None and name in sig.split('+'):
+        if name == sig:
             y = torch.sigmoid(y)
         if name == dep:
             y = (1. / (torch.sigmoid(y) + 1e-6) - 1.) * 2.0
@@ -1037,19 +1032,12 @@ def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
     hd.x, hd.N, hd.H, hd.W, hd.Cin, hd.ldx = xv.ptr, N, H, W, 64, xv.ld
     hd.w0_winograd, hd.b0, hd.nheads = w0p.data_ptr(), b0d.data_ptr(), nh
     c0 = 0
-    keep = []
     for i, (name, c) in enumerate(heads):
+        w2d[i, :c] = w2[i].reshape(c, 256).to(device)
+        b2d[i, :c] = b2[i].to(device)
         hd.cout[i], hd.coff[i] = c, c0
-        sigm = sig is not None and name in sig.split('+')
-        if c > 8:                               # wide head: packed 1x1 weight + bias + its own sigmoid flag
-            wp, bp = ops.pack_weight(w2[i].to(device)), b2[i].to(device).contiguous()
-            keep += [wp, bp]
-            hd.w2_wide[i], hd.b2_wide[i], hd.sig_wide[i] = wp.data_ptr(), bp.data_ptr(), int(sigm)
-        else:
-            w2d[i, :c] = w2[i].reshape(c, 256).to(device)
-            b2d[i, :c] = b2[i].to(device)
-            if sigm:
-                hd.sig_lo, hd.sig_hi = c0, c0 + c
+        if name == sig:
+            hd.sig_lo, hd.sig_hi = c0, c0 + c
         if name == dep:
             hd.dep_lo, hd.dep_hi = c0, c0 + c
         c0 += c
@@ -1057,21 +1045,3 @@ def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
     _lib.check(_lib.load().ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()), 'ct_heads_fused')
     torch.cuda.synchronize()
     _close(out, want, atol=5e-4, rtol=2e-4, msg='fused heads')       # (Winograd tolerance of this suite)
-
-
-def test_heads_fused_rejects_a_wide_head_without_its_packed_weight(device):
-    import ctypes
-    from centertrack_amd import _lib, ops
-    xv = ops.new_view(1, 8, 16, 64, device)
-    w0p = ops.pack_winograd(_rand(256, 64, 3, 3, seed=1).to(device))
-    z = torch.zeros(4096, device=device)
-    hd = _lib.HeadsDesc()
-    hd.x, hd.N, hd.H, hd.W, hd.Cin, hd.ldx = xv.ptr, 1, 8, 16, 64, xv.ld
-    hd.w0_winograd, hd.b0, hd.nheads = w0p.data_ptr(), z.data_ptr(), 1
-    hd.cout[0], hd.coff[0] = 17, 0
-    hd.w2, hd.b2, hd.out, hd.ctot = z.data_ptr(), z.data_ptr(), z.data_ptr(), 17
-    assert _lib.load().ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()) == _lib.CT_ERR_ARG
-    assert b'w2_wide' in _lib.load().ct_last_error()
-    hd.cout[0], hd.ctot = 96, 96
-    assert _lib.load().ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()) == _lib.CT_ERR_ARG
-    assert b'at most 80' in _lib.load().ct_last_error()
