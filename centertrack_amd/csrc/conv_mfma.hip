@@ -188,6 +188,11 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
     };
 
+    // epilogue operands (BN scale / shift of this wave's couts) first: they arrive while the main loop runs
+    float psc[WN], psh[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) ct_load_scale_shift(a.epi, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
+
     f32x4 acc[WM][WN];
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt)
@@ -200,6 +205,14 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     f32x4 accp[PROJ ? WM : 1][PROJ ? WN : 1];
     f32x4 pmax[PROJ ? WM : 1];
     f32x4 bproj[PROJ ? WN : 1];
+    float psc2[PROJ ? WN : 1], psh2[PROJ ? WN : 1];
+    if (PROJ) {
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            psc2[nt] = 1.0f; psh2[nt] = 0.0f;
+            if (proj) ct_load_scale_shift(a.epi2, (nt0 + nt) * 16, lane, psc2[nt], psh2[nt]);
+        }
+    }
     if (PROJ) {
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
@@ -326,7 +339,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-                ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
+                ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
     }
     if constexpr (PROJ) {
         if (proj) {
@@ -334,7 +347,7 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
                 for (int nt = 0; nt < WN; ++nt)
-                    ct_store_tile(a.epi2, accp[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
+                    ct_store_tile(a.epi2, accp[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane, psc2[nt], psh2[nt]);
         }
     }
     CT_STAMP(6);
@@ -372,7 +385,20 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
                                                                    a.epi.Ho, a.epi.Wo);
         }
     };
-    auto fin_main = [&](int mt, int nt, f32x4 sum) {
+    // epilogue operands of the tiles THIS wave finalises (tile j * WK + wave of the workgroup's WM x WN tiles), loaded first
+    constexpr int NJ = (WM * WN + WK - 1) / WK;
+    const int wave_id = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    float psc[NJ], psh[NJ], psc2[NJ], psh2[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; ++j) {
+        const int t = min(j * WK + wave_id, WM * WN - 1);
+        ct_load_scale_shift(a.epi, (nt0 + t % WN) * 16, lane, psc[j], psh[j]);
+        psc2[j] = 1.0f; psh2[j] = 0.0f;
+        if constexpr (POOL && KS == 3 && STRIDE == 2) {
+            if (a.proj_wp) ct_load_scale_shift(a.epi2, (nt0 + t % WN) * 16, lane, psc2[j], psh2[j]);
+        }
+    }
+    auto fin_main = [&](int mt, int nt, f32x4 sum, int j) {
             const int oy = oy0 + mt;
             if (a.ws) {
                 const int li = lane & 15, lg = lane >> 4;
@@ -387,12 +413,14 @@ __global__ __launch_bounds__(64 * WK) void conv_ksplit_kernel(ConvArgs a)
                     }
                 }
             } else {
-                ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane);
+                ct_store_tile(a.epi, sum, n, oy, ox0, (nt0 + nt) * 16, lane, psc[j], psh[j]);
             }
         };
     if constexpr (POOL && KS == 3 && STRIDE == 2) {
         // (the POOL instantiations also carry Tree.project of the pooled input, see ConvArgs::proj_wp)
-        auto fin_proj = [&](int mt, int nt, f32x4 sum) { ct_store_tile(a.epi2, sum, n, oy0 + mt, ox0, (nt0 + nt) * 16, lane); };
+        auto fin_proj = [&](int mt, int nt, f32x4 sum, int j) {
+            ct_store_tile(a.epi2, sum, n, oy0 + mt, ox0, (nt0 + nt) * 16, lane, psc2[j], psh2[j]);
+        };
         ksplit_conv_tile<KS, STRIDE, WM, WN, WK, 2>(xin, a.H, a.W, a.ldx, a.Cin, a.wp, a.NT, nt0, oy0, ox0, c_begin, c_end, lds,
                                                     fin_main, hook, a.proj_wp, fin_proj);
     } else {

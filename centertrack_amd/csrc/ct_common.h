@@ -124,18 +124,29 @@ __device__ __forceinline__ float ct_epilogue_value(const EpiArgs &e, float v, in
     return v;
 }
 
+// Scale / shift of channel co0 + (lane & 15), loaded EARLY (round 4): at one stream every launch is a single round of
+// workgroups, so a workgroup's own latency chain is the kernel's duration; the epilogue's scale / shift loads were a
+// ~1 us round trip into a cold L2 at its very end (s_memtime stamps: 0.9-1.1 us between the last MFMA and the last
+// store of the backbone kernels, 2.1 us in the DCN kernel).  Issued before the main loop they cost two registers per
+// n-tile and arrive long before they are needed.
+__device__ __forceinline__ void ct_load_scale_shift(const EpiArgs &e, int co0, int lane, float &sc, float &sh)
+{
+    const int co = co0 + (lane & 15);
+    const bool ok = co < e.Cout;
+    sc = (e.scale && ok) ? e.scale[co] : 1.0f;
+    sh = (e.shift && ok) ? e.shift[co] : 0.0f;
+}
+
 // Store the 16x16 MFMA tile `acc` (C/D layout: col = lane&15, row = (lane>>4)*4 + e) whose
 // rows are the 16 consecutive output pixels (n, oy, ox0..ox0+15) and whose columns are the
-// couts co0..co0+15.
+// couts co0..co0+15; sc / sh: the channel's scale / shift (ct_load_scale_shift).
 __device__ __forceinline__ void ct_store_tile(const EpiArgs &e, f32x4 acc, int n, int oy, int ox0, int co0,
-                                              int lane)
+                                              int lane, float sc, float sh)
 {
     if (oy >= e.Ho) return;
     const int co = co0 + (lane & 15);
     const int xr = ox0 + ((lane >> 4) << 2);
     if (co >= e.Cout) return;
-    const float sc = e.scale ? e.scale[co] : 1.0f;
-    const float sh = e.shift ? e.shift[co] : 0.0f;
     const size_t pix = ((size_t)n * e.Ho + oy) * e.Wo;
     float v[4];
 #pragma unroll
@@ -159,4 +170,11 @@ __device__ __forceinline__ void ct_store_tile(const EpiArgs &e, f32x4 acc, int n
         for (int i = 0; i < 4; ++i)
             if (xr + i < e.Wo) e.y[(pix + xr + i) * e.ldy + co] = v[i];
     }
+}
+
+__device__ __forceinline__ void ct_store_tile(const EpiArgs &e, f32x4 acc, int n, int oy, int ox0, int co0, int lane)
+{
+    float sc, sh;
+    ct_load_scale_shift(e, co0, lane, sc, sh);
+    ct_store_tile(e, acc, n, oy, ox0, co0, lane, sc, sh);
 }

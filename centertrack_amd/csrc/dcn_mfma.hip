@@ -122,7 +122,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     if (FUSE && a.offsOnly) {
         // ---- CT_DCN_OFFSETS: chunk `split` (64 input channels) of the offset/mask conv of this tile, raw ----
         float *part = a.omPart + ((size_t)split * a.N + n) * a.H * a.W * 32;
-        auto fin = [&](int mt, int nt, f32x4 sum) {
+        auto fin = [&](int mt, int nt, f32x4 sum, int) {
             const int co = nt * 16 + (lane & 15);
             const int oy = oy0 + mt;
 #pragma unroll
@@ -140,7 +140,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 
     if (fuse) {
         // ---- offset / mask conv of this tile (all input channels, whatever K range this split owns) ----
-        auto fin = [&](int mt, int nt, f32x4 sum) {
+        auto fin = [&](int mt, int nt, f32x4 sum, int) {
             const int co = nt * 16 + (lane & 15);
             const float b = (co < 27) ? a.b_off[co] : 0.0f;
 #pragma unroll
@@ -188,6 +188,13 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         int ch, tp;
         step_ct(0, ch, tp);
         load_b(bq[0], ch, tp);
+    }
+    // epilogue operands (BN scale / shift) of this wave's couts: loaded here, needed after the last step
+    float psc[WN], psh[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        psc[nt] = 1.0f; psh[nt] = 0.0f;
+        if (!a.ws) ct_load_scale_shift(a.epi, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
     }
 
     // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
@@ -387,7 +394,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-                ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane);
+                ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
     }
     CT_STAMP(6);
     CT_STAMP_RT(7);

@@ -36,7 +36,8 @@ struct KsCfg {
 // xin: image base (NHWC, pitch ldx); the tile's first output pixel is (oy0, ox0); wp: packed weights
 // (NT n-tiles of 16 couts); this workgroup's first n-tile is nt0; chunks [c_begin, c_end) of 16*WK
 // channels; lds: >= KsCfg::LDS_BYTES (or LDS1_FLOATS floats for a single chunk), free for reuse on
-// return AFTER a __syncthreads().  fin(mt, nt, sum) is called by exactly one wave per tile.
+// return AFTER a __syncthreads().  fin(mt, nt, sum, j) is called by exactly one wave per tile: wave w finalises tiles
+// j * WK + w, j = 0, 1, .. (j is a compile-time position: callers index per-tile registers they loaded early with it).
 // PD = B prefetch distance in (tap) steps: 2 for the multi-chunk backbone layers (registers); the single-chunk offset
 // conv of the DCN launches may fetch every tap's fragments up front (PD = KS*KS - 1): its 9-tap loop is otherwise
 // paced by the L2 latency of the weights (512 MFMA clocks per tap against a > 1000-clock round trip).
@@ -45,7 +46,7 @@ struct KsNoHook {
 };
 
 struct KsNoFin2 {
-    __device__ __forceinline__ void operator()(int, int, f32x4) const {}
+    __device__ __forceinline__ void operator()(int, int, f32x4, int) const {}
 };
 
 // hook(chunk, buf): called by all threads at the top of every chunk with the chunk's staged patch in LDS ([WK slabs][PP]
@@ -236,7 +237,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
             f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (t * 64 + lane) * 4);
 #pragma unroll
             for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
-            fin(t / WN, t % WN, sum);
+            fin(t / WN, t % WN, sum, t0 / WK);
         }
     }
     if constexpr (SIDE) {
@@ -255,7 +256,7 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                     f32x4 sum = *reinterpret_cast<const f32x4 *>(red + (t * 64 + lane) * 4);
 #pragma unroll
                     for (int w = 1; w < WK; ++w) sum += *reinterpret_cast<const f32x4 *>(red + ((w * T + t) * 64 + lane) * 4);
-                    fin2(t / WN, t % WN, sum);
+                    fin2(t / WN, t % WN, sum, t0 / WK);
                 }
             }
         }

@@ -185,6 +185,23 @@ void wino_conv_kernel(WinoArgs a)
     const bool wide = (a.epi.Cout % 4 == 0) && (a.epi.ldy % 4 == 0) && (!a.epi.res || a.epi.ldr % 4 == 0) &&
                       (((uintptr_t)a.epi.y & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
     const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
+    // epilogue operands of the (q, m-tile, n-tile) jobs this wave finalises (BN scale / shift of 4 couts), loaded before
+    // the main loop (ct_common.h, ct_load_scale_shift: a ~1 us round trip off the end of every workgroup)
+    constexpr int NJW = (2 * WM * WN + 4 * KS - 1) / (4 * KS);
+    constexpr bool PRE = NB == 1 && !HEADS && !(KS == 4 && WN == 2);   // (64 x 32 x K-split 4: 1024 threads cap a wave at 128 VGPRs, already spilling)
+    f32x4 psc[PRE ? NJW : 1], psh[PRE ? NJW : 1];
+    if (PRE && wide) {
+#pragma unroll
+        for (int jw = 0; jw < NJW; ++jw) {
+            const int job = min(jw * 4 * KS + wv, 2 * WM * WN - 1);
+            const int tn = job >> 1;
+            const int nt = tn - (tn / WN) * WN;
+            const int c4 = (cb * WN + nt) * 16 + (lane & 3) * 4;
+            const bool ok = c4 < a.epi.Cout;
+            psc[jw] = (a.epi.scale && ok) ? *reinterpret_cast<const f32x4 *>(a.epi.scale + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
+            psh[jw] = (a.epi.shift && ok) ? *reinterpret_cast<const f32x4 *>(a.epi.shift + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
 
     // input transform of slab kk of the current LDS buffer: rows combined first, then the four column combinations
     auto transform = [&](f32x4 (&v)[WM][4], const float *buf, int kk) {
@@ -385,8 +402,14 @@ void wino_conv_kernel(WinoArgs a)
                     if (oy < a.epi.Ho && ox < a.epi.Wo && c4 < a.epi.Cout) {
                         const f32x4 raw = *reinterpret_cast<const f32x4 *>(yb + tp * 16 + cq * 4);
                         const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
-                        const f32x4 sc4 = a.epi.scale ? *reinterpret_cast<const f32x4 *>(a.epi.scale + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
-                        const f32x4 sh4 = a.epi.shift ? *reinterpret_cast<const f32x4 *>(a.epi.shift + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        f32x4 sc4, sh4;
+                        if (PRE) {
+                            sc4 = psc[PRE ? w0 / (4 * KS) : 0];
+                            sh4 = psh[PRE ? w0 / (4 * KS) : 0];
+                        } else {
+                            sc4 = a.epi.scale ? *reinterpret_cast<const f32x4 *>(a.epi.scale + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                            sh4 = a.epi.shift ? *reinterpret_cast<const f32x4 *>(a.epi.shift + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                        }
                         const f32x4 r4 = a.epi.res ? *reinterpret_cast<const f32x4 *>(a.epi.res + pix * a.epi.ldr + c4)
                                                    : f32x4{0.f, 0.f, 0.f, 0.f};
                         f32x4 o;
