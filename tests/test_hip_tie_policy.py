@@ -15,8 +15,13 @@ Policy asserted here, on exactly that stream (T = 32, nothing re-seeded):
   * the frame right after a blob flip: exempt from the 1e-3 bar, bounded by 5e-2 (scores) / 0.5 px (boxes), same
     detections, same ids;
   * re-convergence: from the second frame after the flip on the bar is 1e-3 again (and the blobs agree again).
-The flip itself depends on the last bits of the HIP path's sums (launch shapes): if a re-tuned plan no longer produces
-it, every frame has to meet the 1e-3 bar and the test says so in its output."""
+The flip itself depends on the last bits of the HIP path's sums (launch shapes).  It was found on round 3's plan; round
+4's plan (Tree.project computed by the stride-2 conv launches: other summation orders in four layers) puts that centre on
+the oracle's side of the integer and the same stream runs without a flip (profiles/r04_tie_report.json: 0 flips in 1760
+frames).  The test therefore runs the stream on BOTH plans: on round 3's launch structure (``model.FUSE_PROJ = False``, its
+pinned shapes are still in the table) the flip must occur -- at frame 24, blob (470, 344, 6) vs (469, 344, 6) -- and the
+exemption is exercised; on the shipped plan every frame has to meet the 1e-3 bar (or, should a re-tuned table bring a flip
+back, the same policy applies)."""
 import os
 import sys
 
@@ -34,8 +39,12 @@ SEED = 317 + 7 + 1000 * 39          # tools/tie_report.stream_seed(plan 0, run 3
 T = 32
 
 
-def test_prior_heatmap_flip_stream_follows_the_stated_policy(device):
+@pytest.mark.parametrize('plan', ['shipped', 'round3'])
+def test_prior_heatmap_flip_stream_follows_the_stated_policy(device, plan, monkeypatch):
     import scenarios as S
+    from centertrack_amd import model as M
+    if plan == 'round3':
+        monkeypatch.setattr(M, 'FUSE_PROJ', False)
     import tie_report as TR
     from centertrack_amd.detector import StreamDetector, default_opt
     from centertrack_amd.image import make_meta
@@ -95,5 +104,10 @@ def test_prior_heatmap_flip_stream_follows_the_stated_policy(device):
             flips.append((t, only_o[0], only_g[0]))
             after_flip = True
     assert len(flips) <= 2, 'a blob flip is a rare event (0.6 per 1000 frames measured): %s' % (flips,)
-    print('tie policy: %d blob flip(s) %s; |dscore| max %.2e outside the exempt frames, %.2e inside (%s)'
-          % (len(flips), flips, worst, worst_exempt, exempt))
+    if plan == 'round3':
+        assert flips == [(24, (470, 344, 6), (469, 344, 6))], (
+            'the documented flip of this stream on round 3\'s launch structure did not reproduce (%s): were its pinned shapes '
+            're-tuned?  re-measure with tools/tie_report.py and update this test' % (flips,))
+        assert exempt == [25] and worst_exempt > ATOL, (exempt, worst_exempt)
+    print('tie policy [%s plan]: %d blob flip(s) %s; |dscore| max %.2e outside the exempt frames, %.2e inside (%s)'
+          % (plan, len(flips), flips, worst, worst_exempt, exempt))

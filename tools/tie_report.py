@@ -49,6 +49,7 @@ PLAN = [
     ('coco_512', 4, 1, 24),           # 80 classes, BASELINE per-GPU batch: 96 frames
     ('nusc_800x448', 4, 1, 24),       # 3D heads: 96 frames
     ('kitti_1280x384', 4, 1, 16),     # flip_test: 64 frames
+    ('mot17_544x960', 1, 4, 24),      # round 4: the reference's own MOT input size (datasets/mot.py:15): 96 frames
 ]
 QUICK = [('mot17_512', 1, 1, 4), ('coco_512', 2, 1, 2)]
 DET_FIELDS = ('scores', 'clses', 'xs', 'ys', 'bboxes', 'tracking')
@@ -326,7 +327,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r03_tie_report.json'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_tie_report.json'))
     ap.add_argument('--quick', action='store_true', help='a few frames (plumbing check)')
     ap.add_argument('--mot-runs', type=int, default=0, help='runs of the headline plan (32 frames each); 0 = the PLAN default')
     ap.add_argument('--workers', type=int, default=0)
