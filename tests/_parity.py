@@ -2,7 +2,8 @@
 
 north_star's bar, as asserted here:
   * top-K indices (class, y, x), classes and ranks: IDENTICAL for every detection whose oracle score is >= out_thresh,
-    except inside a *tie group* -- consecutive oracle ranks whose scores differ by less than ``TIE`` (1e-5): fp32 with
+    except inside a *tie group* -- consecutive oracle ranks whose scores differ by less than ``TIE`` (1e-5; ``RANK_TIE_UNPICKED``
+    = 5e-5 on the streams nobody picked, tests/test_hip_plans.py: the measured width of fp32 rank noise): fp32 with
     a different summation order cannot resolve those (SURVEY.md Appendix D.1), they may swap among themselves;
   * heat-map scores and every decode-level value (boxes, centres, tracking displacement, 3D heads) on the OUTPUT
     GRID: within ``ATOL`` = 1e-3 absolute (depth, an unbounded 1/sigmoid - 1: 1e-3 relative on top);
