@@ -62,7 +62,7 @@ __device__ __forceinline__ int ct_block_cout(int &bid, int coutBlocks, int per)
 // of a workgroup writes s_memtime (CT_STAMP), s_memrealtime (100 MHz: CT_STAMP_RT) or a value (CT_STAMP_VAL) into word i
 // of its row; CT_DEFINE_STAMPS(name) exports ct_<name>_read_stamps / ct_<name>_clear_stamps for the host tool.
 #if defined(CT_STAMPS) && defined(__HIPCC__)
-#define CT_STAMP_WORDS 12
+#define CT_STAMP_WORDS 24
 #define CT_STAMP_BLOCKS 8192
 static __device__ unsigned long long ct_stamps_buf[CT_STAMP_WORDS * CT_STAMP_BLOCKS];
 #define CT_STAMP_AT(i, v) do { if (threadIdx.x == 0 && blockIdx.x < CT_STAMP_BLOCKS && blockIdx.y == 0) ct_stamps_buf[blockIdx.x * CT_STAMP_WORDS + (i)] = (unsigned long long)(v); } while (0)

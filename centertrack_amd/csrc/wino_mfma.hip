@@ -290,16 +290,19 @@ void wino_conv_kernel(WinoArgs a)
         const int nchunks = MULTI ? a.nchunks : 1;
         for (int ch = 0; ch < nchunks; ++ch) {
             const int cur = ch & 1;
+            if (ch < 2) CT_STAMP(12 + 6 * ch);          // (loop-internal stamps of the first two chunks: tools/conv_phases.py --loop)
             if (MULTI) {
                 stage_load(min(ch + 1, a.nchunks - 1));
                 __builtin_amdgcn_sched_barrier(0x386);
             }
+            if (ch < 2) CT_STAMP(13 + 6 * ch);
             const float *buf = lds + cur * W_BUF;
 #pragma unroll
             for (int ks = 0; ks < SPK; ++ks) {
                 const int kk = kp * SPK + ks;
                 f32x4 v[WM][4];
                 transform(v, buf, kk);
+                if (ch < 2 && ks == 0) CT_STAMP(14 + 6 * ch);
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int s = ks * 4 + c;
@@ -316,8 +319,11 @@ void wino_conv_kernel(WinoArgs a)
                                                                                      acc[mt][c][nt], 0, 0, 0);
                 }
             }
+            if (ch < 2) CT_STAMP(15 + 6 * ch);
             if (MULTI && ch + 1 < a.nchunks) stage_store(cur ^ 1);
+            if (ch < 2) CT_STAMP(16 + 6 * ch);
             __syncthreads();
+            if (ch < 2) CT_STAMP(17 + 6 * ch);
         }
     }
 

@@ -52,6 +52,9 @@ def main():
     ap.add_argument('--force', default='', help="launch-name substring=algo[,..]: run those launches with another algo code, e.g. "
                                                  "'level3.tree2=225,level5.t2=113' (3x3 stride-1 launches only keep their weights)")
     ap.add_argument('--reps', type=int, default=1, help='print the mean over this many stamped runs')
+    ap.add_argument('--loop', action='store_true', help='also print the loop-internal stamps of the Winograd launches (first two chunks, '
+                                                        'wave 0: chunk top -> next patch fetched -> first slab transformed -> last MFMA '
+                                                        'issued -> patch stored -> barrier passed)')
     args = ap.parse_args()
     if args.build:
         return build()
@@ -79,7 +82,7 @@ def main():
                 if sub in l.name:
                     l.args.algo, l.args.split_k = int(algo), 1
                     l.name = '%s @%s' % (l.name, algo)
-    NB, WORDS = 8192, 12
+    NB, WORDS = 8192, 24
     host = np.zeros(NB * WORDS, dtype=np.uint64)
     kinds = [k for k in args.only.split(',') if k]
     names = ['setup', 'load', 'loop', 'xchg', 'epi']
@@ -127,6 +130,14 @@ def main():
         print('%-44s %-5s %5d %8.1f | %7.2f %7.2f %7.2f %7.2f %7.2f | %6.2f %6.2f | %d x %d, %d' % (
             l.name[:44], kind, len(st), span, *(float(np.mean(p)) for p in ph), float(np.mean(dt_rt)), late,
             len(np.unique(xcc)), len(uniq), int(cnt.max())))
+        if args.loop and kind == 'wino' and (st[:, 12] != 0).any():
+            for chn in range(2):
+                w = st[:, 12 + 6 * chn:18 + 6 * chn].astype(np.float64)
+                if (w[:, 0] == 0).all():
+                    continue
+                d = np.diff(w, axis=1) / tick
+                print('      chunk %d: fetch issue %.2f  transform %.2f  MFMAs issued %.2f  store %.2f  barrier %.2f  | chunk %.2f us' % (
+                    chn, *(float(np.mean(d[:, i])) for i in range(5)), float(np.mean(w[:, 5] - w[:, 0]) / tick)))
         tot += span
     print('sum of spans %.1f us; s_memtime ticks per us (last launch): %.1f' % (tot, tick))
 

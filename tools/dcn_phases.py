@@ -56,7 +56,7 @@ def main():
     torch.cuda.synchronize()
     raw = ctypes.CDLL(LIB)
     print('knobs', plan['dcn_knobs'])
-    NB, WORDS = 8192, 12
+    NB, WORDS = 8192, 24
     host = np.zeros(NB * WORDS, dtype=np.uint64)
     names = ['offset conv', 'table', 'prologue', 'loop', 'epilogue']
     for l in plan['launches']:
