@@ -1,0 +1,47 @@
+// Calibration for DESIGN.md section 8: what a dependent kernel boundary costs inside a captured HIP graph, and what a
+// device-wide barrier inside ONE kernel costs (256 co-resident workgroups, atomic counter + acquire / release fences
+// across the 8 XCDs) -- the two ways a chain of small dependent layers can be sequenced on an MI355X.
+#include <hip/hip_runtime.h>
+
+extern "C" {
+
+__global__ __launch_bounds__(256) void tiny_kernel(float *buf, int round)
+{
+    // every workgroup reads what its neighbour wrote in the previous launch and writes its own cell
+    const int g = gridDim.x, b = blockIdx.x;
+    if (threadIdx.x == 0) buf[(round & 1) * 4096 + b] = buf[((round + 1) & 1) * 4096 + (b + 1) % g] + 1.0f;
+}
+
+int launch_tiny(int blocks, int rounds, float *buf, void *stream)
+{
+    for (int r = 0; r < rounds; ++r) hipLaunchKernelGGL(tiny_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, r);
+    return (int)hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void barrier_kernel(float *buf, unsigned *ctr, unsigned *err, int rounds)
+{
+    const unsigned g = gridDim.x, b = blockIdx.x;
+    for (int r = 0; r < rounds; ++r) {
+        if (threadIdx.x == 0) {
+            buf[(r & 1) * 4096 + b] = buf[((r + 1) & 1) * 4096 + (b + 1) % g] + 1.0f;
+            __threadfence();                                            // release: my cell before my arrival
+            atomicAdd(ctr, 1u);
+            const unsigned target = g * (unsigned)(r + 1);
+            unsigned spins = 0;
+            while (__hip_atomic_load(ctr, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+                if (++spins > (1u << 22)) { atomicAdd(err, 1u); break; }      // (bounded: never hangs the box)
+                __builtin_amdgcn_s_sleep(1);
+            }
+            __threadfence();                                            // acquire: the neighbours' cells
+        }
+        __syncthreads();
+    }
+}
+
+int launch_barrier(int blocks, int rounds, float *buf, unsigned *ctr, unsigned *err, void *stream)
+{
+    hipLaunchKernelGGL(barrier_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf, ctr, err, rounds);
+    return (int)hipGetLastError();
+}
+
+}
