@@ -448,6 +448,66 @@ def test_native_loop_reset_tracking_and_single_detector_run(device):
             np.testing.assert_array_equal(a[f], b[f])
 
 
+def test_native_loop_under_another_torch_stream_and_device_frames(device):
+    """round 4 (advisor review of round 3): the native loop launches on the stream that was current when the context was
+    built; a caller that steps under ANOTHER ``torch.cuda.stream`` -- with frames that are device tensors produced on that
+    stream a moment earlier, or non-contiguous views that go through the in-place slot copy -- must get the same results
+    as a plain run: the loop stream waits for the caller's stream, the step's torch-side work is issued on the loop
+    stream, the caller's stream waits on the way out."""
+    from centertrack_amd import detector as D
+    opt, model, batches, meta = _stream_setup(1)
+    metas = [dict(meta)]
+    ref_det = D.StreamDetector(opt, model=model, num_streams=1)
+    ref = [ref_det.step(b, metas)[0].copy() for b in batches]
+    det = D.StreamDetector(opt, model=model, num_streams=1)
+    det.step(batches[0], metas)                         # context (and its loop stream) built on the default stream
+    assert det._ctx['loop'] is not None
+    side = torch.cuda.Stream()
+    got = [None]
+    for t in range(1, len(batches)):
+        with torch.cuda.stream(side):
+            assert torch.cuda.current_stream() != det._ctx['loop_stream']
+            if t % 2:
+                # produced on the side stream right before the step: a pinned upload + an identity kernel
+                img = batches[t].pin_memory().to(device, non_blocking=True) * 1.0
+            else:
+                # a non-contiguous device view: the in-place slot copy (also on the loop stream)
+                wide = torch.zeros((1, 3, batches[t].shape[2], batches[t].shape[3] + 8), device=device)
+                wide[..., 4:-4].copy_(batches[t].to(device), non_blocking=True)
+                img = wide[..., 4:-4]
+                assert not img.is_contiguous()
+            got.append(det.step(img, metas)[0].copy())
+    torch.cuda.synchronize()
+    for t in range(1, len(batches)):
+        for f in ('tracking_id', 'score', 'bbox', 'ct', 'tracking', 'class', 'age', 'active'):
+            np.testing.assert_array_equal(ref[t][f], got[t][f], err_msg='frame %d %s' % (t, f))
+
+
+def test_frame_loop_finish_without_a_frame_in_flight_is_refused(device):
+    """ct_frame_loop_finish follows ct_frame_loop_submit exactly once: a second association of the stale rows would age
+    the tracks and advance the ids (advisor review of round 3)"""
+    import ctypes
+    from centertrack_amd import _lib
+    from centertrack_amd import detector as D
+    opt, model, batches, meta = _stream_setup(1)
+    det = D.StreamDetector(opt, model=model, num_streams=1)
+    metas = [dict(meta)]
+    a = det.step(batches[0], metas)[0].copy()
+    b = det.step(batches[1], metas)[0].copy()
+    ctx = det._ctx
+    lib = _lib.load()
+    assert lib.ct_frame_loop_in_flight(ctx['loop']) == -1
+    rc = lib.ct_frame_loop_finish(ctx['loop'], ctypes.byref(ctx['args'][0]), ctx['counts'].ctypes.data)
+    assert rc == _lib.CT_ERR_ARG and b'no frame in flight' in lib.ct_last_error()
+    # ... and the tracker state was not touched: the stream continues exactly like an undisturbed one
+    ref_det = D.StreamDetector(opt, model=model, num_streams=1)
+    for t in range(3):
+        want = ref_det.step(batches[t], metas)[0].copy()
+    got = det.step(batches[2], metas)[0].copy()
+    for f in ('tracking_id', 'score', 'bbox', 'age'):
+        np.testing.assert_array_equal(want[f], got[f])
+
+
 def test_native_loop_with_helper_threads_equals_python_loop(device, monkeypatch):
     """the per-stream post-process + association of a frame spread over helper threads (default from 8 streams on; forced
     here for 3 streams): results identical to the Python loop"""
