@@ -12,9 +12,18 @@
 
 namespace {
 
-constexpr int ST_TH = 8, ST_TW = 32;
-constexpr int ST_PH = ST_TH + 6, ST_PW = 40;           // pitch 40 (38 used)
-constexpr int ST_PS = ST_PH * ST_PW;                   // floats per plane
+// Tile = TH x 32 pixels, TH = 8 (2 rows per wave) or 16 (4 rows per wave, round 4): at 512 x 512 x 1 stream the 8-row grid is
+// 1024 workgroups of 140 VGPRs -- 768 resident, then a second round of 256 that runs one wave per SIMD (43 us for 18 us of
+// MFMA time); 16-row tiles are 512 workgroups, all resident, two waves per SIMD, and the 22 KB of weights are staged half
+// as often.  Same per-pixel arithmetic in the same order: bit-identical.
+constexpr int ST_TW = 32;
+constexpr int ST_PW = 40;                              // plane pitch 40 (38 used)
+template <int TH> struct StCfg {
+    static constexpr int PH = TH + 6;
+    static constexpr int PS = PH * ST_PW;              // floats per plane
+    static constexpr int NPV = (3 * PH * 38 + 255) / 256;      // plane values staged per thread (3 planes)
+    static constexpr int HALVES = TH / 8;              // the workgroup walks its tile in slabs of 8 rows (2 rows = 4 m-tiles per wave)
+};
 __host__ __device__ constexpr int st_k4(int s) { return s == 2 ? 52 : 148; }   // K padded to 4
 __host__ __device__ constexpr int st_koff(int s) { return s * 148; }            // offsets into the k tables
 constexpr int ST_KTOT = 348;
@@ -32,11 +41,15 @@ struct StemArgs {
     int N, H, W, ldy, ldadd, tilesX, tilesY;
 };
 
-// per-thread staging register counts: plane values (3 planes: 3*14*38/256 -> 7) and weights (148*16/256 -> 10)
-constexpr int ST_NPV = 7, ST_NWV = 10;
+// per-thread staging register count of the weights (148*16/256 -> 10)
+constexpr int ST_NWV = 10;
 
+template <int TH>
+__attribute__((amdgpu_waves_per_eu(TH == 16 ? 2 : 1)))      // (16-row tiles: the launch needs two workgroups per CU resident)
 __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
 {
+    using SC = StCfg<TH>;
+    constexpr int ST_TH = TH, ST_PH = SC::PH, ST_PS = SC::PS, ST_NPV = SC::NPV, MT = 4, HV = SC::HALVES;
     __shared__ __attribute__((aligned(16))) float planes[7 * ST_PS];
     __shared__ __attribute__((aligned(16))) float wl[ST_KTOT * ST_WLP];
     __shared__ int tab[ST_KTOT];
@@ -117,25 +130,27 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
         }
     };
 
-    // wave -> rows 2w, 2w+1; m-tile mt -> (row 2w + mt/2, column block mt&1)
-    int pbase[4];
+    // slab h (8 rows): wave -> rows 8h + 2w, 8h + 2w + 1; m-tile mt -> (row 8h + 2w + mt/2, column block mt&1)
+    int pbase[MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) pbase[mt] = (2 * wave + (mt >> 1)) * ST_PW + (mt & 1) * 16 + li;
+    for (int mt = 0; mt < MT; ++mt) pbase[mt] = (2 * wave + (mt >> 1)) * ST_PW + (mt & 1) * 16 + li;
 
     // The three terms are summed in the order 0, 1, 2 starting from `add` (or 0): a launch of stems {0, 1} into a
     // partial map followed by a launch of stem {2} on top of it gives the bits of ONE launch of all three
     // ((0 + r0) + r1) + r2 -- the detector computes the first two terms of frame t+1, which do not depend on the
     // tracker, while the host still associates frame t (round 3).
-    f32x4 out[4];
+    f32x4 out[HV][MT];
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        out[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int h = 0; h < HV; ++h)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        out[h][mt] = f32x4{0.f, 0.f, 0.f, 0.f};
         if (a.add) {
-            const int oy = oy0 + 2 * wave + (mt >> 1);
+            const int oy = oy0 + 8 * h + 2 * wave + (mt >> 1);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int ox = ox0 + (mt & 1) * 16 + lg * 4 + e;
-                if (oy < a.H && ox < a.W) out[mt][e] = a.add[(((size_t)n * a.H + oy) * a.W + ox) * a.ldadd + li];
+                if (oy < a.H && ox < a.W) out[h][mt][e] = a.add[(((size_t)n * a.H + oy) * a.W + ox) * a.ldadd + li];
             }
         }
     }
@@ -154,24 +169,27 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
         const bool have_next = a.in[s] != nullptr && nxt < 3;
         if (have_next) stage_load(nxt);
         if (a.in[s]) {
-            f32x4 acc[4];
-#pragma unroll
-            for (int mt = 0; mt < 4; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            const int nsteps = st_k4(s) / 4;
-#pragma unroll 4
-            for (int st = 0; st < nsteps; ++st) {
-                const int k = st_koff(s) + 4 * st + lg;
-                const int off = tab[k];
-                const float b = wl[k * ST_WLP + li];
-#pragma unroll
-                for (int mt = 0; mt < 4; ++mt)
-                    acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[off + pbase[mt]], b, acc[mt], 0, 0, 0);
-            }
             const float sc = a.scale[s * 16 + li], sh = a.shift[s * 16 + li];
 #pragma unroll
-            for (int mt = 0; mt < 4; ++mt)
+            for (int h = 0; h < HV; ++h) {
+                f32x4 acc[MT];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) out[mt][e] += fmaxf(acc[mt][e] * sc + sh, 0.0f);
+                for (int mt = 0; mt < MT; ++mt) acc[mt] = f32x4{0.f, 0.f, 0.f, 0.f};
+                const int nsteps = st_k4(s) / 4;
+#pragma unroll 4
+                for (int st = 0; st < nsteps; ++st) {
+                    const int k = st_koff(s) + 4 * st + lg;
+                    const int off = tab[k] + 8 * h * ST_PW;
+                    const float b = wl[k * ST_WLP + li];
+#pragma unroll
+                    for (int mt = 0; mt < MT; ++mt)
+                        acc[mt] = __builtin_amdgcn_mfma_f32_16x16x4f32(planes[off + pbase[mt]], b, acc[mt], 0, 0, 0);
+                }
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) out[h][mt][e] += fmaxf(acc[mt][e] * sc + sh, 0.0f);
+            }
         }
         if (have_next) stage_store(nxt);
         if (s < 2) __syncthreads();
@@ -181,13 +199,15 @@ __global__ __launch_bounds__(256) void stem_kernel(StemArgs a)
     CT_STAMP(9);
 
 #pragma unroll
-    for (int mt = 0; mt < 4; ++mt) {
-        const int oy = oy0 + 2 * wave + (mt >> 1);
+    for (int h = 0; h < HV; ++h)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+        const int oy = oy0 + 8 * h + 2 * wave + (mt >> 1);
         if (oy >= a.H) continue;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int ox = ox0 + (mt & 1) * 16 + lg * 4 + e;
-            if (ox < a.W) a.y[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + li] = out[mt][e];
+            if (ox < a.W) a.y[(((size_t)n * a.H + oy) * a.W + ox) * a.ldy + li] = out[h][mt][e];
         }
     }
     CT_STAMP(6);
@@ -217,10 +237,17 @@ extern "C" int ct_stem_forward_parts(const float *x, const float *pre_img, const
     a.w[0] = w_x; a.w[1] = w_img; a.w[2] = w_hm;
     a.scale = scale3; a.shift = shift3; a.y = y; a.add = add; a.ldadd = ldadd;
     a.N = N; a.H = H; a.W = W; a.ldy = ldy;
-    a.tilesX = ct_cdiv(W, ST_TW); a.tilesY = ct_cdiv(H, ST_TH);
+    a.tilesX = ct_cdiv(W, ST_TW);
+    // 16-row tiles where the 8-row grid is between one and two rounds of the chip (768 resident workgroups of 140 VGPRs):
+    // its second round would run one wave per SIMD
+    const long blocks8 = (long)N * a.tilesX * ct_cdiv(H, 8);
+    const int want = ct_tune_get(CT_TUNE_STEM_ROWS);
+    const bool rows16 = want == 16 || (want == 0 && blocks8 > 768 && blocks8 <= 1536);
+    a.tilesY = ct_cdiv(H, rows16 ? 16 : 8);
     const long blocks = (long)N * a.tilesX * a.tilesY;
     if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_stem_forward: grid too large");
-    hipLaunchKernelGGL(stem_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    if (rows16) hipLaunchKernelGGL(stem_kernel<16>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(stem_kernel<8>, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
     CT_CHECK_LAUNCH("ct_stem_forward");
     return CT_OK;
 }

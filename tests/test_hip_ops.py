@@ -574,6 +574,36 @@ def test_stem_matches_torch(device, with_img, with_hm, shape):
     _close(out.to_nchw(), y, msg='stem')
 
 
+@pytest.mark.parametrize('shape', [(1, 40, 72), (2, 17, 33), (1, 64, 64)])
+def test_stem_on_16_row_tiles_is_bit_identical(device, shape):
+    """round 4: the stem on 16 x 32 tiles (two 8-row slabs per workgroup on one staging of the planes and weights; picked by
+    ct_stem_forward when the 8-row grid would be between one and two rounds of the chip, knob `stem_rows`) computes every
+    pixel with the arithmetic of the 8-row tiles: equal bit for bit, ragged heights and widths, all three stems and the two-
+    launch form (x / pre_img terms, then pre_hm on top)"""
+    from centertrack_amd import _lib, ops
+    N, H, W = shape
+    x, pi, ph = _rand(N, 3, H, W, seed=125), _rand(N, 3, H, W, seed=126), torch.rand(N, 1, H, W)
+    ws = [_rand(16, 3, 7, 7, seed=127, scale=0.1), _rand(16, 3, 7, 7, seed=128, scale=0.1),
+          _rand(16, 1, 7, 7, seed=129, scale=0.2)]
+    sc = torch.rand(3, 16) + 0.5
+    sh = _rand(3, 16, seed=130, scale=0.3)
+    lib = _lib.load()
+    outs = {}
+    try:
+        for rows in (8, 16):
+            _lib.check(lib.ct_set_tuning(b'stem_rows', rows))
+            o = ops.stem(x.to(device), pi.to(device), ph.to(device), ws[0].to(device), ws[1].to(device), ws[2].to(device),
+                         sc.to(device), sh.to(device))
+            torch.cuda.synchronize()
+            outs[rows] = o.to_nchw().cpu()
+    finally:
+        _lib.check(lib.ct_set_tuning(b'stem_rows', 0))
+    y = sum(F.relu(F.conv2d(inp, ws[i], padding=3) * sc[i].view(1, 16, 1, 1) + sh[i].view(1, 16, 1, 1))
+            for i, inp in enumerate((x, pi, ph)))
+    _close(outs[8], y, msg='stem, 8-row tiles')
+    assert torch.equal(outs[8], outs[16]), float((outs[8] - outs[16]).abs().max())
+
+
 def test_maxpool_and_upsample_add(device):
     from centertrack_amd import ops
     x = _rand(2, 32, 12, 20, seed=31)
