@@ -445,7 +445,7 @@ def main():
             out['box_calibration'] = box_calibration(device)
         except Exception as e:
             out['box_calibration'] = {'error': repr(e)}
-        out['launches_per_frame'] = len([l for l in ctx['plan']['launches'] if l.fn not in ('fork', 'join')])
+        out['launches_per_frame'] = len(ctx['plan']['launches'])
         if not args.no_roofline:
             st = kernel_pass(det.model, ctx['plan'])
             d = st['dcn']

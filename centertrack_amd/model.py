@@ -27,11 +27,6 @@ FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
 FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-pools as side outputs of the stride-2 convs
 FUSE_PROJ = os.environ.get('CENTERTRACK_FUSE_PROJ', '1') != '0'       # Tree.project computed by the tree1.conv1 launch (round 4)
 DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
-# round 4 (late): the DeformConv nodes that do not depend on level 5 (ida_1.proj_1 / node_1, ida_2.proj_1 / node_1 /
-# proj_2 / node_2: dla.py:568-574) on a second captured stream beside level 5 and the ida_0 nodes; a frame of at most
-# DCN_FORK_MAX_PIXELS input pixels in flight (more streams fill the chip without it).  '0' = one stream of launches
-DCN_FORK = os.environ.get('CENTERTRACK_DCN_FORK', '0')
-DCN_FORK_MAX_PIXELS = int(os.environ.get('CENTERTRACK_DCN_FORK_MAX_PIXELS', str(2 * 512 * 512)))
 
 
 def _fold_bn(sd, p):
@@ -43,13 +38,11 @@ def _fold_bn(sd, p):
 
 class _Launch(object):
     """One pre-built C-ABI call of the frame (`keep` pins the tensors its raw pointers refer to)."""
-    __slots__ = ('fn', 'args', 'name', 'keep', 'us', 'ws_need', 'side', 'layers')
+    __slots__ = ('fn', 'args', 'name', 'keep', 'us', 'ws_need')
 
     def __init__(self, name, fn, args, keep=(), reads=(), writes=(), us=5.0, ws_need=0):
         self.name, self.fn, self.args, self.keep = name, fn, args, keep
         self.us, self.ws_need = us, ws_need
-        self.side = False        # enqueued on the plan's second stream (between its 'fork' and 'join' entries)
-        self.layers = ()         # DCN launches: the _DcnLayer nodes they carry
 
 
 class _DcnLayer(object):
@@ -301,7 +294,6 @@ class DLASegHIP(torch.nn.Module):
 
         feats = [l0, l1]
         x = l1
-        level_end = {}
         for i in range(2, 6):
             p = 'base.level%d' % i
             cin, cout = CHANNELS[i - 1], CHANNELS[i]
@@ -321,7 +313,6 @@ class DLASegHIP(torch.nn.Module):
                 leaf(p + '.tree2', x1, P[p + '.tree2'], cout, cout, 1, R2, out)
             feats.append(out)
             x = out
-            level_end[i] = len(L)
 
         dcn_layers = []
 
@@ -356,62 +347,7 @@ class DLASegHIP(torch.nn.Module):
         knobs, dcn_launches = self._tune_dcn_schedule(dcn_layers, produced0, N, H, W, dev, tune)
         plan['dcn_knobs'] = knobs
         plan['dcn_layers'] = {ly.name: (ly.up[3] if ly.up is not None else ly.out) for ly in dcn_layers}   # name -> result view
-        fork = DCN_FORK != '0' and N * H * W <= DCN_FORK_MAX_PIXELS
-        if fork:
-            # Nodes whose inputs (and IDAUp skip tensors) do not descend from level 5 can run while level 5 and the ida_0
-            # nodes do: level 5 is eight launches of 256 workgroups, a quarter of the chip.  Same knobs, hence the same
-            # per-layer tiles, splits and summation order as the one-stream schedule -- only the grouping into launches
-            # differs, the results are bit-identical.
-            late_bufs = {id(feats[5].buf)}
-            depth_of = {}                              # result buffer of an early node -> length of its chain of nodes
-            max_depth = 2 if DCN_FORK == '2' else 99   # ('2': only the proj_1 / node_1 pairs that start from a backbone level)
-            early, late = [], []
-            for ly in dcn_layers:
-                deps = [ly.x] + ([ly.up[2]] if ly.up is not None else [])
-                depth = 1 + max(depth_of.get(id(v.buf), 0) for v in deps)
-                if any(id(v.buf) in late_bufs for v in deps) or depth > max_depth:
-                    late.append(ly)
-                    late_bufs.add(id(ly.out.buf))
-                    if ly.up is not None:
-                        late_bufs.add(id(ly.up[3].buf))
-                else:
-                    early.append(ly)
-                    depth_of[id(ly.out.buf)] = depth
-                    if ly.up is not None:
-                        depth_of[id(ly.up[3].buf)] = depth
-            fork = bool(early) and bool(late)
-        if fork:
-            del dcn_launches
-            early_l = self._schedule_dcn(early, produced0, N, dev, knobs, tune)
-            early_bufs = set()
-            for ly in early:
-                early_bufs.add(id(ly.out.buf))
-                if ly.up is not None:
-                    early_bufs.add(id(ly.up[3].buf))
-            # (for the main stream's schedule the side stream's results exist from its third slot on: behind level 5
-            #  and the two ida_0 nodes, where the one-stream schedule reads them too)
-            produced_late = dict(produced0)
-            produced_late.update({b_: 4 for b_ in early_bufs})
-            late_l = self._schedule_dcn(late, produced_late, N, dev, knobs, tune)
-            join_at = len(late_l)
-            for j, l in enumerate(late_l):
-                if any(id(v.buf) in early_bufs for ly in l.layers for v in ([ly.x] + ([ly.up[2]] if ly.up is not None else []))):
-                    join_at = j
-                    break
-            for l in early_l:
-                l.side = True
-            level5 = L[level_end[4]:]
-            del L[level_end[4]:]
-            L.append(_Launch('fork', 'fork', None))
-            L.extend(early_l)
-            L.extend(level5)
-            L.extend(late_l[:join_at])
-            L.append(_Launch('join', 'join', None))
-            L.extend(late_l[join_at:])
-            plan['side_stream'] = torch.cuda.Stream(device=dev)
-            plan['fork_events'] = (torch.cuda.Event(), torch.cuda.Event())
-        else:
-            L.extend(dcn_launches)
+        L.extend(dcn_launches)
 
         small, big = P['heads_small'], P['heads_big']
         if small:
@@ -463,12 +399,10 @@ class DLASegHIP(torch.nn.Module):
         # sequential); every DCN layer owns its workspace (the layers of a group run concurrently)
         need = max([l.ws_need for l in L if l.fn == 'conv'] + [16])
         ws = torch.empty(need // 4, dtype=torch.float32, device=dev)
-        ws_side = torch.empty(need // 4, dtype=torch.float32, device=dev) if any(l.side and l.fn == 'conv' for l in L) else None
-        plan['ws'] = [ws, ws_side]
+        plan['ws'] = [ws]
         for l in L:
             if l.fn == 'conv':
-                w_ = ws_side if l.side else ws          # (the side stream's convs run beside the main stream's)
-                l.args.workspace, l.args.workspace_bytes = w_.data_ptr(), w_.numel() * 4
+                l.args.workspace, l.args.workspace_bytes = ws.data_ptr(), ws.numel() * 4
         plan['ws_need'] = ws.numel() * 4
         return plan
 
@@ -537,19 +471,8 @@ class DLASegHIP(torch.nn.Module):
         of the stem (``run_stem_partial``): only the pre_hm term is computed, on top of it."""
         P = self._prepared
         lib = _lib.load()
-        main_st = _lib.stream_ptr()
-        side = plan.get('side_stream')
-        side_st = ctypes.c_void_p(side.cuda_stream) if side is not None else None
+        st = _lib.stream_ptr()
         for l in plan['launches']:
-            if l.fn == 'fork':                      # the side stream starts behind everything enqueued so far ...
-                plan['fork_events'][0].record(torch.cuda.current_stream())
-                side.wait_event(plan['fork_events'][0])
-                continue
-            if l.fn == 'join':                      # ... and the main stream waits for it here (inside a capture: graph edges)
-                plan['fork_events'][1].record(side)
-                torch.cuda.current_stream().wait_event(plan['fork_events'][1])
-                continue
-            st = side_st if l.side else main_st
             if l.fn == 'conv':
                 rc = lib.ct_conv2d(ctypes.byref(l.args), st)
             elif l.fn == 'dcn_group':
@@ -657,7 +580,6 @@ class DLASegHIP(torch.nn.Module):
                 convs.setdefault(ly.main, []).append(
                     _Launch(ly.name + '.offset', 'conv', d, (ly.x, omv, pk),
                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-                convs[ly.main][-1].layers = (ly,)
             elif not ly.fused and split_offsets and ly.x.C % 64 == 0:
                 part = torch.empty((ly.x.C // 64) * N * ly.x.H * ly.x.W * 32, dtype=torch.float32, device=dev)
                 offs.setdefault(ly.main, []).append(ly)
@@ -669,7 +591,6 @@ class DLASegHIP(torch.nn.Module):
                 convs.setdefault(ly.main, []).append(
                     _Launch(ly.name + '.offset', 'conv', d, (ly.x, om, pk),
                             ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
-                convs[ly.main][-1].layers = (ly,)
             own = ly.fused or part is not None
             dd = ops.make_dcn_desc(ly.x, om, pk['w'], ly.cout, pk['scale'], pk['shift'], True, ly.out, up=ly.up,
                                    split_k=ly.splits, algo=3264, om_partial=part, raw_offsets=raw,
@@ -709,7 +630,6 @@ class DLASegHIP(torch.nn.Module):
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
-                out[-1].layers = tuple(part)
 
         for t in sorted(slots):
             out.extend(convs.get(t, []))
@@ -842,10 +762,9 @@ class DLASegHIP(torch.nn.Module):
 
     def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False):
         key = (N, H, W, with_img, with_hm, fuse_sigmoid)
-        ckey = key + (DCN_FORK, FUSE_PROJ)             # (module switches a test may flip between two plans of one model)
-        if ckey not in self._plans:
-            self._plans[ckey] = self._build_plan(*key)
-        return self._plans[ckey]
+        if key not in self._plans:
+            self._plans[key] = self._build_plan(*key)
+        return self._plans[key]
 
     def forward_plan(self, plan, x, pre_img=None, pre_hm=None):
         """Copy the inputs into the plan's static buffers and enqueue all launches."""

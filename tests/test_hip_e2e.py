@@ -423,41 +423,6 @@ def test_native_frame_loop_equals_python_loop(device, monkeypatch, B, split):
                 np.testing.assert_array_equal(ref[t][1][k], got[t][1][k], err_msg='%s %s frame %d rows %s' % (native, mode, t, k))
 
 
-@pytest.mark.parametrize('B', [1, 2])
-def test_forked_dcn_schedule_in_the_captured_frame(device, monkeypatch, B):
-    """round 4: with the level-5-independent DeformConv nodes on a second captured stream (model.DCN_FORK) the frame graph
-    holds one fork and one join; results, decode rows and ids of every frame are bit-identical to the one-stream graph
-    (native loop with prefetch, the benchmarked way of running)."""
-    from centertrack_amd import detector as D, model as M
-    monkeypatch.setenv('CENTERTRACK_DCN_KNOBS', '128,4,4,1,0,0')
-    opt, model, batches, meta = _stream_setup(B)
-    T = len(batches)
-    metas = [dict(meta) for _ in range(B)]
-
-    def run(fork):
-        monkeypatch.setattr(M, 'DCN_FORK', fork)
-        det = D.StreamDetector(opt, model=model, num_streams=B)
-        out = []
-        for t in range(T):
-            kw = {'prefetch': batches[t + 1]} if t + 1 < T else {}
-            res = det.step(batches[t], metas, **kw)
-            out.append(([r.copy() for r in res], {k: np.array(v) for k, v in det.last_dets.items()}))
-        assert det._ctx['loop'] is not None and det._ctx['raw']
-        assert ('fork' in [l.name for l in det._ctx['plan']['launches']]) == (fork == '1')
-        return out
-    ref = run('0')
-    for rep in range(2):
-        got = run('1')
-        for t in range(T):
-            for s in range(B):
-                a, b = ref[t][0][s], got[t][0][s]
-                assert len(a) == len(b) and len(a) > 0, (t, s)
-                for f in ('tracking_id', 'score', 'bbox', 'ct', 'tracking', 'class', 'age', 'active', 'row'):
-                    np.testing.assert_array_equal(a[f], b[f], err_msg='frame %d stream %d %s' % (t, s, f))
-            for k in ref[t][1]:
-                np.testing.assert_array_equal(ref[t][1][k], got[t][1][k], err_msg='frame %d rows %s' % (t, k))
-
-
 def test_native_loop_reset_tracking_and_single_detector_run(device):
     """Detector.run (no prefetch) goes through the native loop from the second frame on; reset_tracking() in the middle
     of a prefetched stream drops the frame launched ahead and starts over: the second pass equals the first."""

@@ -137,59 +137,3 @@ def test_split_stem_is_bit_identical(device):
     for k, v in plan['outputs'].items():
         assert torch.equal(v, want[k]), k
     assert float(want['hm'].abs().sum()) > 0
-
-
-EARLY_DCN_NODES = {'dla_up.ida_1.proj_1', 'dla_up.ida_1.node_1', 'dla_up.ida_2.proj_1', 'dla_up.ida_2.node_1',
-                   'dla_up.ida_2.proj_2', 'dla_up.ida_2.node_2'}
-
-
-@pytest.mark.parametrize('shape', [(1, 256, 320), (2, 128, 160)])
-def test_forked_dcn_schedule_is_bit_identical(device, monkeypatch, shape):
-    """round 4: the DeformConv nodes that do not descend from level 5 (DLAUp.forward, dla.py:568-574: ida_1 and ida_2
-    start from levels 3 / 4) run on a second stream beside level 5 and the ida_0 nodes.  Same knobs -> same tiles,
-    splits and summation order per layer: every node's output, the feature map and the heads are BIT-identical to
-    the one-stream schedule; the side stream carries exactly those six nodes and the main stream joins it before the
-    first launch that reads one of their results."""
-    from centertrack_amd import model as M, weights as W
-    monkeypatch.setenv('CENTERTRACK_DCN_KNOBS', '128,4,4,1,0,0')
-    heads = W.MOT_HEADS
-    sd = W.make_synthetic_state_dict(heads, seed=5, off_std=0.05)
-    x, pre, hm = W.synthetic_inputs(*shape, seed=5)
-    model = M.DLASegHIP(heads)
-    model.load_state_dict(sd)
-    model = model.to(device)
-    outs = {}
-    for fork in ('0', '1'):
-        monkeypatch.setattr(M, 'DCN_FORK', fork)
-        for rep in range(3):                     # (replays of a racy schedule would not agree with each other either)
-            got = model(x.to(device), pre.to(device), hm.to(device))[-1]
-            torch.cuda.synchronize()
-            plan = model.get_plan(shape[0], shape[1], shape[2], True, True, False)
-            cur = ({k: v.clone() for k, v in got.items()}, plan['feat'].to_nchw().clone(),
-                   {n: v.to_nchw().clone() for n, v in plan['dcn_layers'].items()})
-            if rep == 0:
-                outs[fork] = cur
-            else:
-                for k in cur[0]:
-                    assert torch.equal(cur[0][k], outs[fork][0][k]), (fork, rep, k)
-        names = [l.name for l in plan['launches']]
-        assert ('fork' in names) == (fork == '1') and ('join' in names) == (fork == '1')
-        if fork == '1':
-            side = set()
-            for l in plan['launches']:
-                if l.side:
-                    side.update(ly.name for ly in l.layers)
-            assert side == EARLY_DCN_NODES
-            i_fork, i_join = names.index('fork'), names.index('join')
-            assert all(l.side for l in plan['launches'][i_fork + 1:i_fork + 1 + sum(l.side for l in plan['launches'])])
-            first_reader = min(i for i, l in enumerate(plan['launches'])
-                               if not l.side and any(ly.name == 'dla_up.ida_1.proj_2' for ly in l.layers))
-            assert i_fork < i_join <= first_reader
-            assert any(n.startswith('base.level5') for n in names[i_fork:i_join])       # level 5 runs beside them
-            assert not any(n.startswith('base.level4') for n in names[i_fork:])
-    a, b = outs['0'], outs['1']
-    for n in a[2]:
-        assert torch.equal(a[2][n], b[2][n]), n
-    assert torch.equal(a[1], b[1])
-    for k in a[0]:
-        assert torch.equal(a[0][k], b[0][k]), k
