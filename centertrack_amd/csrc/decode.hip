@@ -26,6 +26,7 @@
 #include "ct_common.h"
 
 namespace {
+CT_DEFINE_STAMPS(decode)    // (tools/decode_phases.py; expands to nothing in the shipped build)
 
 constexpr int SEG_MAX = 1024;      // pixels per stage-1 workgroup (<=)
 constexpr int MAXK = 512;
@@ -203,7 +204,7 @@ struct Stage2Args {
     size_t hm_bs;
     float *out;
     long long *inds;
-    int B, C, h, w, K, nseg, F;
+    int B, C, h, w, K, nseg, F;      // F = floats between consecutive rows
     int M2;                          // candidate slots per image
     int keys_final;                  // the slots already hold (score : ~(class*HW + pixel)) keys (written by stage 2a)
     float *host_out;                 // optional pinned host copy of the rows, flag raised when all images are done
@@ -274,13 +275,17 @@ __device__ __forceinline__ void bitonic_desc(unsigned long long *v, int n, int t
 }
 
 
-// ---- top-K of <= 8 keys per thread (1024 threads: <= 8192 keys) by a linear score histogram ------------------
-// The keys sit in REGISTERS (one global round trip, no second scan, no sort of the whole set): 1024 bins over the
-// score range (0, 1) -- heat maps are post-sigmoid -- are filled with wave-aggregated LDS atomics, one suffix scan
-// finds the bin b* that holds the K-th largest key, every key in a higher bin is a winner, the keys of b* itself
-// (a handful) are ranked by counting and the best `need` of them complete the set.  Exact for any input; a boundary
-// bin with more than TIECAP keys (scores clustered in < 1/1024 of the range) reports overflow and the caller falls
-// back to the general path.
+// ---- top-K of <= 8 keys per thread (1024 threads: <= 8192 keys) by a score histogram ---------------------------
+// The keys sit in REGISTERS (one global round trip, no second scan, no sort of the whole set): 1024 bins are filled
+// with LDS atomics, one suffix scan finds the bin b* that holds the K-th largest key, every key in a higher bin is a
+// winner, the keys of b* itself (a handful) are ranked by counting and the best `need` of them complete the set.
+// Exact for any input -- the bin is a monotone function of the key, nothing else is assumed; a boundary bin with more
+// than TIECAP keys (scores clustered inside one bin) reports overflow and the caller falls back to the general path.
+// Round 4: the bins are LOGARITHMIC -- exponent and six mantissa bits of the score, 64 bins per octave from 2^-16 to
+// 1 -- instead of linear in (0, 1): the survivors of a post-sigmoid heat map crowd the low end of the range (most of
+// them below 0.1, a tenth of the linear bins), where same-bin lanes serialise the histogram atomics and the boundary
+// bin held tens of keys to rank; and the winners / boundary keys are compacted with ONE atomic per wave and list
+// (wave prefix sums of the per-lane counts) instead of one per wave, list and key slot.
 constexpr int SEL_U = 8;          // keys per thread
 constexpr int SEL_BINS = 1024;
 constexpr int TIECAP = 1024;
@@ -294,8 +299,9 @@ struct SelShared {
 
 __device__ __forceinline__ int sel_bin(unsigned long long k)
 {
-    const float sc = ord2f((unsigned)(k >> 32));
-    const int b = (int)(sc * (float)SEL_BINS);
+    const unsigned o = (unsigned)(k >> 32);              // f2ord(score): order-preserving, positive floats have the top bit set
+    if (!(o & 0x80000000u)) return 0;                    // (a negative score sorts below every positive one)
+    const int b = (int)((o & 0x7fffffffu) >> 17) - ((127 - 16) << 6);
     return b < 0 ? 0 : (b > SEL_BINS - 1 ? SEL_BINS - 1 : b);
 }
 
@@ -313,7 +319,7 @@ __device__ __forceinline__ int select_topk_regs(const unsigned long long (&keys)
 #pragma unroll
     for (int u = 0; u < SEL_U; ++u) {
         bins[u] = sel_bin(keys[u]);
-        hist_add(sh.hist, (unsigned)bins[u], keys[u] != 0ull);
+        if (keys[u] != 0ull) atomicAdd(&sh.hist[bins[u]], 1u);
     }
     __syncthreads();
     // suffix sums over the 1024 bins: thread t owns bin t
@@ -352,28 +358,37 @@ __device__ __forceinline__ int select_topk_regs(const unsigned long long (&keys)
         return -1;
     }
     const int bstar = sh.bstar, need = sh.need;
+    // winners (bins above b*) and boundary keys (bin b*) of this lane as bit masks over its key slots; their counts,
+    // packed (winners : low half, boundary keys : high half -- at most 512 per wave), prefix-summed over the wave;
+    // one atomic per wave and list reserves the slots
+    unsigned hitm = 0u, tiem = 0u;
 #pragma unroll
     for (int u = 0; u < SEL_U; ++u) {
         const bool live = keys[u] != 0ull;
-        const bool hit = live && bins[u] > bstar;
-        const bool tied = live && bins[u] == bstar;
-        unsigned long long mask = __ballot(hit);
-        int base = 0;
-        if (mask) {
-            const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) base = atomicAdd(&sh.nwin, (int)__popcll(mask));
-            base = __shfl(base, leader);
-        }
-        if (hit) win[base + (int)__popcll(mask & ((1ull << lane) - 1ull))] = keys[u];
-        mask = __ballot(tied);
-        if (mask) {
-            const int leader = __ffsll((long long)mask) - 1;
-            if (lane == leader) base = atomicAdd(&sh.ntie, (int)__popcll(mask));
-            base = __shfl(base, leader);
-        }
-        if (tied) {
-            const int sl = base + (int)__popcll(mask & ((1ull << lane) - 1ull));
-            if (sl < TIECAP) sh.tie[sl] = keys[u];
+        hitm |= (live && bins[u] > bstar) ? (1u << u) : 0u;
+        tiem |= (live && bins[u] == bstar) ? (1u << u) : 0u;
+    }
+    const int packed = __popc(hitm) | (__popc(tiem) << 16);
+    int pre = packed;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const int t = __shfl_up(pre, o);
+        if (lane >= o) pre += t;
+    }
+    const int tot = __shfl(pre, 63);
+    int bh = 0, bt = 0;
+    if (lane == 63) {
+        if (tot & 0xffff) bh = atomicAdd(&sh.nwin, tot & 0xffff);
+        if (tot >> 16) bt = atomicAdd(&sh.ntie, tot >> 16);
+    }
+    int sw = __shfl(bh, 63) + ((pre - packed) & 0xffff);
+    int st = __shfl(bt, 63) + ((pre - packed) >> 16);
+#pragma unroll
+    for (int u = 0; u < SEL_U; ++u) {
+        if ((hitm >> u) & 1u) win[sw++] = keys[u];
+        if ((tiem >> u) & 1u) {
+            if (st < TIECAP) sh.tie[st] = keys[u];
+            ++st;
         }
     }
     __syncthreads();
@@ -462,6 +477,8 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     const int tid = threadIdx.x, NT = blockDim.x, lane = tid & 63;
     const int HW = a.h * a.w;
     const int M2 = a.M2;
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
     const unsigned long long *cand = a.cand + (size_t)b * M2;
     const int per_class = a.nseg * a.K;
 
@@ -473,6 +490,15 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         return (k & 0xFFFFFFFF00000000ull) | (unsigned long long)(0xFFFFFFFFu - (cls * (unsigned)HW + p));
     };
     auto get = [&](int i) -> unsigned long long { return key2(i, cand[i]); };
+    const bool in_regs = M2 <= SEL_U * 1024 && NT == 1024;
+    unsigned long long keys[SEL_U];
+    if (in_regs) {                                         // (the candidates' round trip runs under the LDS set-up below)
+#pragma unroll
+        for (int u = 0; u < SEL_U; ++u) {
+            const int i = tid + u * NT;
+            keys[u] = (i < M2) ? cand[i] : 0ull;
+        }
+    }
     int KP = 1;
     while (KP < a.K) KP <<= 1;
     for (int i = tid; i < KP; i += NT) win[i] = 0ull;
@@ -480,22 +506,24 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     __syncthreads();
     bool need_sort = true;
     bool selected = false;
-    if (M2 <= SEL_U * 1024 && NT == 1024) {
+    if (in_regs) {
         // ---- the common case (round 3): <= 8 candidates per thread, kept in registers; histogram select ----
-        unsigned long long keys[SEL_U];
 #pragma unroll
-        for (int u = 0; u < SEL_U; ++u) {
-            const int i = tid + u * NT;
-            keys[u] = (i < M2) ? key2(i, cand[i]) : 0ull;
-        }
+        for (int u = 0; u < SEL_U; ++u) keys[u] = key2(tid + u * NT, keys[u]);
+        CT_STAMP(2);
         const int rc = select_topk_regs(keys, a.K, sel, filt, false);
+        CT_STAMP(3);
         if (rc == a.K) {
-            // sort the K winners by counting (distinct keys)
-            for (int i = tid; i < a.K; i += NT) {
-                const unsigned long long k = filt[i];
+            // sort the K winners by counting (distinct keys): eight lanes per winner, each over an eighth of the list
+            for (int i0 = 0; i0 < a.K; i0 += NT / 8) {
+                const int i = i0 + (tid >> 3), part = tid & 7;
+                const unsigned long long k = (i < a.K) ? filt[i] : 0ull;
                 int r = 0;
-                for (int j = 0; j < a.K; ++j) r += (filt[j] > k) ? 1 : 0;
-                win[r] = k;
+                for (int j = part; j < a.K; j += 8) r += (filt[j] > k) ? 1 : 0;
+                r += __shfl_xor(r, 1);
+                r += __shfl_xor(r, 2);
+                r += __shfl_xor(r, 4);
+                if (i < a.K && part == 0) win[r] = k;
             }
             need_sort = false;
             selected = true;
@@ -611,6 +639,7 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         }
     }
     __syncthreads();
+    CT_STAMP(4);
     if (need_sort) bitonic_desc(win, KP, tid, NT);          // (block-uniform)
     for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
         const unsigned long long k = win[r];
@@ -636,6 +665,9 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
         }
         auto hv = [&](int hd, int ch) { return hval[hd][ch]; };
         int f = 0;
+        // (round 4: assembling the rows in LDS and storing them coalesced was measured and dropped -- the host copy's cost
+        //  is the PCIe write round trip the system fence below waits for, ~3.3 us however the stores are shaped, and the
+        //  lane-per-row stores start it a microsecond earlier: 6.6 against 9.0 us from the gathers to the raised flag)
         auto put = [&](float v) { row[f] = v; if (hrow) hrow[f] = v; ++f; };
         put(score); put((float)cls); put(xs0); put(ys0);
         float xs = xs0 + 0.5f, ys = ys0 + 0.5f;                       // decode.py:102-110
@@ -670,11 +702,16 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
             for (int ch = 0; ch < HCH[hd]; ++ch) put(hval[hd][ch]);
         }
     }
+    CT_STAMP(5);
     if (a.done_flag) {
         // every row of this image is out (device + host copy): the last image raises the host flag
         __threadfence_system();
         __syncthreads();
-        if (threadIdx.x == 0) {
+        CT_STAMP(6);
+        if (threadIdx.x == 0 && a.B == 1) {
+            // one image: this workgroup's rows are all there is (fenced above) -- no arrival counter to go through
+            __hip_atomic_store(a.done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else if (threadIdx.x == 0) {
             // acq_rel at system scope: the last arriver ACQUIRES the other workgroups' host_out stores (released by their
             // own increments) before it releases the flag to the host, which skips the runtime wait once it sees it
             const unsigned prev = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -684,6 +721,8 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
             }
         }
     }
+    CT_STAMP(7);
+    CT_STAMP_RT(8);
 }
 
 const int kHeadCh[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};

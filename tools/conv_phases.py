@@ -21,7 +21,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT)
 DBG = os.path.join(ROOT, 'centertrack_amd', 'build', 'dbg')
 LIB = os.path.join(DBG, 'libct_stamps.so')
-STAMPED = ['dcn_mfma', 'wino_mfma', 'conv_mfma', 'stem']
+STAMPED = ['dcn_mfma', 'wino_mfma', 'conv_mfma', 'stem', 'decode']
 
 
 def build():
