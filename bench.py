@@ -78,6 +78,10 @@ def parse():
     ap.add_argument('--raw-u8', action='store_true',
                     help='also report the rate with raw u8 1080p frames handed to step() (u8 H2D + device-side '
                          'pre-processing) under "raw_u8_1080p_fps" -- never the headline value')
+    ap.add_argument('--no-extra-configs', action='store_true',
+                    help='skip the BASELINE configs 3-5 / 544x960 measurements the default invocation appends as "configs"')
+    ap.add_argument('--extra-steps', type=int, default=6, help='timed steps of each appended configuration')
+    ap.add_argument('--no-box-probes', action='store_true', help='box_calibration without the latency / clock probes')
     return ap.parse_args()
 
 
@@ -202,39 +206,6 @@ def profiled_dcn():
         return None
 
 
-def box_calibration(device):
-    """What class of box produced this line (the MI355X boxes of the pool differ by 5-15 % on memory-side kernels):
-    sustained fp32 MFMA rate of a pure v_mfma_f32_16x16x4_f32 loop (ct_calib_mfma, 2 workgroups per CU) and the
-    device-to-device copy bandwidth of a 1 GiB and a 16 MiB (L2 / MALL resident) buffer, HIP events on the launch stream."""
-    import ctypes
-    from centertrack_amd import _lib
-    lib = _lib.load()
-    st = _lib.stream_ptr()
-    out = torch.zeros(1 << 20, device=device)
-
-    def timed(fn, reps=1):
-        fn()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
-            fn()
-        e1.record()
-        torch.cuda.synchronize()
-        return e0.elapsed_time(e1) / reps
-    iters, blocks = 50000, 512
-    ms = timed(lambda: lib.ct_calib_mfma(blocks, iters, ctypes.c_void_p(out.data_ptr()), st))
-    mfma = blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 4 / ms / 1e9
-    a = torch.empty(1 << 28, device=device)
-    b = torch.empty(1 << 28, device=device)
-    d2d = 2.0 * a.numel() * 4 / timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), a.numel() * 4, 0, st), 5) / 1e6
-    n = 1 << 22
-    d2d_small = 2.0 * n * 4 / timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), n * 4, 0, st), 50) / 1e6
-    del a, b
-    return {'device': torch.cuda.get_device_name(device), 'mfma_f32_tflops': round(mfma, 1),
-            'd2d_1GiB_GBps': round(d2d), 'd2d_16MiB_GBps': round(d2d_small)}
-
-
 def cpu_model():
     try:
         with open('/proc/cpuinfo') as f:
@@ -287,6 +258,11 @@ def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
                        'pure-PyTorch CPU restatement of the reference path incl. DCNv2')
 
 
+# BASELINE.json configs[2..4] at their per-GPU batch + the reference's own MOT input size (datasets/mot.py:15): measured by
+# the DEFAULT invocation after the headline and appended to its line as "configs"  -- never `value`
+EXTRA_CONFIGS = (('kitti_1280x384', 4), ('coco_512', 4), ('nusc_800x448', 4), ('mot17_544x960', 1))
+
+
 def main():
     args = parse()
     from centertrack_amd import parallel
@@ -300,6 +276,47 @@ def main():
         raise SystemExit('bench.py needs an MI355X (the hot path has no CPU fallback)')
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
+    env = (rank, world, device)
+    out = measure(args, env, headline=True)
+    default_workload = (args.config == 'mot17_512' and args.streams <= 1 and not args.height and not args.width
+                        and not args.no_graph)
+    if rank == 0 and world == 1 and default_workload and not args.no_extra_configs:
+        out['configs'] = []
+        for name, streams in EXTRA_CONFIGS:
+            a = argparse.Namespace(**vars(args))
+            a.config, a.streams, a.frames_per_step = name, streams, 0
+            a.steps, a.warmup = args.extra_steps, 2
+            a.no_resident = a.no_cpu_baseline = True
+            a.raw_u8 = False
+            t0 = time.perf_counter()
+            try:
+                o = measure(a, env, headline=False)
+                out['configs'].append({
+                    'workload': o['config']['workload'].split(';')[0], 'streams_per_gpu': streams,
+                    'fps': o['value'], 'steps': a.steps, 'frames_per_step': o['config']['frames_per_step'],
+                    'timed_region_s': o['timed_region_s'], 'ms_per_frame_batch': o['ms_per_frame_batch'],
+                    'device_ms_per_frame_batch': o['device_ms_per_frame_batch'], 'launches_per_frame': o['launches_per_frame'],
+                    'roofline': {'kernel': 'dcn_mfma_kernel (all DCNv2 launches of a frame batch)', 'bound': 'mfma',
+                                 'achieved': o['roofline']['achieved'], 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                                 'frac': o['roofline']['frac'], 'total_ms': o['roofline']['total_ms']},
+                    'roofline_conv': {'achieved': o['roofline_conv']['achieved'], 'frac': o['roofline_conv']['frac'],
+                                      'total_ms': o['roofline_conv']['total_ms'],
+                                      'algorithmic_tflops': o['roofline_conv']['algorithmic_tflops']},
+                    'mean_detections_per_frame': o['config']['mean_detections_per_frame'],
+                    'plan_hash': o['plan_hash'], 'wall_s': round(time.perf_counter() - t0, 1)})
+            except Exception as e:       # the extra configurations never cost the headline line
+                out['configs'].append({'workload': name, 'streams_per_gpu': streams, 'error': repr(e)})
+    if rank == 0:
+        print(json.dumps(out))
+        sys.stdout.flush()
+    parallel.barrier()
+    parallel.shutdown()
+
+
+def measure(args, env, headline=True):
+    """one workload (args.config x args.streams): build the detector, warm up, time, and (rank 0) describe it"""
+    from centertrack_amd import parallel
+    rank, world, device = env
 
     import scenarios as S
     from centertrack_amd import weights as W
@@ -405,9 +422,16 @@ def main():
     }
     if gathered is not None:
         out['gathered'] = gathered
+    clocks = None
     if not args.no_resident:
+        from tools import box_calib
         frames = [f.to(device) for f in frames_cpu]
+        sampler = box_calib.ClockSampler() if rank == 0 else None      # (reads sysfs beside the loop: never the headline)
+        if sampler is not None:
+            sampler.start()
         dt2, nfr2, _ = timed(lambda t: frames[t % T], args.steps)
+        if sampler is not None:
+            clocks = sampler.summary()
         out['resident_frames_fps'] = round(total_streams * nfr2 / dt2, 2)
     if rank == 0:
         ctx = det._ctx
@@ -441,10 +465,14 @@ def main():
         out['device_ms_prestage'] = round(pre_ms, 4)
         # wall - graph: what the host adds between two frame graphs (association, launch); the pre-stage runs inside it
         out['host_gap_ms_per_frame_batch'] = round(1000.0 * dt / max(1, nfr) - graph_ms, 4)
-        try:
-            out['box_calibration'] = box_calibration(device)
-        except Exception as e:
-            out['box_calibration'] = {'error': repr(e)}
+        if headline:
+            try:
+                from tools import box_calib
+                out['box_calibration'] = box_calib.box_calibration(device, probes=not args.no_box_probes)
+                if clocks is not None:
+                    out['box_calibration']['clocks_under_load'] = clocks
+            except Exception as e:
+                out['box_calibration'] = {'error': repr(e)}
         out['launches_per_frame'] = len(ctx['plan']['launches'])
         if not args.no_roofline:
             st = kernel_pass(det.model, ctx['plan'])
@@ -523,10 +551,7 @@ def main():
             except Exception as e:  # the baseline is informational; never lose the GPU line
                 out['cpu_baseline'] = {'value': None, 'unit': 'frames/s', 'cores': torch.get_num_threads(),
                                        'kind': 'port', 'sample': 'failed: %r' % (e,)}
-        print(json.dumps(out))
-        sys.stdout.flush()
-    parallel.barrier()
-    parallel.shutdown()
+    return out
 
 
 def det_rows_shape(det, cfg):

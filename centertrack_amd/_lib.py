@@ -150,6 +150,8 @@ class FrameStepArgs(ctypes.Structure):
 CT_FRAME_DEVICE, CT_FRAME_HOST, CT_FRAME_IN_PLACE, CT_FRAME_UPLOADED = range(4)
 
 
+ABI_VERSION = 101       # CT_ABI_VERSION of include/centertrack_hip.h
+
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
            'ct_conv2d_workspace_bytes', 'ct_heads_fused', 'ct_dcn_v2', 'ct_dcn_v2_workspace_bytes', 'ct_dcn_v2_offsets_bytes', 'ct_dcn_v2_group', 'ct_dcn_v2_group_workspace_bytes', 'ct_dcn_v2_group_plan', 'ct_stem_forward',
@@ -160,7 +162,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
            'ct_tracker_step_public', 'ct_tracker_step_dets', 'ct_transform_points',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
-           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_flip_merge', 'ct_flip_images',
+           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_calib_chase', 'ct_calib_stream', 'ct_calib_launches', 'ct_flip_merge', 'ct_flip_images',
            'ct_frame_loop_create', 'ct_frame_loop_destroy', 'ct_frame_loop_submit', 'ct_frame_loop_wait', 'ct_frame_loop_finish',
            'ct_frame_loop_finish_submit', 'ct_frame_loop_upload', 'ct_frame_loop_pending_slot', 'ct_frame_loop_in_flight',
            'ct_frame_loop_forget_upload', 'ct_frame_loop_prestage', 'ct_stem_forward_parts', 'ct_signal_host']
@@ -189,6 +191,9 @@ def load():
     i, p, sz = ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t
     lib.ct_last_error.restype = ctypes.c_char_p
     lib.ct_version.restype = i
+    if lib.ct_version() != ABI_VERSION:      # the ctypes structs below mirror ONE header version (tests/test_cabi.py)
+        raise CTError('%s is ABI version %d, this binding was written against %d: rebuild it (python -m '
+                      'centertrack_amd.build)' % (LIB_PATH, lib.ct_version(), ABI_VERSION))
     lib.ct_set_tuning.argtypes = [ctypes.c_char_p, i]
     lib.ct_packed_weight_elems.restype = sz
     lib.ct_packed_weight_elems.argtypes = [i, i, i]
@@ -254,6 +259,9 @@ def load():
     lib.ct_memset_async.argtypes = [p, i, sz, p]
     lib.ct_signal_host.argtypes = [p, i, p]
     lib.ct_calib_mfma.argtypes = [i, i, p, p]
+    lib.ct_calib_chase.argtypes = [p, i, ctypes.c_uint, p, p]
+    lib.ct_calib_stream.argtypes = [p, p, sz, i, i, p]
+    lib.ct_calib_launches.argtypes = [i, i, p, p]
     lib.ct_flip_merge.argtypes = [ctypes.POINTER(FlipHead), i, p, i, i, i, i, p]
     lib.ct_flip_images.argtypes = [p, p, sz, i, p]
     lib.ct_frame_loop_create.restype = p

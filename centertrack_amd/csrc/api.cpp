@@ -16,7 +16,10 @@ void ct_set_error(const char *fmt, ...)
 }
 
 extern "C" const char *ct_last_error(void) { return g_err; }
-extern "C" int ct_version(void) { return 100; }
+// 101 (round 5): ct_conv_desc grew by proj_w_packed / proj_scale / proj_shift / proj_y / proj_ldy (round 4) and the tuning
+// key "dcn_offs16" became "stem_rows"; a caller built against the 100 header passes a shorter struct -- it must compare
+// ct_version() with CT_ABI_VERSION of the header it was compiled against before the first descriptor call.
+extern "C" int ct_version(void) { return CT_ABI_VERSION; }
 
 // ---- tuning knobs -------------------------------------------------------------------------
 enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,

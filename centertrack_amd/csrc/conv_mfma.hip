@@ -577,7 +577,9 @@ int make_plan(const ct_conv_desc *d, Plan *p)
     if (p->ks >= 0 && splits <= 0) splits = 1;
     if (splits <= 0) {
         splits = 1;
-        if (d->workspace && tiles < 256) {
+        // (the fused projection has no split-K form: an automatic split would turn a valid descriptor into a plan-time
+        // error, so only an EXPLICIT split_k > 1 is refused below; ct_conv2d_workspace_bytes reports 0 accordingly)
+        if (d->workspace && tiles < 256 && !d->proj_w_packed) {
             splits = (int)((ct_tune_get(CT_TUNE_SPLITK_TARGET) + tiles - 1) / tiles);
             // keep at least ~2 chunks (>= 18 MFMA steps for 3x3) per split
             const int maxs = p->nchunks >= 2 ? p->nchunks / 2 : 1;

@@ -107,6 +107,77 @@ extern "C" int ct_calib_mfma(int blocks, int iters, float *out, void *stream)
     return CT_OK;
 }
 
+// ---- box probes (diagnostics of bench.py's "box_calibration": what separates the boxes of a pool) ----
+// (1) dependent-load latency: ONE lane follows a ring of `hops` indices through `ring` (one element per 128-byte line,
+//     a random cycle built by the host) -- footprint chosen by the caller: inside one L2 (<= 2 MB), inside the
+//     Infinity Cache (64 MB), HBM (>= 1 GiB), or PINNED HOST memory (the PCIe read round trip).  out[0] = last index
+//     (keeps the chain alive), out[1] = elapsed ticks of s_memrealtime (100 MHz, constant), out[2] = s_memtime clocks.
+__global__ void calib_chase_kernel(const unsigned *ring, int hops, unsigned start, unsigned long long *out)
+{
+    unsigned idx = start;
+    for (int i = 0; i < 64; ++i) idx = ring[(size_t)idx * 32];      // first touches (page walks) outside the interval
+    const unsigned long long r0 = __builtin_amdgcn_s_memtime(), t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < hops; ++i) idx = ring[(size_t)idx * 32];
+    const unsigned long long r1 = __builtin_amdgcn_s_memtime(), t1 = __builtin_amdgcn_s_memrealtime();
+    out[0] = idx;
+    out[1] = t1 - t0;
+    out[2] = r1 - r0;
+}
+
+extern "C" int ct_calib_chase(const unsigned *ring, int hops, unsigned start, unsigned long long *out, void *stream)
+{
+    if (!ring || hops <= 0 || !out) CT_FAIL_ARG("ct_calib_chase: bad arguments");
+    hipLaunchKernelGGL(calib_chase_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, ring, hops, start, out);
+    CT_CHECK_LAUNCH("ct_calib_chase");
+    return CT_OK;
+}
+
+// (2) streaming copy at a chosen occupancy: `blocks` workgroups of `threads` lanes, each lane moves 16-byte vectors with
+//     `inflight` loads issued before the first store -- 256 x 256 x 1 is "one wave per SIMD, one load in flight", the
+//     regime of the frame's latency-bound launches; 2048 x 256 x 4 is the bandwidth regime.
+template <int INFLIGHT>
+__global__ __launch_bounds__(256) void calib_stream_kernel(const float4 *src, float4 *dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    for (; i + (INFLIGHT - 1) * stride < n; i += INFLIGHT * stride) {
+        float4 v[INFLIGHT];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) v[k] = src[i + k * stride];
+#pragma unroll
+        for (int k = 0; k < INFLIGHT; ++k) dst[i + k * stride] = v[k];
+    }
+    for (; i < n; i += stride) dst[i] = src[i];
+}
+
+extern "C" int ct_calib_stream(const void *src, void *dst, size_t bytes, int blocks, int inflight, void *stream)
+{
+    if (!src || !dst || blocks <= 0 || (bytes & 15)) CT_FAIL_ARG("ct_calib_stream: bad arguments");
+    const size_t n = bytes / 16;
+    if (inflight >= 4)
+        hipLaunchKernelGGL(calib_stream_kernel<4>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst, n);
+    else
+        hipLaunchKernelGGL(calib_stream_kernel<1>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst, n);
+    CT_CHECK_LAUNCH("ct_calib_stream");
+    return CT_OK;
+}
+
+// (3) `n` dependent launches of a `blocks`-workgroup kernel that adds 1 to what its predecessor wrote: the kernel
+//     boundary (dispatch + argument fetch + first load + drain) of this box, per launch.
+__global__ __launch_bounds__(256) void calib_chain_kernel(float *buf)
+{
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    buf[i] = buf[i] + 1.0f;
+}
+
+extern "C" int ct_calib_launches(int n, int blocks, float *buf, void *stream)
+{
+    if (n <= 0 || blocks <= 0 || !buf) CT_FAIL_ARG("ct_calib_launches: bad arguments");
+    for (int k = 0; k < n; ++k) hipLaunchKernelGGL(calib_chain_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, buf);
+    CT_CHECK_LAUNCH("ct_calib_launches");
+    return CT_OK;
+}
+
 // ---- end-of-frame flag in pinned host memory ----
 __global__ void signal_host_kernel(int *flag, int value)
 {

@@ -451,6 +451,21 @@ class StreamDetector(object):
             m['_trans_inv'] = cached = (ident, tinv)
         return cached[1]
 
+    def _checked_submit(self, ctx, rc, what):
+        """a submit can fail AFTER its graph launch (upload of the next frame, its pre-stage; frame_loop.hip: "the frame
+        itself is in flight"): drain that frame and forget the half-issued upload before raising, so that the next
+        step() finds an idle loop instead of failing with 'the previous frame was not finished' for ever.  The error text
+        is read first -- the calls below would overwrite it."""
+        if rc == 0:
+            return
+        lib = _lib.load()
+        msg = lib.ct_last_error().decode('utf-8', 'replace')
+        lib.ct_frame_loop_wait(ctx['loop'])
+        lib.ct_frame_loop_forget_upload(ctx['loop'])
+        ctx['launched'] = None
+        self._prefetched = None
+        raise _lib.CTError('%s failed (%d): %s' % (what, rc, msg))
+
     def _drop_launched(self, ctx):
         """a frame the native loop launched ahead will not be used (other frame handed over, reset): wait for it and
         give its slot back -- the trackers never saw it"""
@@ -531,7 +546,7 @@ class StreamDetector(object):
             if self._rows_free is not None:                    # (left by a step of the Python path)
                 ctx['loop_stream'].wait_event(self._rows_free)
                 self._rows_free = None
-            _lib.check(lib.ct_frame_loop_submit(loop, ctypes.byref(cur)), 'ct_frame_loop_submit')
+            self._checked_submit(ctx, lib.ct_frame_loop_submit(loop, ctypes.byref(cur)), 'ct_frame_loop_submit')
             ctx['slot'] = (slot + 1) % n
         if can_prefetch:
             self._prefetched = (prefetch, prefetch._version, (slot + 1) % n)
@@ -547,8 +562,9 @@ class StreamDetector(object):
         if early:
             # finish this frame and launch the next one in ONE native call: the GPU idles for the association only
             nxt.slot, nxt.frame_kind, nxt.frame, nxt.next_frame = (slot + 1) % n, _lib.CT_FRAME_UPLOADED, None, None
-            _lib.check(lib.ct_frame_loop_finish_submit(loop, ctypes.byref(cur), counts.ctypes.data, ctypes.byref(nxt)),
-                       'ct_frame_loop_finish_submit')
+            ctx['slot'] = (slot + 1) % n            # (where the loop stands if the call below fails half-way)
+            self._checked_submit(ctx, lib.ct_frame_loop_finish_submit(loop, ctypes.byref(cur), counts.ctypes.data,
+                                                                      ctypes.byref(nxt)), 'ct_frame_loop_finish_submit')
             ctx['slot'] = (slot + 2) % n
             ctx['launched'] = (prefetch, prefetch._version, list(metas),
                                [self._meta_transforms(m).tobytes() for m in metas])

@@ -28,8 +28,12 @@ def init_from_env(backend=None):
     (``group_active``), which is how a single-GPU box exercises them (tests/test_hip_rccl.py)."""
     if 'RANK' not in os.environ:
         return 0, 1, int(os.environ.get('LOCAL_RANK', 0))
-    rank, world = int(os.environ['RANK']), int(os.environ['WORLD_SIZE'])
+    rank, world = int(os.environ['RANK']), int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', rank))
+    if world == 1 and not ('MASTER_ADDR' in os.environ and 'MASTER_PORT' in os.environ) and not dist.is_initialized():
+        # RANK exported by something that is not a launcher (a scheduler's task index): a plain single-process run --
+        # the one-rank group is only created when torchrun's rendezvous variables are there
+        return 0, 1, local
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     if backend is None:
@@ -116,6 +120,14 @@ class DetectionGatherer(object):
         # with a process group the exchange is a real collective even for a group of one rank (RCCL on a one-GPU box);
         # without one (plain `python bench.py`) the rows are only copied
         self.collective = world > 1 or group_active()
+        if self.collective:
+            if not group_active():
+                raise RuntimeError('DetectionGatherer(world=%d) needs an initialised torch.distributed group' % world)
+            if dist.get_world_size() != world:
+                # (recv is sized for `world` ranks: a collective over another group size would fail inside RCCL with a
+                # shape error -- say what is wrong instead)
+                raise ValueError('DetectionGatherer(world=%d) inside a process group of %d ranks: pass the group\'s '
+                                 'world size' % (world, dist.get_world_size()))
         self.overlap = bool(overlap) and device.type == 'cuda'
         self.consumed_steps = 0
         self.consumed_detections = 0

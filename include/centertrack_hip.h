@@ -34,8 +34,13 @@ extern "C" {
 #define CT_RELU 1
 #define CT_OUT_NCHW 2      /* write y as NCHW [N,Cout,Ho,Wo] instead of an NHWC view */
 
+/* ABI version of THIS header: bumped whenever a descriptor struct changes layout or a tuning key changes meaning.  A
+ * binding compares it with ct_version() of the loaded library before the first descriptor call (centertrack_amd/_lib.py
+ * does).  100 = rounds 1-3; 101 = ct_conv_desc.proj_* (fused Tree.project), key "stem_rows", box probes. */
+#define CT_ABI_VERSION 101
+
 const char *ct_last_error(void);
-int ct_version(void);
+int ct_version(void);                      /* CT_ABI_VERSION the library was built with */
 /* Experiment knobs of the launch heuristics (process-global; not part of the reference's
  * interface): "conv_cfg" (-1 auto, 0..5 force a tile shape), "conv_pipe" (0/1 pinned B prefetch),
  * "conv_small_tiles" (below this many workgroups pick the smaller tile), "splitk_target"
@@ -391,6 +396,16 @@ int ct_signal_host(int *flag, int value, void *stream);
  * independent-chain v_mfma_f32_16x16x4_f32 on registers -- the sustained fp32 MFMA rate of the box a bench line was
  * measured on (bench.py's "box_calibration").  out: DEVICE float[>= blocks * 256] (never written in practice). */
 int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
+/* Box probes (round 5, diagnostics): what separates the "fast" from the "slow" boxes of a pool on the latency-bound
+ * launches of a one-stream frame.  ct_calib_chase: ONE lane follows `hops` dependent loads through `ring` (uint32 index
+ * of the next 128-byte line at every line start; a random cycle built by the caller; DEVICE memory of the footprint
+ * under test or PINNED HOST memory); out (DEVICE uint64[3]) = last index, elapsed 100 MHz ticks, elapsed shader clocks.
+ * ct_calib_stream: copy `bytes` (multiple of 16) with `blocks` workgroups of 256 lanes and 1 or 4 16-byte loads in
+ * flight per lane.  ct_calib_launches: n dependent launches of a `blocks`-workgroup kernel over buf (DEVICE
+ * float[blocks * 256]). */
+int ct_calib_chase(const unsigned *ring, int hops, unsigned start, unsigned long long *out, void *stream);
+int ct_calib_stream(const void *src, void *dst, size_t bytes, int blocks, int inflight, void *stream);
+int ct_calib_launches(int n, int blocks, float *buf, void *stream);
 
 /* ---- the host loop of one frame of B streams, natively (round 3) ----------------------------------------------
  * Replaces, for the steady state of the tracking path, the per-frame host work of Detector.run

@@ -27,7 +27,8 @@ def test_bench_under_torchrun_one_rank_goes_through_rccl(device):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', MASTER_ADDR='127.0.0.1')
     cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', '1', '--master-addr', '127.0.0.1',
            '--master-port', str(_free_port()), os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
-           '--frames-per-step', '4', '--no-cpu-baseline', '--no-roofline', '--no-resident']
+           '--frames-per-step', '4', '--no-cpu-baseline', '--no-roofline', '--no-resident', '--no-extra-configs',
+           '--no-box-probes']
     p = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [l for l in p.stdout.splitlines() if l.startswith('{')]

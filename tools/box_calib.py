@@ -1,27 +1,36 @@
 #!/usr/bin/env python
-"""One JSON line that characterises the GPU box a measurement ran on: sustained fp32 MFMA rate (tools/micro/mfma_peak.hip,
-2 WG/CU, MFMA only), device-to-device copy bandwidth (1 GiB) and the duration of an empty-kernel graph node.  The MI355X
-boxes of the pool differ by 5-15 % on memory-bound kernels; profiles/ records this line beside every sweep."""
+"""What box did a measurement run on?  ``python tools/box_calib.py`` prints one JSON line; ``bench.py`` embeds the same
+dict as ``box_calibration``.  The MI355X boxes of the pool run the one-stream frame 16 % apart while their fp32 MFMA
+loops agree to 0.3 %; rounds 3/4 recorded only the MFMA rate and the device-to-device copy bandwidth, which did not
+predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for:
+
+  chase_ns       dependent-load latency of ONE lane through a random ring of 128-byte lines (ct_calib_chase): 16 KB
+                 (the CU's L1), 1 MB (one XCD's L2), 64 MB (Infinity Cache), 2 GiB (HBM) and 1 MB of PINNED HOST memory
+                 (the PCIe round trip the decode's row stores and the end-of-frame flag see)
+  shader_mhz     s_memtime clocks / s_memrealtime ticks of those one-lane kernels: the shader clock a nearly idle chip runs
+  stream_GBps    copy of 1 GiB at one wave per SIMD with one 16-byte load in flight per lane (the regime of the stem and
+                 the decode) and at 8 workgroups per CU with four in flight (the bandwidth regime)
+  launch_us      dependent kernel boundary inside a captured graph: 200 launches of 1 / 256 workgroups
+  sysfs          clock levels (sclk / mclk / fclk / socclk: active level and the table), partition modes and power cap as
+                 the amdgpu driver reports them for the device
+  clocks_under_load (bench.py only) the active sclk / mclk / fclk levels sampled every 20 ms while the resident-frame
+                 loop runs
+"""
 import ctypes
+import glob
 import json
 import os
-import subprocess
 import sys
+import threading
+import time
 
-import torch
-
-HERE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'micro')
-SO = os.path.join(HERE, 'libmfma_peak.so')
-if not os.path.exists(SO):
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-O3', '-shared', '-fPIC', '-o', SO,
-                           os.path.join(HERE, 'mfma_peak.hip')])
-lib = ctypes.CDLL(SO)
-lib.mfma_peak.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
-out = torch.zeros(1 << 20, device='cuda')
-st = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
 
-def timed(fn, reps=1):
+def _timed(fn, reps=1):
+    import torch
     fn()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -33,17 +42,191 @@ def timed(fn, reps=1):
     return e0.elapsed_time(e1) / reps
 
 
-iters = 100000
-ms = timed(lambda: lib.mfma_peak(0, 512, iters, out.data_ptr(), st))
-mfma = 512 * 4 * iters * 16 * 2.0 * 16 * 16 * 4 / ms / 1e9
-a = torch.empty(1 << 28, device='cuda')
-b = torch.empty(1 << 28, device='cuda')
-ms = timed(lambda: b.copy_(a), reps=5)
-d2d = 2.0 * a.numel() * 4 / ms / 1e6          # read + write, GB/s
-small = torch.empty(1 << 22, device='cuda')   # 16 MiB: the size of one 128x128x64 activation x 4 (L2 / MALL resident)
-small2 = torch.empty(1 << 22, device='cuda')
-ms = timed(lambda: small2.copy_(small), reps=50)
-d2d_small = 2.0 * small.numel() * 4 / ms / 1e6
-name = torch.cuda.get_device_name(0)
-print(json.dumps({'box_calibration': {'device': name, 'mfma_f32_tflops': round(mfma, 1), 'd2d_1GiB_GBps': round(d2d, 0),
-                                      'd2d_16MiB_GBps': round(d2d_small, 0)}}))
+def _ring(n_lines, device, pinned=False):
+    """uint32 index of the next line at the start of every 128-byte line: one random cycle over all lines"""
+    import torch
+    g = torch.Generator(device='cpu').manual_seed(5)
+    perm = torch.randperm(n_lines, generator=g, dtype=torch.int64)
+    nxt = torch.empty(n_lines, dtype=torch.int32)
+    nxt[perm] = torch.roll(perm, -1).to(torch.int32)
+    if pinned:
+        ring = torch.zeros(n_lines * 32, dtype=torch.int32).pin_memory()
+        ring[::32] = nxt
+        return ring
+    ring = torch.zeros(n_lines * 32, dtype=torch.int32, device=device)
+    ring[::32] = nxt.to(device)
+    return ring
+
+
+def chase(lib, st, device):
+    import torch
+    out = torch.zeros(3, dtype=torch.int64, device=device)
+    res, mhz = {}, {}
+    for name, lines, hops, pinned in (('l1_16KB', 128, 20000, False), ('l2_1MB', 8192, 20000, False),
+                                      ('mall_64MB', 1 << 19, 20000, False), ('hbm_2GiB', 1 << 24, 20000, False),
+                                      ('host_pinned_1MB', 8192, 3000, True)):
+        ring = _ring(lines, device, pinned)
+        if not pinned:
+            ring.sum().item()                 # one streaming pass: the footprint is in whatever level can hold it
+        best = None
+        start = 0
+        for rep in range(3):
+            # every repetition CONTINUES the chain where the last one stopped: re-walking the same 20 000 lines (2.5 MB)
+            # would find them in the L2 whatever the footprint (the first version of this probe did: 90 ns "HBM")
+            lib.ct_calib_chase(ctypes.c_void_p(ring.data_ptr()), hops, start, ctypes.c_void_p(out.data_ptr()), st)
+            torch.cuda.synchronize()
+            start, ticks, clocks = (int(v) for v in out.tolist())
+            ns = ticks * 10.0 / hops
+            if best is None or ns < best[0]:
+                best = (ns, clocks / max(1, ticks) * 100.0)
+        res[name] = round(best[0], 1)
+        mhz[name] = round(best[1])
+        del ring
+    return res, mhz
+
+
+def stream(lib, st, device):
+    import torch
+    n = 1 << 28
+    a = torch.empty(n, device=device)
+    b = torch.empty(n, device=device)
+    res = {}
+    for name, blocks, inflight in (('1GiB_1wave_per_simd_1load', 256, 1), ('1GiB_8wg_per_cu_4loads', 2048, 4)):
+        ms = _timed(lambda: lib.ct_calib_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n * 4, blocks, inflight, st), 3)
+        res[name] = round(2.0 * n * 4 / ms / 1e6)
+    m = 1 << 22           # 16 MiB: L2 / Infinity-Cache resident
+    ms = _timed(lambda: lib.ct_calib_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), m * 4, 256, 1, st), 20)
+    res['16MiB_1wave_per_simd_1load'] = round(2.0 * m * 4 / ms / 1e6)
+    del a, b
+    return res
+
+
+def launches(lib, device):
+    import torch
+    from centertrack_amd import _lib
+    buf = torch.zeros(256 * 256, device=device)
+    res = {}
+    N = 200
+    for blocks in (1, 256):
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            lib.ct_calib_launches(4, blocks, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            lib.ct_calib_launches(N, blocks, ctypes.c_void_p(buf.data_ptr()), _lib.stream_ptr())
+        ms = _timed(g.replay, 5)
+        res['graph_%dwg' % blocks] = round(ms * 1e3 / N, 2)
+    return res
+
+
+def _card_dir():
+    """sysfs directory of the first amdgpu device that exposes clock tables"""
+    for d in sorted(glob.glob('/sys/class/drm/card*/device')):
+        if os.path.exists(os.path.join(d, 'pp_dpm_sclk')):
+            return d
+    return None
+
+
+def _read(path, limit=400):
+    try:
+        with open(path) as f:
+            return f.read(limit).strip()
+    except OSError:
+        return None
+
+
+def _active(table):
+    """'0: 132Mhz\\n1: 2400Mhz *' -> 2400 (MHz of the starred level)"""
+    if not table:
+        return None
+    for line in table.splitlines():
+        if '*' in line:
+            try:
+                return int(''.join(c for c in line.split(':', 1)[1] if c.isdigit()))
+            except (ValueError, IndexError):
+                return None
+    return None
+
+
+def sysfs():
+    d = _card_dir()
+    if d is None:
+        return {'error': 'no /sys/class/drm/card*/device/pp_dpm_sclk'}
+    out = {'dir': d}
+    for k in ('pp_dpm_sclk', 'pp_dpm_mclk', 'pp_dpm_fclk', 'pp_dpm_socclk'):
+        t = _read(os.path.join(d, k))
+        if t is not None:
+            out[k] = t.replace('\n', ' | ')
+    for k in ('current_compute_partition', 'current_memory_partition', 'power_dpm_force_performance_level',
+              'gpu_busy_percent', 'mem_busy_percent'):
+        t = _read(os.path.join(d, k), 80)
+        if t is not None:
+            out[k] = t
+    for h in glob.glob(os.path.join(d, 'hwmon', 'hwmon*')):
+        for k in ('power1_cap', 'power1_average', 'power1_input', 'freq1_input', 'freq2_input', 'temp1_input'):
+            t = _read(os.path.join(h, k), 40)
+            if t is not None:
+                out[k] = t
+    return out
+
+
+class ClockSampler(threading.Thread):
+    """active sclk / mclk / fclk levels every `period` s while something else runs; summary() -> min / median / max MHz"""
+
+    def __init__(self, period=0.02):
+        threading.Thread.__init__(self, daemon=True)
+        self.period, self.dir, self.stop_flag, self.samples = period, _card_dir(), threading.Event(), []
+
+    def run(self):
+        if self.dir is None:
+            return
+        while not self.stop_flag.is_set():
+            self.samples.append(tuple(_active(_read(os.path.join(self.dir, k))) for k in ('pp_dpm_sclk', 'pp_dpm_mclk', 'pp_dpm_fclk')))
+            time.sleep(self.period)
+
+    def summary(self):
+        self.stop_flag.set()
+        self.join(1.0)
+        out = {'samples': len(self.samples)}
+        for i, k in enumerate(('sclk', 'mclk', 'fclk')):
+            v = sorted(s[i] for s in self.samples if s[i] is not None)
+            if v:
+                out[k + '_mhz'] = {'min': v[0], 'median': v[len(v) // 2], 'max': v[-1]}
+        return out
+
+
+def box_calibration(device=None, probes=True):
+    import torch
+    from centertrack_amd import _lib
+    lib = _lib.load()
+    st = _lib.stream_ptr()
+    device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
+    out = torch.zeros(1 << 20, device=device)
+    iters, blocks = 50000, 512
+    ms = _timed(lambda: lib.ct_calib_mfma(blocks, iters, ctypes.c_void_p(out.data_ptr()), st))
+    mfma = blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 4 / ms / 1e9
+    a = torch.empty(1 << 28, device=device)
+    b = torch.empty(1 << 28, device=device)
+    d2d = 2.0 * a.numel() * 4 / _timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), a.numel() * 4, 0, st), 5) / 1e6
+    n = 1 << 22
+    d2d_small = 2.0 * n * 4 / _timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), n * 4, 0, st), 50) / 1e6
+    del a, b
+    res = {'device': torch.cuda.get_device_name(device), 'mfma_f32_tflops': round(mfma, 1),
+           'd2d_1GiB_GBps': round(d2d), 'd2d_16MiB_GBps': round(d2d_small)}
+    if probes:
+        for key, fn in (('chase', lambda: chase(lib, st, device)), ('stream_GBps', lambda: stream(lib, st, device)),
+                        ('launch_us', lambda: launches(lib, device)), ('sysfs', sysfs)):
+            try:
+                v = fn()
+                if key == 'chase':
+                    res['chase_ns'], res['shader_mhz'] = v
+                else:
+                    res[key] = v
+            except Exception as e:       # a probe must never cost the bench line
+                res[key] = {'error': repr(e)}
+    return res
+
+
+if __name__ == '__main__':
+    print(json.dumps({'box_calibration': box_calibration()}))

@@ -11,7 +11,7 @@ mkdir -p $OUT
 export CENTERTRACK_TUNE_CACHE=${CENTERTRACK_TUNE_CACHE:-/tmp/tune_profile.json}      # the profiled runs replay the tuned choices
 cd $R
 python bench.py > $OUT/${TAG}_bench_n1.json 2> $OUT/${TAG}_bench_n1.err
-BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-resident"
+BENCH="python $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-roofline --no-resident --no-extra-configs --no-box-probes"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_kt /tmp/pmcA /tmp/pmcB /tmp/pmcC
 rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -- $BENCH > /dev/null 2>&1
@@ -20,7 +20,7 @@ python $R/tools/rocpd_stats.py $(ls /tmp/prof_kt/*/*.db | head -1) 40 > $OUT/${T
 rm -rf /tmp/prof_csv
 rocprofv3 --kernel-trace --output-format csv -d /tmp/prof_csv -o kt -- $BENCH > /dev/null 2>&1
 python $R/tools/rounds.py $(ls /tmp/prof_csv/*kernel_trace.csv /tmp/prof_csv/*/*kernel_trace.csv 2>/dev/null | head -1) > $OUT/${TAG}_rounds_b1.txt 2>&1
-BENCH2="python $R/bench.py --steps 1 --warmup 1 --frames-per-step 24 --no-cpu-baseline --no-roofline --no-resident"
+BENCH2="python $R/bench.py --steps 1 --warmup 1 --frames-per-step 24 --no-cpu-baseline --no-roofline --no-resident --no-extra-configs --no-box-probes"
 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE --output-format csv -d /tmp/pmcA -o pmcA -- $BENCH2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d /tmp/pmcB -o pmcB -- $BENCH2 > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d /tmp/pmcC -o pmcC -- $BENCH2 > /dev/null 2>&1

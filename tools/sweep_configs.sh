@@ -16,13 +16,13 @@ export CENTERTRACK_TUNE_CACHE=${CENTERTRACK_TUNE_CACHE:-/tmp/tune_sweep.json}
 python $R/tools/box_calib.py > $OUT/${TAG}_box.json 2>/dev/null   # (every bench line carries its own box_calibration since round 3)
 run() {  # config streams
     cd $R
-    python bench.py --config $1 --streams $2 --steps 10 --warmup 3 --no-cpu-baseline \
+    python bench.py --config $1 --streams $2 --steps 10 --warmup 3 --no-cpu-baseline --no-extra-configs --no-box-probes \
         >> $OUT/${TAG}_sweep.jsonl 2>> $OUT/${TAG}_sweep.err
     if [ -n "$PROF" ]; then
         cd /tmp && export TMPDIR=/tmp
         rm -rf /tmp/prof_sw
         rocprofv3 --kernel-trace --stats -d /tmp/prof_sw -- python $R/bench.py --config $1 --streams $2 --steps 3 --warmup 1 \
-            --no-cpu-baseline --no-roofline --no-resident > /dev/null 2>&1
+            --no-cpu-baseline --no-roofline --no-resident --no-extra-configs --no-box-probes > /dev/null 2>&1
         python $R/tools/rocpd_stats.py $(ls /tmp/prof_sw/*/*.db | head -1) 30 > $OUT/${TAG}_kstats_$1_b$2.txt
     fi
 }
