@@ -816,9 +816,21 @@ class Detector(object):
     def __init__(self, opt, model=None, use_graph=True, native_host=True):
         if not hasattr(opt, 'device'):
             opt.device = torch.device('cuda')
-        self.opt = opt
+        self._init_host(opt)
         self.impl = StreamDetector(opt, model=model, num_streams=1, use_graph=use_graph, native_host=native_host)
         self.model = self.impl.model
+
+    def _init_host(self, opt):
+        """the host-side state ``pre_process`` / ``frame_meta`` / the prefetch-dict parser need (no device): what a
+        DataLoader worker process of test.py:75 touches"""
+        scales = list(getattr(opt, 'test_scales', [1.0]))
+        if len(scales) != 1:
+            # detector.py:78-133,371-377 loops over the scales and merges the detections before ONE tracker step; no
+            # tracking experiment of the reference uses it (experiments/*.sh) and the fused frame (decode -> association
+            # in one native call) has no multi-scale form: refuse instead of silently taking the first scale
+            raise _lib.CTError('centertrack_amd.Detector supports one test scale (got test_scales=%s): multi-scale '
+                               'testing (detector.py:78, merge_outputs) is not part of the accelerated path' % scales)
+        self.opt = opt
         self.mean, self.std = MEAN, STD
         self.pause = not getattr(opt, 'no_pause', True)
         self.rest_focal_length = (REST_FOCAL_LENGTH.get(getattr(opt, 'dataset', ''), 1200)
@@ -876,13 +888,7 @@ class Detector(object):
         start = time.time()
         x = image_or_path_or_tensor
         if isinstance(x, dict):                                # prefetch path, detector.py:66-70,84-92
-            scale = self.opt.test_scales[0] if hasattr(self.opt, 'test_scales') else 1.0
-            images = x['images'][scale][0]
-            m = {k: (v.numpy()[0] if torch.is_tensor(v) else v) for k, v in x['meta'][scale].items()}
-            for k in ('pre_dets', 'cur_dets'):
-                if k in x['meta']:
-                    m[k] = x['meta'][k]
-            meta = m
+            images, meta = self.parse_prefetched(x)
         elif torch.is_tensor(x):
             images = x
         elif isinstance(x, (str, os.PathLike)) or isinstance(x, np.ndarray):
@@ -904,6 +910,18 @@ class Detector(object):
         ret = {'results': results, 'tot': end - start, 'load': loaded - start, 'display': 0.0}
         ret.update(timers)
         return ret
+
+    def parse_prefetched(self, x):
+        """the dict test.py's ``PrefetchDataset`` yields through a DataLoader of batch size 1 (test.py:22-51,74-76:
+        ``{'images': {scale: [1,B,3,H,W]}, 'image': ..., 'meta': {scale: {key: [1,...]}, 'pre_dets'/'cur_dets': ...}}``)
+        -> (images [B,3,H,W], meta) exactly as detector.py:84-92 unpacks it"""
+        scale = self.opt.test_scales[0] if hasattr(self.opt, 'test_scales') else 1.0
+        images = x['images'][scale][0]
+        meta = {k: (v.numpy()[0] if torch.is_tensor(v) else v) for k, v in x['meta'][scale].items()}
+        for k in ('pre_dets', 'cur_dets'):
+            if k in x['meta']:
+                meta[k] = x['meta'][k]
+        return images, meta
 
     def reset_tracking(self):
         self.impl.reset_tracking()

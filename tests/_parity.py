@@ -50,6 +50,10 @@ class StreamParity(object):
         self.tie_ids = set()        # oracle ids born inside a tie group (the only ones allowed to map off-identity)
         self.frames = 0
         self.detections = 0
+        # order changes inside tie groups that only exist because rank_tie is wider than TIE (consecutive oracle scores
+        # 1e-5 .. rank_tie apart): tolerated one by one, but COUNTED -- a decode that mis-orders close scores
+        # systematically would swap in every frame, fp32 noise does in < 1 % of them (advisor, round 4)
+        self.wide_swaps = []
 
     @staticmethod
     def _key(d, b, i):
@@ -86,6 +90,9 @@ class StreamParity(object):
             assert ours == ref, '%s: top-K entries at ranks %d..%d differ\n got %s\nwant %s' % (tag, a, b - 1, ours, ref)
             if b - a > 1:
                 tied_keys.update(ref)
+                if self.rank_tie > TIE and [self._key(gd, gb, i) for i in range(a, b)] != [self._key(od, 0, i) for i in range(a, b)] \
+                        and max(float(sc[i - 1] - sc[i]) for i in range(a + 1, b)) >= TIE:
+                    self.wide_swaps.append((t, a, b - 1, float(sc[a] - sc[b - 1])))
         # (also below the threshold cut the rank of the first n entries is what the tracker sees: nothing else matters)
         by_key = {self._key(gd, gb, i): i for i in range(n)}
         for j in range(n):                                         # decode-level values on the output grid

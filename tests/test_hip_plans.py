@@ -58,3 +58,7 @@ def test_benchmarked_plan_matches_oracle(device, name, streams, sample, T):
     stopped = [(c.tag,) + c.stopped for c in checks if c.stopped is not None]
     assert compared >= (2 * T * len(sample) + 2) // 3, 'threshold ties ended too many streams early: %s' % (stopped,)
     assert sum(c.detections for c in checks) >= 10 * compared
+    # the 5e-5 rank-tie width must stay an exception: order changes between scores 1e-5 .. 5e-5 apart are counted
+    # (tools/tie_report.py: 8 per 1000 frames over all widths) -- a systematic mis-ordering would show in every frame
+    wide = [(c.tag,) + w for c in checks for w in c.wide_swaps]
+    assert len(wide) <= max(2, compared // 8), 'rank swaps between scores 1e-5 .. 5e-5 apart: %s' % (wide,)

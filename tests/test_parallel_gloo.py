@@ -265,7 +265,12 @@ def _worker_one_rank_group(port, q):
     g = parallel.DetectionGatherer(3, 1, 0, 5, 11, 'cpu')
     out = g(rows).clone()
     h = parallel.check_same_plan('conv:201:1;dcn_knobs=(128, 4, 4, 1, 0, 0)')
-    q.put((r, w, parallel.group_active(), g.collective, bool(torch.equal(out, rows)), g.verify(rows), len(h)))
+    try:        # a gatherer sized for another world than the group's is refused with a clear error, not a shape error
+        parallel.DetectionGatherer(4, 2, 0, 5, 11, 'cpu')
+        refused = False
+    except ValueError as e:
+        refused = 'process group of 1 ranks' in str(e)
+    q.put((r, w, parallel.group_active(), g.collective, bool(torch.equal(out, rows)), g.verify(rows), len(h), refused))
     torch.distributed.destroy_process_group()
 
 
@@ -283,4 +288,17 @@ def test_group_of_one_rank_exchanges_through_the_collective():
     got = q.get(timeout=180)
     p.join(timeout=60)
     assert p.exitcode == 0
-    assert got == (0, 1, True, True, True, 1, 16)
+    assert got == (0, 1, True, True, True, 1, 16, True)
+
+
+def test_rank_variable_without_a_rendezvous_is_a_plain_single_process(monkeypatch):
+    """RANK exported by something that is not a launcher (WORLD_SIZE 1 or absent, no MASTER_ADDR / MASTER_PORT): no
+    process group is created -- init_process_group would fail on the missing rendezvous (advisor, round 4)"""
+    from centertrack_amd import parallel
+    for k in ('MASTER_ADDR', 'MASTER_PORT', 'WORLD_SIZE', 'LOCAL_RANK'):
+        monkeypatch.delenv(k, raising=False)
+    monkeypatch.setenv('RANK', '0')
+    assert parallel.init_from_env(backend='gloo') == (0, 1, 0)
+    monkeypatch.setenv('WORLD_SIZE', '1')
+    assert parallel.init_from_env(backend='gloo') == (0, 1, 0)
+    assert not parallel.group_active()

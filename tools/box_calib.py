@@ -121,7 +121,16 @@ def launches(lib, device):
 
 
 def _card_dir():
-    """sysfs directory of the first amdgpu device that exposes clock tables"""
+    """sysfs directory of THE device HIP runs on (by PCI address; a box holds eight cards and the lease is one of them:
+    card0 is usually somebody else's, idle at 95 MHz); falls back to the first amdgpu device with clock tables"""
+    try:
+        import torch
+        pr = torch.cuda.get_device_properties(torch.cuda.current_device())
+        d = '/sys/bus/pci/devices/%04x:%02x:%02x.0' % (pr.pci_domain_id, pr.pci_bus_id, pr.pci_device_id)
+        if os.path.exists(os.path.join(d, 'pp_dpm_sclk')):
+            return d
+    except Exception:
+        pass
     for d in sorted(glob.glob('/sys/class/drm/card*/device')):
         if os.path.exists(os.path.join(d, 'pp_dpm_sclk')):
             return d
