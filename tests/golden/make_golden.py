@@ -160,6 +160,107 @@ def gen_e2e():
           [[d['tracking_id'] for d in f] for f in out['frames']])
 
 
+def _ref_detector(opt, sd):
+    """the reference's Detector (detector.py) on CPU with ``sd`` instead of a checkpoint file"""
+    import detector as ref_detector
+    from model.model import create_model
+    ref_detector.create_model = lambda arch, h, hc, opt=None: create_model(arch, h, hc, opt=opt)
+
+    def fake_load(model, path, o):
+        model.load_state_dict(sd)
+        return model
+    ref_detector.load_model = fake_load
+    return ref_detector.Detector(opt)
+
+
+def _prefetch_dict(images, meta):
+    """the PrefetchDataset dict of test.py:31-48 collated with a leading batch dim of 1; pre_dets / cur_dets attached
+    the way test.py:88-107 attaches them (plain lists, after the DataLoader)"""
+    arrays = {k: v for k, v in meta.items() if k not in ('pre_dets', 'cur_dets')}
+    pre = {'image': torch.zeros(1, 4, 4, 3), 'images': {1.0: images.unsqueeze(0)},
+           'meta': {1.0: {k: torch.from_numpy(np.asarray(v)[None]) for k, v in arrays.items()}}}
+    for k in ('pre_dets', 'cur_dets'):
+        if k in meta:
+            pre['meta'][k] = meta[k]
+    return pre
+
+
+def _calibrate_hm(case, opt, top=0.8, n_above=40):
+    """per-class scale / bias of the hm output layer from the reference model's own logits on frame 0 (the pooled
+    recipe of make_hm_calibration.py): every class standardised over the map, the pooled NMS peaks mapped so that the
+    5th best scores ``top`` and the ``n_above``-th the threshold -- ~40 detections of mixed classes, scores apart"""
+    import math
+    import torch.nn.functional as F
+    from model.model import create_model
+    from scenarios import e2e_mode_frames
+    sd = W.make_synthetic_state_dict(case['heads'], seed=case['seed'], hm_gain=1.0)
+    model = create_model(opt.arch, opt.heads, opt.head_conv, opt=opt).eval()
+    model.load_state_dict(sd)
+    x = next(iter(e2e_mode_frames(case)))[0][:1]
+    with torch.no_grad():
+        raw = model(x, x, torch.zeros((1, 1, case['H'], case['W'])))[-1]['hm'][0].double()
+    logit = lambda p: math.log(p / (1 - p))
+    thr = case['opt']['track_thresh']
+    mu, sg = raw.mean(dim=(1, 2)), raw.std(dim=(1, 2))
+    z = (raw - mu.view(-1, 1, 1)) / sg.view(-1, 1, 1)
+    pooled = torch.sort(z[F.max_pool2d(z[None], 3, 1, 1)[0] == z], descending=True)[0]
+    lift = 1.0 if case['opt'].get('flip_test') else 0.0      # (the flip merge averages two maps: peaks flatten)
+    G = (logit(top) - logit(thr)) / float(pooled[4] - pooled[n_above - 1])
+    P = logit(top) + lift - G * float(pooled[4])
+    scale = [float(G / sg[c]) for c in range(raw.shape[0])]
+    bias = [float(P - scale[c] * (mu[c] + 4.6)) for c in range(raw.shape[0])]          # raw = w.h - 4.6 (prior bias)
+    return {'scale': scale, 'bias': bias}
+
+
+def gen_e2e_modes():
+    """reference Detector.run in the modes scenarios.e2e_mode_cases() lists (T up to 16; Hungarian, max_age, public
+    detections, flip_test, tracking,ddd with calib, 80 classes)"""
+    from scenarios import e2e_mode_cases, e2e_mode_frames, e2e_mode_state_dict
+    out, cal = {}, {}
+    for case in e2e_mode_cases():
+        opt = ref_opt(case['ref_args'] + ['--input_h', str(case['H']), '--input_w', str(case['W'])],
+                      case['heads']['hm'], case['task'])
+        assert dict(opt.heads) == dict(case['heads']), (opt.heads, case['heads'])
+        if case['calibrated']:
+            cal[case['name']] = _calibrate_hm(case, opt)
+        det = _ref_detector(opt, e2e_mode_state_dict(case, cal.get(case['name'])))
+        frames = []
+        for t, (images, meta) in enumerate(e2e_mode_frames(case)):
+            ret = det.run(_prefetch_dict(images, meta))
+            frames.append([{k: np.asarray(v, np.float64).tolist() for k, v in r.items()} for r in ret['results']])
+        out[case['name']] = frames
+        ids = sorted({int(d['tracking_id']) for f in frames for d in f})
+        print('%-14s dets/frame %s  ids %d  classes %s  carried %d' % (
+            case['name'], [len(f) for f in frames], len(ids), sorted({int(d['class']) for f in frames for d in f}),
+            sum(int(d['active']) == 0 for f in frames for d in f)))
+    with open(os.path.join(HERE, 'e2e_modes_calibration.json'), 'w') as f:
+        json.dump(cal, f)
+    with open(os.path.join(HERE, 'e2e_modes.json'), 'w') as f:
+        json.dump(out, f)
+    print('e2e_modes.json', os.path.getsize(os.path.join(HERE, 'e2e_modes.json')))
+
+
+def gen_model_full():
+    """reference DLASeg forward at the BENCHMARKED sizes: 512 x 512 (BASELINE configs[1]) and 544 x 960 (the reference's
+    own MOT input, datasets/mot.py:15: ragged 17 x 30 / 34 x 60 deep maps).  Stored: the full ``hm`` map and every
+    regression head at stride 2 (a wrong halo / ragged-tile rule anywhere in the 50 layers shows in every pixel)"""
+    from model.model import create_model
+    out = {}
+    heads = W.MOT_HEADS
+    for name, h, w in (('mot_512', 512, 512), ('mot_544x960', 544, 960)):
+        opt = ref_opt(['--pre_hm', '--ltrb_amodal', '--input_h', str(h), '--input_w', str(w)], heads['hm'])
+        model = create_model(opt.arch, opt.heads, opt.head_conv, opt=opt).eval()
+        model.load_state_dict(W.make_synthetic_state_dict(heads, seed=317))
+        x, pre, hm = W.synthetic_inputs(1, h, w, seed=317)
+        with torch.no_grad():
+            y = model(x, pre, hm)[-1]
+        for k, v in y.items():
+            out['%s.%s' % (name, k)] = v.numpy() if k == 'hm' else v[:, :, ::2, ::2].contiguous().numpy()
+    np.savez_compressed(os.path.join(HERE, 'model_forward_full.npz'), **out)
+    print('model_forward_full.npz', os.path.getsize(os.path.join(HERE, 'model_forward_full.npz')),
+          {k: v.shape for k, v in out.items()})
+
+
 def gen_pre_hm():
     """reference Detector._get_additional_inputs + meta transforms"""
     import detector as ref_detector
@@ -226,7 +327,7 @@ def gen_writers():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers', 'poseflip']
+    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers', 'poseflip', 'e2emodes', 'modelfull']
     if 'model' in which:
         gen_model()
     if 'decode' in which:
@@ -243,3 +344,7 @@ if __name__ == '__main__':
         gen_writers()
     if 'poseflip' in which:
         gen_pose_flip()
+    if 'e2emodes' in which:
+        gen_e2e_modes()
+    if 'modelfull' in which:
+        gen_model_full()

@@ -62,6 +62,42 @@ def test_detector_stream_matches_reference(device, golden_dir, use_graph, native
     assert det.tracker.id_count == 0 and len(det.tracker.tracks) == 0
 
 
+def _mode_cases():
+    import scenarios as S
+    return S.e2e_mode_cases()
+
+
+@pytest.mark.parametrize('case', _mode_cases(), ids=lambda c: c['name'])
+def test_detector_modes_match_reference_golden(device, golden_dir, case):
+    """the HIP detector against REFERENCE-made results directly (tests/golden/e2e_modes.json = the reference's own
+    Detector.run, tests/golden/make_golden.py::gen_e2e_modes), in every mode a BASELINE configuration or the MOT
+    protocol uses: T = 16 frames, --hungarian, --max_age 2, --public_det with pre_dets / cur_dets, --flip_test,
+    tracking,ddd with calib (dep / dim / alpha / loc / rot_y), 80 classes.  Track ids, classes, ages, active flags and
+    the ORDER of the results identical; values within 1e-3 on the output grid (12 image px per cell here)."""
+    import scenarios as S
+    from centertrack_amd.detector import Detector, default_opt
+    from centertrack_amd.model import DLASegHIP
+    g = json.load(open(os.path.join(golden_dir, 'e2e_modes.json')))[case['name']]
+    cal = json.load(open(os.path.join(golden_dir, 'e2e_modes_calibration.json'))).get(case['name'])
+    sd = S.e2e_mode_state_dict(case, cal)
+    opt = default_opt(case['heads'], input_h=case['H'], input_w=case['W'], **case['opt'])
+    model = DLASegHIP(case['heads'])
+    model.load_state_dict(sd)
+    det = Detector(opt, model=model)
+    assert det.impl.native
+    for t, (images, meta) in enumerate(S.e2e_mode_frames(case)):
+        res = det.run(images, dict(meta))['results']
+        ref = g[t]
+        _check_frame(res, ref, t, case['name'])
+        for a, b in zip(res, ref):
+            for k in ('dep', 'dim', 'alpha', 'loc', 'rot_y'):
+                assert (k in a) == (k in b), '%s frame %d: field %s' % (case['name'], t, k)
+                if k in b:
+                    np.testing.assert_allclose(np.asarray(a[k], np.float64).reshape(-1), np.asarray(b[k], np.float64).reshape(-1),
+                                               rtol=2e-3, atol=2e-3, err_msg='%s frame %d %s' % (case['name'], t, k))
+    assert len(g) == case['T'] and sum(len(f) for f in g) > 10 * case['T']
+
+
 def test_batched_streams_equal_single_streams(device):
     """3 streams advanced together give, per stream, what a lone detector gives (IDs exact)."""
     import scenarios as S

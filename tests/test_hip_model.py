@@ -55,6 +55,28 @@ def test_forward_matches_oracle(device, golden_dir, name, shape, off_std):
         np.testing.assert_allclose(got2['hm'].cpu().numpy(), g[name + '_nohm.hm'], atol=1e-3, rtol=1e-3)
 
 
+@pytest.mark.parametrize('name,h,w', [('mot_512', 512, 512), ('mot_544x960', 544, 960)])
+def test_forward_full_size_matches_reference_golden(device, golden_dir, name, h, w):
+    """the HIP forward against the REFERENCE's DLASeg at the benchmarked sizes (tests/golden/model_forward_full.npz: the
+    full hm map, the regression heads at stride 2): 512 x 512 = BASELINE configs[1], 544 x 960 = the reference's own MOT
+    input with its ragged 17 x 30 / 34 x 60 deep maps; 1e-3 like north_star asks"""
+    from centertrack_amd import weights as W
+    from centertrack_amd.model import DLASegHIP
+    g = np.load(os.path.join(golden_dir, 'model_forward_full.npz'))
+    heads = W.MOT_HEADS
+    model = DLASegHIP(heads)
+    model.load_state_dict(W.make_synthetic_state_dict(heads, seed=317))
+    model = model.to(device)
+    x, pre, hm = W.synthetic_inputs(1, h, w, seed=317)
+    got = model(x.to(device), pre.to(device), hm.to(device))[-1]
+    torch.cuda.synchronize()
+    for k in heads:
+        v = got[k].cpu().numpy()
+        v = v if k == 'hm' else v[:, :, ::2, ::2]
+        print(_report('%s %s' % (name, k), torch.from_numpy(np.ascontiguousarray(v)), torch.from_numpy(g['%s.%s' % (name, k)])))
+        np.testing.assert_allclose(v, g['%s.%s' % (name, k)], atol=1e-3, rtol=1e-3, err_msg=k)
+
+
 def test_backbone_levels_match_oracle(device):
     """level-by-level check of the DLA backbone outputs (localises a bad layer)."""
     from centertrack_amd import weights as W

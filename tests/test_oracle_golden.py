@@ -119,6 +119,46 @@ def test_e2e_detector_matches_reference(golden_dir):
             assert int(a['age']) == int(b['age']) and int(a['active']) == int(b['active'])
 
 
+@pytest.mark.parametrize('case', S.e2e_mode_cases(), ids=lambda c: c['name'])
+def test_e2e_modes_match_reference(golden_dir, case):
+    """reference Detector.run (tests/golden/e2e_modes.json) in every mode a BASELINE configuration or the MOT protocol
+    uses -- T = 16, Hungarian, max_age 2, public detections with pre_dets / cur_dets, --flip_test, tracking,ddd with calib,
+    80 classes -- against the oracle detector: ids / classes / ages identical, values to 1e-4"""
+    g = json.load(open(os.path.join(golden_dir, 'e2e_modes.json')))[case['name']]
+    cal = json.load(open(os.path.join(golden_dir, 'e2e_modes_calibration.json'))).get(case['name'])
+    sd = S.e2e_mode_state_dict(case, cal)
+    opt = odet.default_opt(input_h=case['H'], input_w=case['W'], num_classes=case['heads']['hm'], **case['opt'])
+    det = odet.Detector(opt, sd, case['heads'])
+    assert len(g) == case['T']
+    for t, (images, meta) in enumerate(S.e2e_mode_frames(case)):
+        res = det.run(images, meta)
+        ref = g[t]
+        assert [int(r['tracking_id']) for r in res] == [int(r['tracking_id']) for r in ref], t
+        assert [int(r['class']) for r in res] == [int(r['class']) for r in ref]
+        for a, b in zip(res, ref):
+            assert int(a['age']) == int(b['age']) and int(a['active']) == int(b['active'])
+            for k in ('score', 'ct', 'bbox', 'tracking', 'dep', 'dim', 'alpha', 'loc', 'rot_y'):
+                assert (k in a) == (k in b), k
+                if k in b:
+                    np.testing.assert_allclose(np.asarray(a[k], np.float64).reshape(-1), np.asarray(b[k], np.float64).reshape(-1),
+                                               rtol=1e-4, atol=2e-4, err_msg='%s frame %d %s' % (case['name'], t, k))
+
+
+@pytest.mark.parametrize('name,h,w', [('mot_512', 512, 512), ('mot_544x960', 544, 960)])
+def test_model_forward_full_size_matches_reference(golden_dir, name, h, w):
+    """the oracle forward pinned to the reference's DLASeg at the sizes that are BENCHMARKED (model_forward.npz holds
+    64 x 96 / 64 x 64 only): 512 x 512 and the reference's own 544 x 960 with its ragged 17 x 30 deep maps"""
+    g = _load(golden_dir, 'model_forward_full.npz')
+    heads = W.MOT_HEADS
+    sd = W.make_synthetic_state_dict(heads, seed=317)
+    x, pre, hm = W.synthetic_inputs(1, h, w, seed=317)
+    with torch.no_grad():
+        y = dla34.forward(x, pre, hm, sd, heads)[-1]
+    for k in heads:
+        got = y[k].numpy() if k == 'hm' else y[k][:, :, ::2, ::2].numpy()
+        np.testing.assert_allclose(got, g['%s.%s' % (name, k)], rtol=1e-5, atol=2e-5, err_msg=k)
+
+
 def test_pose_flip_matches_reference(golden_dir):
     """oracle mirror_joints == the reference's flip_lr (hm_hp) / flip_lr_off (hps), model/utils.py:33-50"""
     from oracle import detector as odet
