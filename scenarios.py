@@ -270,7 +270,9 @@ def e2e_mode_cases():
              opt=dict(track_thresh=0.4, pre_thresh=0.5)),
         dict(name='mot_hungarian', heads=W.MOT_HEADS, T=8, task='tracking', ref_args=mot + ['--hungarian'],
              opt=dict(track_thresh=0.4, pre_thresh=0.5, hungarian=True)),
-        dict(name='mot_max_age2', heads=W.MOT_HEADS, T=10, task='tracking', ref_args=mot + ['--max_age', '2'],
+        # (own gain: at 14 two detections of frame 1 score EXACTLY the same saturated fp32 value, and the order torch.topk gives
+        # exact ties is unspecified -- SURVEY.md App. D.1; the generator refuses such data)
+        dict(name='mot_max_age2', heads=W.MOT_HEADS, T=10, task='tracking', ref_args=mot + ['--max_age', '2'], seed=317, hm_gain=10.0,
              opt=dict(track_thresh=0.4, pre_thresh=0.5, max_age=2)),
         # MOT public-detection protocol (test.py:88-107, tracker.py:83-101): births only next to a provided detection
         dict(name='mot_public', heads=W.MOT_HEADS, T=8, task='tracking', ref_args=mot + ['--public_det', '--load_results', 'x'],

@@ -228,6 +228,9 @@ def gen_e2e_modes():
         for t, (images, meta) in enumerate(e2e_mode_frames(case)):
             ret = det.run(_prefetch_dict(images, meta))
             frames.append([{k: np.asarray(v, np.float64).tolist() for k, v in r.items()} for r in ret['results']])
+            sc = [float(r['score']) for r in ret['results'] if int(r['age']) == 1]
+            assert len(set(sc)) == len(sc), ('TEST DATA: %s frame %d holds two detections with exactly the same score (the '
+                                             'order of exact ties in torch.topk is unspecified): change the seed' % (case['name'], t))
         out[case['name']] = frames
         ids = sorted({int(d['tracking_id']) for f in frames for d in f})
         print('%-14s dets/frame %s  ids %d  classes %s  carried %d' % (
