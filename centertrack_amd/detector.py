@@ -603,6 +603,10 @@ class StreamDetector(object):
         t0 = time.time()
         B = self.B
         raw_frames = isinstance(images, (list, tuple))
+        if not raw_frames and self.flip and images.shape[0] == 2 * B:
+            # what the reference's pre_process hands over under --flip_test (detector.py:225-226: the frame and its
+            # mirrored copy): the mirrored half is rebuilt on the device by the frame's first launch
+            images = images[:B]
         assert len(images) == B and len(metas) == B
         if raw_frames:
             H, W = int(metas[0]['inp_height']), int(metas[0]['inp_width'])
@@ -631,8 +635,6 @@ class StreamDetector(object):
             for s in range(B):
                 self._warp_frame(s, images[s], metas[s], fr, H, W)
         else:
-            if images.shape[0] == 2 * B and self.flip:
-                images = images[:B]                            # (a pre-flipped batch: the copy is rebuilt on device)
             if tuple(images.shape) != (B, 3, H, W):
                 raise _lib.CTError('step() expects [%d,3,%d,%d] frames, got %s' % (B, H, W, tuple(images.shape)))
             # the SAME tensor object, unmodified since it was handed over (an in-place edit bumps ``_version``; a new
