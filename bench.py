@@ -81,6 +81,9 @@ def parse():
     ap.add_argument('--no-extra-configs', action='store_true',
                     help='skip the BASELINE configs 3-5 / 544x960 measurements the default invocation appends as "configs"')
     ap.add_argument('--extra-steps', type=int, default=6, help='timed steps of each appended configuration')
+    ap.add_argument('--sparse-heads', action='store_true',
+                    help='opt.sparse_heads: regression heads evaluated at the K decode winners only (opt-in product mode, '
+                         'never the headline: the reference computes dense maps)')
     ap.add_argument('--no-box-probes', action='store_true', help='box_calibration without the latency / clock probes')
     return ap.parse_args()
 
@@ -279,8 +282,28 @@ def main():
     env = (rank, world, device)
     out = measure(args, env, headline=True)
     default_workload = (args.config == 'mot17_512' and args.streams <= 1 and not args.height and not args.width
-                        and not args.no_graph)
+                        and not args.no_graph and not args.sparse_heads)
+
+    def sparse_line(name, streams):
+        """the same workload with opt.sparse_heads (opt-in product mode; reported beside the dense figure, never as `value`)"""
+        a = argparse.Namespace(**vars(args))
+        a.config, a.streams, a.frames_per_step, a.sparse_heads = name, streams, 0, True
+        a.steps, a.warmup = args.extra_steps, 2
+        a.no_resident = a.no_cpu_baseline = a.no_roofline = True
+        a.raw_u8 = False
+        try:
+            o = measure(a, env, headline=False)
+            return {'fps': o['value'], 'device_ms_per_frame_batch': o['device_ms_per_frame_batch'],
+                    'launches_per_frame': o['launches_per_frame'], 'active': bool(o['config'].get('sparse_heads')),
+                    'mean_detections_per_frame': o['config']['mean_detections_per_frame']}
+        except Exception as e:
+            return {'error': repr(e)}
+
     if rank == 0 and world == 1 and default_workload and not args.no_extra_configs:
+        out['sparse_heads'] = dict(sparse_line('mot17_512', 1), note=(
+            'opt.sparse_heads (opt-in, not the reference\'s computation graph: its regression heads are dense maps that '
+            'generic_decode reads at K pixels): the same workload with those heads evaluated at the K winners only; rows '
+            'equal the dense path\'s (tests/test_hip_sparse_heads.py); never `value`'))
         out['configs'] = []
         for name, streams in EXTRA_CONFIGS:
             a = argparse.Namespace(**vars(args))
@@ -304,6 +327,11 @@ def main():
                                       'algorithmic_tflops': o['roofline_conv']['algorithmic_tflops']},
                     'mean_detections_per_frame': o['config']['mean_detections_per_frame'],
                     'plan_hash': o['plan_hash'], 'wall_s': round(time.perf_counter() - t0, 1)})
+                import scenarios as S_
+                if not S_.CONFIGS[name]['flip']:
+                    sp = sparse_line(name, streams)
+                    if sp.get('active') or 'error' in sp:
+                        out['configs'][-1]['sparse_heads'] = sp
             except Exception as e:       # the extra configurations never cost the headline line
                 out['configs'].append({'workload': name, 'streams_per_gpu': streams, 'error': repr(e)})
     if rank == 0:
@@ -336,7 +364,7 @@ def measure(args, env, headline=True):
     if 'ltrb_amodal' in heads:
         sd['ltrb_amodal.2.bias'] = torch.tensor([-3.0, -3.0, 3.0, 3.0])
     opt_kw = dict(track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'])
-    opt = default_opt(heads, **opt_kw)
+    opt = default_opt(heads, sparse_heads=bool(getattr(args, 'sparse_heads', False)), **opt_kw)
     model = DLASegHIP(heads)
     model.load_state_dict(sd)
     det = StreamDetector(opt, model=model, num_streams=B, use_graph=not args.no_graph)
@@ -420,6 +448,9 @@ def measure(args, env, headline=True):
         'process_group': (torch.distributed.get_backend() if parallel.group_active() else None),
         'plan_hash': plan_hash,
     }
+    if det.sparse:
+        out['config']['sparse_heads'] = True
+        out['config']['workload'] += '; SPARSE HEADS (regression heads evaluated at the K decode winners only -- opt-in mode)'
     if gathered is not None:
         out['gathered'] = gathered
     clocks = None

@@ -74,6 +74,14 @@ class HeadsDesc(ctypes.Structure):
                 ('depth_scale', ctypes.c_float)]
 
 
+class SparseHeadsDesc(ctypes.Structure):
+    _fields_ = [('feat', ctypes.c_void_p), ('ldf', ctypes.c_int), ('nheads', ctypes.c_int),
+                ('head', ctypes.c_int * NUM_HEADS),
+                ('w1', ctypes.c_void_p * NUM_HEADS), ('b1', ctypes.c_void_p * NUM_HEADS),
+                ('w2', ctypes.c_void_p * NUM_HEADS), ('b2', ctypes.c_void_p * NUM_HEADS),
+                ('depth_scale', ctypes.c_float), ('zero_tracking', ctypes.c_int)]
+
+
 class DecodeDesc(ctypes.Structure):
     _fields_ = [('hm', ctypes.c_void_p), ('B', ctypes.c_int), ('C', ctypes.c_int), ('h', ctypes.c_int),
                 ('w', ctypes.c_int), ('K', ctypes.c_int),
@@ -82,7 +90,8 @@ class DecodeDesc(ctypes.Structure):
                 ('workspace', ctypes.c_void_p), ('workspace_bytes', ctypes.c_size_t),
                 ('hm_batch_stride', ctypes.c_size_t), ('head_batch_stride', ctypes.c_size_t * NUM_HEADS),
                 ('out_stride', ctypes.c_int),
-                ('host_out', ctypes.c_void_p), ('done_flag', ctypes.c_void_p), ('done_counter', ctypes.c_void_p)]
+                ('host_out', ctypes.c_void_p), ('done_flag', ctypes.c_void_p), ('done_counter', ctypes.c_void_p),
+                ('sparse', ctypes.POINTER(SparseHeadsDesc))]
 
 
 class PoseDesc(ctypes.Structure):
@@ -150,7 +159,7 @@ class FrameStepArgs(ctypes.Structure):
 CT_FRAME_DEVICE, CT_FRAME_HOST, CT_FRAME_IN_PLACE, CT_FRAME_UPLOADED = range(4)
 
 
-ABI_VERSION = 101       # CT_ABI_VERSION of include/centertrack_hip.h
+ABI_VERSION = 102       # CT_ABI_VERSION of include/centertrack_hip.h
 
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',

@@ -210,7 +210,80 @@ struct Stage2Args {
     float *host_out;                 // optional pinned host copy of the rows, flag raised when all images are done
     int *done_flag;
     unsigned *done_counter;
+    // sparse heads (round 5): stage 2 stops after the selection and hands the K sorted winner keys of every image to
+    // sparse_heads_kernel, which evaluates the regression heads at those pixels and assembles the rows itself
+    unsigned long long *winners;     // [B][K], nullptr = dense head maps (rows assembled here)
+    unsigned present;                // bit hd: head hd is part of the row (a dense map OR a sparse head)
 };
+
+// One packed row (ct_decode_desc: score, cls, xs0, ys0, box, amodal box, the remaining heads) from the winner's score /
+// class / pixel and its head values hv(head, channel) -- decode.py:99-159; shared by the dense gather of stage 2 and
+// the sparse heads' epilogue
+template <typename HV>
+__device__ __forceinline__ void emit_row(float *row, float *hrow, unsigned present, float score, int cls, float xs0,
+                                         float ys0, HV hv)
+{
+    constexpr int HCH[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
+    auto has = [&](int hd) { return (present >> hd) & 1u; };
+    int f = 0;
+    // (round 4: assembling the rows in LDS and storing them coalesced was measured and dropped -- the host copy's cost
+    //  is the PCIe write round trip the system fence below waits for, ~3.3 us however the stores are shaped, and the
+    //  lane-per-row stores start it a microsecond earlier: 6.6 against 9.0 us from the gathers to the raised flag; a
+    //  wave-local transpose without the workgroup barrier: 5.7 against 5.0 us for the stores, 18.1-19.5 against 17.1-17.8
+    //  us for the kernel inside the frame)
+    auto put = [&](float v) { row[f] = v; if (hrow) hrow[f] = v; ++f; };
+    put(score); put((float)cls); put(xs0); put(ys0);
+    float xs = xs0 + 0.5f, ys = ys0 + 0.5f;                       // decode.py:102-110
+    if (has(CT_HEAD_REG)) { xs = xs0 + hv(CT_HEAD_REG, 0); ys = ys0 + hv(CT_HEAD_REG, 1); }
+    const bool has_box = has(CT_HEAD_WH) || has(CT_HEAD_LTRB) || has(CT_HEAD_LTRB_AMODAL);
+    float bb[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has(CT_HEAD_WH)) {                                        // decode.py:112-128
+        float ww = hv(CT_HEAD_WH, 0), hh = hv(CT_HEAD_WH, 1);
+        if (ww < 0.f) ww = 0.f;
+        if (hh < 0.f) hh = 0.f;
+        bb[0] = xs - ww / 2; bb[1] = ys - hh / 2; bb[2] = xs + ww / 2; bb[3] = ys + hh / 2;
+    }
+    if (has(CT_HEAD_LTRB)) {                                      // decode.py:131-139
+        bb[0] = xs0 + hv(CT_HEAD_LTRB, 0); bb[1] = ys0 + hv(CT_HEAD_LTRB, 1);
+        bb[2] = xs0 + hv(CT_HEAD_LTRB, 2); bb[3] = ys0 + hv(CT_HEAD_LTRB, 3);
+    }
+    float am[4] = {0.f, 0.f, 0.f, 0.f};
+    if (has(CT_HEAD_LTRB_AMODAL)) {                               // decode.py:150-159
+        am[0] = xs0 + hv(CT_HEAD_LTRB_AMODAL, 0); am[1] = ys0 + hv(CT_HEAD_LTRB_AMODAL, 1);
+        am[2] = xs0 + hv(CT_HEAD_LTRB_AMODAL, 2); am[3] = ys0 + hv(CT_HEAD_LTRB_AMODAL, 3);
+        for (int i = 0; i < 4; ++i) bb[i] = am[i];
+    }
+    if (has_box) for (int i = 0; i < 4; ++i) put(bb[i]);
+    if (has(CT_HEAD_LTRB_AMODAL)) for (int i = 0; i < 4; ++i) put(am[i]);
+    const int rest[7] = {CT_HEAD_TRACKING, CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET,
+                         CT_HEAD_NUSCENES_ATT, CT_HEAD_VELOCITY};
+#pragma unroll
+    for (int q = 0; q < 7; ++q) {
+        const int hd = rest[q];
+        if (!has(hd)) continue;
+#pragma unroll
+        for (int ch = 0; ch < HCH[hd]; ++ch) put(hv(hd, ch));
+    }
+}
+
+// every row of a workgroup is out (device + host copy): the last of `nwg` workgroups raises the host flag
+__device__ __forceinline__ void raise_done_flag(int *done_flag, unsigned *done_counter, int nwg)
+{
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0 && nwg == 1) {
+        // one workgroup: its rows are all there is (fenced above) -- no arrival counter to go through
+        __hip_atomic_store(done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    } else if (threadIdx.x == 0) {
+        // acq_rel at system scope: the last arriver ACQUIRES the other workgroups' host_out stores (released by their
+        // own increments) before it releases the flag to the host, which skips the runtime wait once it sees it
+        const unsigned prev = __hip_atomic_fetch_add(done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (prev == (unsigned)nwg - 1u) {
+            *done_counter = 0u;
+            __hip_atomic_store(done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
 
 // NMS'd score key of flat index f = cls*HW + p, straight from HBM (slow path only)
 __device__ __forceinline__ unsigned long long key_from_map(const float *hm_b, int C, int h, int w, unsigned f)
@@ -642,6 +715,19 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
     __syncthreads();
     CT_STAMP(4);
     if (need_sort) bitonic_desc(win, KP, tid, NT);          // (block-uniform)
+    if (a.winners) {
+        // sparse heads: the sorted winners go to sparse_heads_kernel (rows, host copy and flag are its job)
+        for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
+            const unsigned long long k = win[r];
+            a.winners[(size_t)b * a.K + r] = k;
+            if (a.inds) a.inds[(size_t)b * a.K + r] = (int)((0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull)) % (unsigned)HW);
+        }
+        CT_STAMP(5);
+        CT_STAMP(6);
+        CT_STAMP(7);
+        CT_STAMP_RT(8);
+        return;
+    }
     for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
         const unsigned long long k = win[r];
         const float score = ord2f((unsigned)(k >> 32));
@@ -664,68 +750,183 @@ __global__ __launch_bounds__(1024) void decode_stage2_kernel(Stage2Args a)
 #pragma unroll
             for (int ch = 0; ch < HCH[hd]; ++ch) hval[hd][ch] = base[on ? (size_t)ch * HW : 0];
         }
-        auto hv = [&](int hd, int ch) { return hval[hd][ch]; };
-        int f = 0;
-        // (round 4: assembling the rows in LDS and storing them coalesced was measured and dropped -- the host copy's cost
-        //  is the PCIe write round trip the system fence below waits for, ~3.3 us however the stores are shaped, and the
-        //  lane-per-row stores start it a microsecond earlier: 6.6 against 9.0 us from the gathers to the raised flag; a
-        //  wave-local transpose without the workgroup barrier: 5.7 against 5.0 us for the stores, 18.1-19.5 against 17.1-17.8
-        //  us for the kernel inside the frame)
-        auto put = [&](float v) { row[f] = v; if (hrow) hrow[f] = v; ++f; };
-        put(score); put((float)cls); put(xs0); put(ys0);
-        float xs = xs0 + 0.5f, ys = ys0 + 0.5f;                       // decode.py:102-110
-        if (a.heads[CT_HEAD_REG]) { xs = xs0 + hv(CT_HEAD_REG, 0); ys = ys0 + hv(CT_HEAD_REG, 1); }
-        const bool has_box = a.heads[CT_HEAD_WH] || a.heads[CT_HEAD_LTRB] || a.heads[CT_HEAD_LTRB_AMODAL];
-        float bb[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.heads[CT_HEAD_WH]) {                                    // decode.py:112-128
-            float ww = hv(CT_HEAD_WH, 0), hh = hv(CT_HEAD_WH, 1);
-            if (ww < 0.f) ww = 0.f;
-            if (hh < 0.f) hh = 0.f;
-            bb[0] = xs - ww / 2; bb[1] = ys - hh / 2; bb[2] = xs + ww / 2; bb[3] = ys + hh / 2;
-        }
-        if (a.heads[CT_HEAD_LTRB]) {                                  // decode.py:131-139
-            bb[0] = xs0 + hv(CT_HEAD_LTRB, 0); bb[1] = ys0 + hv(CT_HEAD_LTRB, 1);
-            bb[2] = xs0 + hv(CT_HEAD_LTRB, 2); bb[3] = ys0 + hv(CT_HEAD_LTRB, 3);
-        }
-        float am[4] = {0.f, 0.f, 0.f, 0.f};
-        if (a.heads[CT_HEAD_LTRB_AMODAL]) {                           // decode.py:150-159
-            am[0] = xs0 + hv(CT_HEAD_LTRB_AMODAL, 0); am[1] = ys0 + hv(CT_HEAD_LTRB_AMODAL, 1);
-            am[2] = xs0 + hv(CT_HEAD_LTRB_AMODAL, 2); am[3] = ys0 + hv(CT_HEAD_LTRB_AMODAL, 3);
-            for (int i = 0; i < 4; ++i) bb[i] = am[i];
-        }
-        if (has_box) for (int i = 0; i < 4; ++i) put(bb[i]);
-        if (a.heads[CT_HEAD_LTRB_AMODAL]) for (int i = 0; i < 4; ++i) put(am[i]);
-        const int rest[7] = {CT_HEAD_TRACKING, CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET,
-                             CT_HEAD_NUSCENES_ATT, CT_HEAD_VELOCITY};
-#pragma unroll
-        for (int q = 0; q < 7; ++q) {
-            const int hd = rest[q];
-            if (!a.heads[hd]) continue;
-#pragma unroll
-            for (int ch = 0; ch < HCH[hd]; ++ch) put(hval[hd][ch]);
-        }
+        emit_row(row, hrow, a.present, score, cls, xs0, ys0, [&](int hd, int ch) { return hval[hd][ch]; });
     }
     CT_STAMP(5);
     if (a.done_flag) {
-        // every row of this image is out (device + host copy): the last image raises the host flag
-        __threadfence_system();
-        __syncthreads();
+        raise_done_flag(a.done_flag, a.done_counter, a.B);
         CT_STAMP(6);
-        if (threadIdx.x == 0 && a.B == 1) {
-            // one image: this workgroup's rows are all there is (fenced above) -- no arrival counter to go through
-            __hip_atomic_store(a.done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-        } else if (threadIdx.x == 0) {
-            // acq_rel at system scope: the last arriver ACQUIRES the other workgroups' host_out stores (released by their
-            // own increments) before it releases the flag to the host, which skips the runtime wait once it sees it
-            const unsigned prev = __hip_atomic_fetch_add(a.done_counter, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (prev == (unsigned)a.B - 1u) {
-                *a.done_counter = 0u;
-                __hip_atomic_store(a.done_flag, 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-        }
     }
     CT_STAMP(7);
     CT_STAMP_RT(8);
+}
+
+// ---- sparse heads (round 5, opt-in) --------------------------------------------------------------------------
+// generic_decode reads the regression heads (reg, wh, tracking, ltrb*, dep, rot, dim, amodel_offset, ...) at the K winner
+// pixels ONLY (decode.py:99-180: every one of them goes through _tranpose_and_gather_feat(head, inds)); the reference
+// still computes their dense maps because a framework conv has no other form.  With ct_decode_desc.sparse the maps are
+// never made: after the selection this kernel evaluates conv3x3 64 -> 256 + bias + ReLU + conv1x1 256 -> c of every
+// listed head at the winners -- a [16 winners x 576] x [576 x 256] MFMA product per (workgroup, head), the winner's
+// 3x3 x 64 patch gathered from the NHWC feature map (zero outside the map: padding 1) -- applies the dense epilogue's
+// transforms (dep: detector.py:305-307) and assembles the packed rows exactly like the dense gather (emit_row).
+// One workgroup = 16 waves = 16 winners of one image x ALL sparse heads; wave w owns hidden channels 16w .. 16w+15.
+// 4 heads x 100 winners = 0.12 GFLOP instead of 9.7 GFLOP of dense maps at 512 x 512.
+constexpr int SP_HID = 256;          // hidden channels of a head (head_conv, opts.py:294-295)
+
+struct SparseArgs {
+    const float *feat; int ldf; size_t feat_bs;
+    int nheads;
+    int head[CT_NUM_HEADS];
+    const float *w1[CT_NUM_HEADS], *b1[CT_NUM_HEADS], *w2[CT_NUM_HEADS], *b2[CT_NUM_HEADS];
+    float depth_scale;
+    int zero_tracking;
+    const unsigned long long *winners;
+    float *partial;                  // [B * tiles][nheads][4][16][8] partial head outputs (one hidden quarter each)
+    unsigned *arrive;                // [B * tiles] arrival counters, zero between launches
+    float *out, *host_out;
+    int *done_flag; unsigned *done_counter;
+    int B, h, w, K, F, tiles;        // tiles = ceil(K / 16) winner tiles per image
+    unsigned present;
+};
+
+// One workgroup = 4 waves = (16 winners of one image) x (one head) x (one quarter of its 256 hidden channels): wave w owns
+// hidden channels 64 * quarter + 16 * w ...  First version (one workgroup per winner tile, all heads, 16 waves): 68 us at
+// one stream -- seven workgroups each pulling all 2.4 MB of head weights through one CU's L1 (rocprofv3,
+// gpurun_out/r05_e); spread over tiles x heads x quarters every workgroup streams 147 KB, issued in full BEFORE the
+// winners are even read.  The partial 1x1 outputs of the four quarters meet in a scratch block; the last workgroup of
+// a winner tile to arrive (agent-scope counter) sums them in quarter order (deterministic), applies bias / transforms
+// and assembles the tile's rows.
+__global__ __launch_bounds__(256) void sparse_heads_kernel(SparseArgs a)
+{
+    __shared__ __attribute__((aligned(16))) float A[36 * 256];            // [tap * 4 + slab][16 winners][16 ch], swizzled
+    __shared__ __attribute__((aligned(16))) float Hd[16 * 68];            // this quarter's 64 hidden activations per winner
+    __shared__ float V[16][CT_NUM_HEADS * 8];                             // (last workgroup) head outputs of the 16 winners
+    __shared__ int wy[16], wx[16], wcls[16];
+    __shared__ float wscore[16];
+    __shared__ unsigned last_flag;
+    constexpr int HCH[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    const int quarter = bid & 3; bid >>= 2;
+    const int hi = bid % a.nheads; bid /= a.nheads;
+    const int tile = bid;                                   // b * tiles + t
+    const int b = tile / a.tiles, t = tile - b * a.tiles;
+    const int HW = a.h * a.w;
+    const int hd = a.head[hi];
+    const int cout = HCH[hd];
+    // ---- this wave's weights: 36 (tap, slab) fragments of 1 KiB for n-tile 4 * quarter + wave, all requested now ----
+    const float *wp = a.w1[hi] + ((size_t)(quarter * 4 + wave) << 8) + (lane << 2);
+    f32x4 bq[36];
+#pragma unroll
+    for (int st = 0; st < 36; ++st) bq[st] = *reinterpret_cast<const f32x4 *>(wp + (size_t)st * (16 << 8));
+    const int li = lane & 15, lg = lane >> 4;
+    const float bias1 = a.b1[hi][quarter * 64 + wave * 16 + li];
+    if (tid < 16) {
+        const int r = t * 16 + tid;
+        int y = -4, x = -4, cls = 0;
+        float sc = 0.f;
+        if (r < a.K) {
+            const unsigned long long k = a.winners[(size_t)b * a.K + r];
+            const unsigned flat = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            cls = (int)(flat / (unsigned)HW);
+            const int p = (int)(flat - (unsigned)cls * (unsigned)HW);
+            y = p / a.w; x = p - y * a.w;
+            sc = ord2f((unsigned)(k >> 32));
+        }
+        wy[tid] = y; wx[tid] = x; wcls[tid] = cls; wscore[tid] = sc;
+    }
+    __syncthreads();
+    // ---- the 16 winners' 3x3 x 64 patches: 16 x 9 x 16 float4 items (rows past K and taps outside the map: zero) ----
+    {
+        const float *fb = a.feat + (size_t)b * a.feat_bs;
+        f32x4 pv[9];
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int it = tid + 256 * j;
+            const int m = it / 144, rem = it - m * 144;
+            const int tap = rem >> 4, q = rem & 15;
+            const int y = wy[m] + tap / 3 - 1, x = wx[m] + tap % 3 - 1;
+            const bool ok = y >= 0 && y < a.h && x >= 0 && x < a.w && wy[m] >= 0;
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(fb + (ok ? ((size_t)y * a.w + x) * a.ldf + q * 4 : 0));
+            pv[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int j = 0; j < 9; ++j) {
+            const int it = tid + 256 * j;
+            const int m = it / 144, rem = it - m * 144;
+            const int tap = rem >> 4, q = rem & 15;
+            *reinterpret_cast<f32x4 *>(A + (tap * 4 + (q >> 2)) * 256 + m * 16 + (((q & 3) ^ ((m >> 1) & 2)) << 2)) = pv[j];
+        }
+    }
+    __syncthreads();
+    {
+        const int aoff = li * 16 + ((lg ^ ((li >> 1) & 2)) << 2);
+        f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < 36; ++st) {
+            const f32x4 af = *reinterpret_cast<const f32x4 *>(A + st * 256 + aoff);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(af[e], bq[st][e], acc, 0, 0, 0);
+        }
+        // C layout: row (winner) = lg * 4 + e, column (hidden channel of this quarter) = 16 * wave + li
+#pragma unroll
+        for (int e = 0; e < 4; ++e) Hd[(lg * 4 + e) * 68 + wave * 16 + li] = fmaxf(acc[e] + bias1, 0.0f);
+    }
+    __syncthreads();
+    // ---- this quarter's share of conv1x1 256 -> cout: 2 lanes per (winner, channel), 32 hidden values each ----
+    {
+        const int pair = tid >> 1, part = tid & 1;
+        const int m = pair >> 3, c = pair & 7;
+        float sum = 0.f;
+        if (c < cout) {
+            const float *w2 = a.w2[hi] + c * SP_HID + quarter * 64 + part * 32;
+            const float *hh = Hd + m * 68 + part * 32;
+#pragma unroll
+            for (int j = 0; j < 32; ++j) sum += hh[j] * w2[j];
+        }
+        sum += __shfl_xor(sum, 1);
+        if (part == 0) a.partial[((((size_t)tile * a.nheads + hi) * 4 + quarter) * 16 + m) * 8 + c] = sum;
+    }
+    // ---- last workgroup of the winner tile: sum the quarters, finish the heads, assemble the rows ----
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) {
+        const unsigned total = (unsigned)a.nheads * 4u;
+        const unsigned prev = __hip_atomic_fetch_add(a.arrive + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        last_flag = (prev == total - 1u) ? 1u : 0u;
+        if (prev == total - 1u) a.arrive[tile] = 0u;             // (ready for the next launch)
+    }
+    __syncthreads();
+    if (!last_flag) return;
+    __threadfence();
+    for (int i = tid; i < 16 * CT_NUM_HEADS * 8; i += 256) (&V[0][0])[i] = 0.f;
+    __syncthreads();
+    for (int i = tid; i < a.nheads * 128; i += 256) {
+        const int h2 = i >> 7, m = (i >> 3) & 15, c = i & 7;
+        const int hd2 = a.head[h2];
+        if (c >= HCH[hd2]) continue;
+        const float *pp = a.partial + (((size_t)tile * a.nheads + h2) * 4 * 16 + m) * 8 + c;
+        float v = __builtin_nontemporal_load(pp);
+        v += __builtin_nontemporal_load(pp + 128);
+        v += __builtin_nontemporal_load(pp + 256);
+        v += __builtin_nontemporal_load(pp + 384);
+        v += a.b2[h2][c];
+        if (hd2 == CT_HEAD_DEP) v = (1.0f / (1.0f / (1.0f + expf(-v)) + 1e-6f) - 1.0f) * a.depth_scale;
+        if (hd2 == CT_HEAD_TRACKING && a.zero_tracking) v = 0.0f;
+        V[m][hd2 * 8 + c] = v;
+    }
+    __syncthreads();
+    if (tid < 16) {
+        const int r = t * 16 + tid;
+        if (r < a.K) {
+            float *row = a.out + ((size_t)b * a.K + r) * a.F;
+            float *hrow = a.host_out ? a.host_out + ((size_t)b * a.K + r) * a.F : nullptr;
+            emit_row(row, hrow, a.present, wscore[tid], wcls[tid], (float)wx[tid], (float)wy[tid],
+                     [&](int hd3, int ch) { return V[tid][hd3 * 8 + ch]; });
+        }
+    }
+    if (a.done_flag) raise_done_flag(a.done_flag, a.done_counter, a.B * a.tiles);
 }
 
 const int kHeadCh[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
@@ -742,15 +943,29 @@ int check(const ct_decode_desc *d, const char *who)
 
 }  // namespace
 
+// bit hd: head hd is part of the packed row -- it has a dense map or it is one of the sparse heads
+static unsigned present_mask(const ct_decode_desc *d)
+{
+    unsigned m = 0;
+    for (int i = 0; i < CT_NUM_HEADS; ++i)
+        if (d->heads[i]) m |= 1u << i;
+    if (d->sparse)
+        for (int i = 0; i < d->sparse->nheads && i < CT_NUM_HEADS; ++i)
+            if (d->sparse->head[i] >= 0 && d->sparse->head[i] < CT_NUM_HEADS) m |= 1u << d->sparse->head[i];
+    return m;
+}
+
 extern "C" int ct_decode_row_floats(const ct_decode_desc *d)
 {
+    const unsigned m = present_mask(d);
+    auto has = [&](int hd) { return (m >> hd) & 1u; };
     int f = 4;
-    if (d->heads[CT_HEAD_WH] || d->heads[CT_HEAD_LTRB] || d->heads[CT_HEAD_LTRB_AMODAL]) f += 4;
-    if (d->heads[CT_HEAD_LTRB_AMODAL]) f += 4;
+    if (has(CT_HEAD_WH) || has(CT_HEAD_LTRB) || has(CT_HEAD_LTRB_AMODAL)) f += 4;
+    if (has(CT_HEAD_LTRB_AMODAL)) f += 4;
     const int rest[7] = {CT_HEAD_TRACKING, CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET,
                          CT_HEAD_NUSCENES_ATT, CT_HEAD_VELOCITY};
     for (int q = 0; q < 7; ++q)
-        if (d->heads[rest[q]]) f += kHeadCh[rest[q]];
+        if (has(rest[q])) f += kHeadCh[rest[q]];
     return f;
 }
 
@@ -774,13 +989,21 @@ static int pick_groups(const ct_decode_desc *d, int seg, int nseg)
     return (int)G;
 }
 
+// sparse heads: [B][K] winner keys | [B * tiles] arrival counters (padded to 8 bytes) | partial head outputs
+static size_t sparse_bytes(const ct_decode_desc *d)
+{
+    if (!d->sparse) return 0;
+    const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
+    return (size_t)d->B * d->K * 8 + ((tiles * 4 + 7) & ~(size_t)7) + tiles * (size_t)d->sparse->nheads * 4 * 16 * 8 * sizeof(float);
+}
+
 extern "C" size_t ct_decode_workspace_bytes(const ct_decode_desc *d)
 {
     if (check(d, "ct_decode_workspace_bytes") != CT_OK) return 0;
     const int seg = pick_seg(d);
     const int nseg = ct_cdiv(d->h * d->w, seg);
     const long M2 = (long)d->C * nseg * d->K;
-    return ((size_t)d->B * M2 + (size_t)d->B * pick_groups(d, seg, nseg) * d->K) * sizeof(unsigned long long);
+    return ((size_t)d->B * M2 + (size_t)d->B * pick_groups(d, seg, nseg) * d->K) * sizeof(unsigned long long) + sparse_bytes(d);
 }
 
 extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
@@ -793,7 +1016,18 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     const int nseg = ct_cdiv(d->h * d->w, seg);
     const long M2 = (long)d->C * nseg * d->K;
     const int G = pick_groups(d, seg, nseg);
-    const size_t need = ((size_t)d->B * M2 + (size_t)d->B * G * d->K) * sizeof(unsigned long long);
+    const size_t need = ((size_t)d->B * M2 + (size_t)d->B * G * d->K) * sizeof(unsigned long long) + sparse_bytes(d);
+    const ct_sparse_heads_desc *sp = d->sparse;
+    if (sp) {
+        if (sp->nheads < 1 || sp->nheads > CT_NUM_HEADS || !sp->feat || sp->ldf < 64 || (sp->ldf & 3) || ((uintptr_t)sp->feat & 15))
+            CT_FAIL_ARG("ct_decode: sparse heads need 1..%d heads and a 16-byte aligned NHWC feature view of >= 64 channels", CT_NUM_HEADS);
+        for (int i = 0; i < sp->nheads; ++i) {
+            if (sp->head[i] < 0 || sp->head[i] >= CT_NUM_HEADS || !sp->w1[i] || !sp->b1[i] || !sp->w2[i] || !sp->b2[i])
+                CT_FAIL_ARG("ct_decode: sparse head %d is incomplete", i);
+            if (d->heads[sp->head[i]]) CT_FAIL_ARG("ct_decode: head %d is both dense and sparse", sp->head[i]);
+        }
+        if (d->done_flag && !d->done_counter) CT_FAIL_ARG("ct_decode: done_flag needs done_counter");
+    }
     if (!d->workspace || d->workspace_bytes < need) {
         ct_set_error("ct_decode: needs %zu workspace bytes, got %zu", need, d->workspace_bytes);
         return CT_ERR_WORKSPACE;
@@ -829,6 +1063,8 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     if (a2.F < ct_decode_row_floats(d)) CT_FAIL_ARG("ct_decode: out_stride %d < row floats", d->out_stride);
     a2.M2 = (int)M2; a2.keys_final = 0;
     a2.host_out = d->host_out; a2.done_flag = d->done_flag; a2.done_counter = d->done_counter;
+    a2.present = present_mask(d);
+    a2.winners = sp ? (unsigned long long *)d->workspace + (size_t)d->B * M2 + (size_t)d->B * G * d->K : nullptr;
     if (G > 0) {
         Stage2aArgs aa;
         aa.cand = a1.cand; aa.cand2 = a1.cand + (size_t)d->B * M2;
@@ -839,5 +1075,29 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     }
     hipLaunchKernelGGL(decode_stage2_kernel, dim3((unsigned)d->B), dim3(1024), 0, s, a2);
     CT_CHECK_LAUNCH("ct_decode(stage 2)");
+    if (sp) {
+        SparseArgs sa;
+        sa.feat = sp->feat; sa.ldf = sp->ldf; sa.feat_bs = (size_t)d->h * d->w * sp->ldf;
+        sa.nheads = sp->nheads;
+        for (int i = 0; i < CT_NUM_HEADS; ++i) {
+            const bool on = i < sp->nheads;
+            sa.head[i] = on ? sp->head[i] : 0;
+            sa.w1[i] = on ? sp->w1[i] : nullptr; sa.b1[i] = on ? sp->b1[i] : nullptr;
+            sa.w2[i] = on ? sp->w2[i] : nullptr; sa.b2[i] = on ? sp->b2[i] : nullptr;
+        }
+        sa.depth_scale = sp->depth_scale; sa.zero_tracking = sp->zero_tracking;
+        {
+            const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
+            unsigned char *base = (unsigned char *)(a2.winners + (size_t)d->B * d->K);
+            sa.arrive = (unsigned *)base;
+            sa.partial = (float *)(base + ((tiles * 4 + 7) & ~(size_t)7));
+        }
+        sa.winners = a2.winners; sa.out = d->out; sa.host_out = d->host_out;
+        sa.done_flag = d->done_flag; sa.done_counter = d->done_counter;
+        sa.B = d->B; sa.h = d->h; sa.w = d->w; sa.K = d->K; sa.F = a2.F; sa.tiles = ct_cdiv(d->K, 16);
+        sa.present = a2.present;
+        hipLaunchKernelGGL(sparse_heads_kernel, dim3((unsigned)(d->B * sa.tiles * sp->nheads * 4)), dim3(256), 0, s, sa);
+        CT_CHECK_LAUNCH("ct_decode(sparse heads)");
+    }
     return CT_OK;
 }

@@ -60,8 +60,28 @@ extern "C" int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kin
     return CT_OK;
 }
 
+// (round 5: a KERNEL, not hipMemsetAsync -- inside a captured frame graph the runtime's memset node wrote garbage instead of
+//  the value on this stack (zero_tracking streams replayed through a graph: tracking rows of 1e-21 .. 1e12 instead of 0,
+//  tools/calls/dbg_zero.py; eager launches were fine).  Kernel nodes are what every other launch of the graph is.)
+__global__ __launch_bounds__(256) void fill_words_kernel(unsigned *dst, unsigned pattern, size_t nwords)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) dst[i] = pattern;
+}
+
 extern "C" int ct_memset_async(void *dst, int value, size_t bytes, void *stream)
 {
+    if (!dst && bytes) CT_FAIL_ARG("ct_memset_async: null pointer");
+    if (bytes == 0) return CT_OK;
+    if (((uintptr_t)dst & 3) == 0 && (bytes & 3) == 0) {
+        const unsigned b = (unsigned)value & 0xffu;
+        const size_t n = bytes / 4;
+        const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+        hipLaunchKernelGGL(fill_words_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned *)dst,
+                           b | (b << 8) | (b << 16) | (b << 24), n);
+        CT_CHECK_LAUNCH("ct_memset_async");
+        return CT_OK;
+    }
     hipError_t e = hipMemsetAsync(dst, value, bytes, (hipStream_t)stream);
     if (e != hipSuccess) {
         ct_set_error("ct_memset_async: %s", hipGetErrorString(e));

@@ -156,6 +156,11 @@ class StreamDetector(object):
         self.model = model.to(self.device).eval()
         self.B = num_streams
         self.flip = bool(getattr(opt, 'flip_test', False))
+        # opt.sparse_heads (round 5, opt-in, NOT a reference flag): the regression heads are evaluated at the K winners of
+        # the decode only instead of as dense maps (ct_sparse_heads_desc) -- same results (the decode reads nothing else of
+        # them, decode.py:99-180), 1/5 of the heads' work.  Not with flip_test (the merge averages maps) or pose heads.
+        self.sparse = (bool(getattr(opt, 'sparse_heads', False)) and not self.flip
+                       and not ({'hps', 'hm_hp'} & set(opt.heads)))
         self.use_graph = use_graph
         self.trackers = [Tracker(opt) for _ in range(self.B)]
         # native host path (C++ post-process + association incl. the Hungarian / public-detection / pre_dets branches
@@ -206,7 +211,7 @@ class StreamDetector(object):
         NB = self.B * (2 if self.flip else 1)
         with_img = bool(getattr(opt, 'tracking', False)) and bool(getattr(opt, 'pre_img', True))
         with_hm = bool(getattr(opt, 'tracking', False)) and bool(getattr(opt, 'pre_hm', False))
-        plan = self.model.get_plan(NB, H, W, with_img, with_hm, True)
+        plan = self.model.get_plan(NB, H, W, with_img, with_hm, True, self.sparse)
         x_in, img_in, hm_in = plan['inputs']
         outs = plan['outputs']
         ctx = {'hw': (H, W), 'plan': plan, 'NB': NB}
@@ -236,14 +241,17 @@ class StreamDetector(object):
         ctx['merged'] = merged
         dec_heads = {k: v for k, v in merged.items() if k != 'hm'}
         ctx['done_flag'] = torch.zeros((16,), dtype=torch.int32).pin_memory()      # (its own cache line)
-        F = ops.Decoder.row_floats(dec_heads)
+        sparse = plan.get('sparse')
+        if sparse is not None:
+            sparse = dict(sparse, zero_tracking=bool(getattr(opt, 'zero_tracking', False)))
+        F = ops.Decoder.row_floats(dec_heads, [n for n, *_ in sparse['heads']] if sparse else None)
         ctx['host_out'] = torch.zeros((merged['hm'].shape[0], opt.K, F), dtype=torch.float32).pin_memory()
         # (round 3: the decode stores its rows straight into the pinned block and raises the end-of-frame flag itself --
         #  no D2H copy node and no flag kernel at the end of the frame graph; not with pose heads, whose kernels
         #  complete the rows after the decode)
         direct = HOST_FLAG and HOST_ROWS
         ctx['decoder'] = ops.Decoder(merged['hm'], dec_heads, opt.K, host_out=ctx['host_out'] if direct else None,
-                                     done_flag=ctx['done_flag'] if direct else None)
+                                     done_flag=ctx['done_flag'] if direct else None, sparse=sparse)
         assert tuple(ctx['decoder'].out.shape) == tuple(ctx['host_out'].shape)
         ctx['host_rows'] = ctx['host_out'].numpy()
         ctx['host_hm'] = torch.zeros((NB, 1, H, W), dtype=torch.float32).pin_memory() if (with_hm and not self.native) else None

@@ -176,17 +176,22 @@ class DLASegHIP(torch.nn.Module):
                  if (FUSE_HEADS and WINOGRAD and hc == 256) else [])
         small = small[:_lib.CT_MAX_FUSED_HEADS]
         P['heads_small'] = small
-        if small:
-            w0s = torch.cat([sd[h + '.0.weight'] for h in small], 0)
-            w2s = torch.zeros((len(small), 8, hc), device=dev)
-            b2s = torch.zeros((len(small), 8), device=dev)
-            for i, h in enumerate(small):
+        def fused(names):
+            """(w0 Winograd-packed, b0, w2 [n,8,256], b2 [n,8]) of ct_heads_fused for the heads ``names``"""
+            w0s = torch.cat([sd[h + '.0.weight'] for h in names], 0)
+            w2s = torch.zeros((len(names), 8, hc), device=dev)
+            b2s = torch.zeros((len(names), 8), device=dev)
+            for i, h in enumerate(names):
                 c = self.heads[h]
                 w2s[i, :c] = sd[h + '.2.weight'].reshape(c, hc)
                 b2s[i, :c] = sd[h + '.2.bias']
-            P['hs_w0'] = ops.pack_winograd(w0s)
-            P['hs_b0'] = torch.cat([sd[h + '.0.bias'] for h in small], 0).contiguous()
-            P['hs_w2'], P['hs_b2'] = w2s.contiguous(), b2s.contiguous()
+            return (ops.pack_winograd(w0s), torch.cat([sd[h + '.0.bias'] for h in names], 0).contiguous(),
+                    w2s.contiguous(), b2s.contiguous())
+
+        if small:
+            P['hs:' + ','.join(small)] = fused(small)
+            if 'hm' in small and small != ['hm']:
+                P['hs:hm'] = fused(['hm'])             # (sparse-heads plans: the dense launch holds 'hm' alone)
         big = [h for h in self.heads if h not in small]
         P['heads_big'] = big
         if small and big:                  # the remaining (wide) heads keep the two-launch form on their own channels
@@ -211,11 +216,17 @@ class DLASegHIP(torch.nn.Module):
         P['head2_b'] = torch.cat([sd[h + '.2.bias'] for h in self.heads], 0).contiguous()
         for h in self.heads:      # per-head form, used when the block-diagonal one would waste too many flops
             P[h + '.2'] = (ops.pack_weight(sd[h + '.2.weight']), sd[h + '.2.bias'].contiguous())
+        # sparse heads (round 5, opt-in): the regression heads the decode only reads at the K winners -- direct-form
+        # packed conv3x3 weights (the Winograd form has no single-pixel evaluation), hidden bias, [c, 256] output layer
+        if hc == 256:
+            for h, c in self.heads.items():
+                if h in _lib.HEAD_INDEX:
+                    P['sparse.' + h] = (ops.pack_weight(sd[h + '.0.weight']), sd[h + '.0.bias'].contiguous(),
+                                        sd[h + '.2.weight'].reshape(c, hc).contiguous(), sd[h + '.2.bias'].contiguous())
         self._prepared = P
         return P
 
-    # --- plan ---------------------------------------------------------------------------
-    def _build_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid):
+    def _build_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid, sparse_heads=False):
         P = self._prepare()
         lib = _lib.load()
         dev = next(self.buffers()).device
@@ -350,7 +361,24 @@ class DLASegHIP(torch.nn.Module):
         L.extend(dcn_launches)
 
         small, big = P['heads_small'], P['heads_big']
-        if small:
+        plan['sparse'] = None
+        if sparse_heads:
+            # opt-in (detector only, never Module.forward): the regression heads the decode reads at the K winners are not
+            # computed as maps -- ct_decode evaluates them at those pixels (ct_sparse_heads_desc)
+            sp = [h for h in self.heads if ('sparse.' + h) in P]
+            if {'ltrb', 'ltrb_amodal'} & set(self.heads):
+                # dead heads: generic_decode overwrites the wh box with the ltrb / ltrb_amodal box (decode.py:131-139,150-159)
+                # and `reg` only feeds the wh box (decode.py:102-110) -- neither reaches the returned dict, so with the
+                # MOT head set (opts.py:343-359 + --ltrb_amodal) they are not evaluated at all
+                sp = [h for h in sp if h not in ('reg', 'wh')]
+            if not sp or 'hm' not in self.heads or {'hps', 'hm_hp'} & set(self.heads) or not fuse_sigmoid:
+                raise _lib.CTError('sparse heads need an hm head, regression heads with head_conv 256, no pose heads '
+                                   'and the detector\'s fused epilogues')
+            plan['sparse'] = {'feat': feat, 'heads': [(h,) + P['sparse.' + h] for h in sp], 'depth_scale': self.depth_scale}
+            small = [h for h in small if ('sparse.' + h) not in P]          # (the dead heads leave the dense launch too)
+            if any(('sparse.' + h) in P for h in big):          # (more small heads than one fused launch holds: not with sparse heads)
+                raise _lib.CTError('sparse heads: %s do not fit the fused-heads launch' % [h for h in big if ('sparse.' + h) in P])
+        if small or plan['sparse'] is not None:
             outputs = self._plan_heads_fused(plan, L, P, feat, N, dev, tune, fuse_sigmoid, small, big)
         else:
             nh = len(self.heads)
@@ -412,25 +440,27 @@ class DLASegHIP(torch.nn.Module):
         lib = _lib.load()
         hc = self.head_conv
         outputs = {}
-        ctot = sum(self.heads[h] for h in small)
-        comb = torch.empty((N, ctot, feat.H, feat.W), device=dev)
-        hd = _lib.HeadsDesc()
-        hd.x, hd.N, hd.H, hd.W, hd.Cin, hd.ldx = feat.ptr, N, feat.H, feat.W, feat.C, feat.ld
-        hd.w0_winograd, hd.b0, hd.nheads = P['hs_w0'].data_ptr(), P['hs_b0'].data_ptr(), len(small)
-        hd.w2, hd.b2, hd.out, hd.ctot = P['hs_w2'].data_ptr(), P['hs_b2'].data_ptr(), comb.data_ptr(), ctot
-        hd.depth_scale = self.depth_scale
-        c0 = 0
-        for i, h in enumerate(small):
-            c = self.heads[h]
-            hd.cout[i], hd.coff[i] = c, c0
-            if fuse_sigmoid and h == 'hm':
-                hd.sig_lo, hd.sig_hi = c0, c0 + c
-            if fuse_sigmoid and h == 'dep':
-                hd.dep_lo, hd.dep_hi = c0, c0 + c
-            outputs[h] = comb[:, c0:c0 + c]
-            c0 += c
-        L.append(_Launch('heads.fused[%s]' % ' + '.join(small), 'heads', hd, (feat, comb, P['hs_w0'], P['hs_b0'], P['hs_w2'], P['hs_b2']),
-                         us=100.0))
+        if small:
+            ctot = sum(self.heads[h] for h in small)
+            comb = torch.empty((N, ctot, feat.H, feat.W), device=dev)
+            hd = _lib.HeadsDesc()
+            hd.x, hd.N, hd.H, hd.W, hd.Cin, hd.ldx = feat.ptr, N, feat.H, feat.W, feat.C, feat.ld
+            hs_w0, hs_b0, hs_w2, hs_b2 = P['hs:' + ','.join(small)]
+            hd.w0_winograd, hd.b0, hd.nheads = hs_w0.data_ptr(), hs_b0.data_ptr(), len(small)
+            hd.w2, hd.b2, hd.out, hd.ctot = hs_w2.data_ptr(), hs_b2.data_ptr(), comb.data_ptr(), ctot
+            hd.depth_scale = self.depth_scale
+            c0 = 0
+            for i, h in enumerate(small):
+                c = self.heads[h]
+                hd.cout[i], hd.coff[i] = c, c0
+                if fuse_sigmoid and h == 'hm':
+                    hd.sig_lo, hd.sig_hi = c0, c0 + c
+                if fuse_sigmoid and h == 'dep':
+                    hd.dep_lo, hd.dep_hi = c0, c0 + c
+                outputs[h] = comb[:, c0:c0 + c]
+                c0 += c
+            L.append(_Launch('heads.fused[%s]' % ' + '.join(small), 'heads', hd, (feat, comb, hs_w0, hs_b0, hs_w2, hs_b2),
+                             us=100.0))
         if big:
             mid = ops.new_view(N, feat.H, feat.W, hc * len(big), dev)
             d = ops.make_conv_desc(feat, P['hb_w'], hc * len(big), 3, 1, shift=P['hb_b'], relu=True, out=mid, w_wino=P['hb_ww'])
@@ -448,7 +478,7 @@ class DLASegHIP(torch.nn.Module):
                 L.append(_Launch('heads.%s.2' % h, 'conv', d, (mid, o), us=us,
                                  ws_need=lib.ct_conv2d_workspace_bytes(ctypes.byref(d))))
                 outputs[h] = o
-        return OrderedDict((h, outputs[h]) for h in self.heads)
+        return OrderedDict((h, outputs[h]) for h in self.heads if h in outputs)
 
     def run_stem_partial(self, x, pre_img, out):
         """the terms of the stem that do not depend on the tracker (dla.py:305-311: base_layer(x) + pre_img_layer(
@@ -760,8 +790,8 @@ class DLASegHIP(torch.nn.Module):
                 parts.append('%s:%s' % (l.name, l.fn))
         return ';'.join(parts)
 
-    def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False):
-        key = (N, H, W, with_img, with_hm, fuse_sigmoid)
+    def get_plan(self, N, H, W, with_img, with_hm, fuse_sigmoid=False, sparse_heads=False):
+        key = (N, H, W, with_img, with_hm, fuse_sigmoid, sparse_heads)
         if key not in self._plans:
             self._plans[key] = self._build_plan(*key)
         return self._plans[key]

@@ -252,16 +252,19 @@ class Decoder(object):
     pose task, by the refined key points [2J] and ``kps_score`` [1]."""
 
     @staticmethod
-    def row_floats(heads):
-        """floats per packed row for this set of heads (the pose fields included)"""
-        _, F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX])
+    def row_floats(heads, sparse=None):
+        """floats per packed row for this set of heads (the pose fields included; ``sparse``: names of sparse heads)"""
+        _, F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX] + list(sparse or ()))
         if 'hps' in heads and 'hm_hp' in heads:
             F += heads['hps'].shape[1] + 1
         return F
 
-    def __init__(self, hm, heads, K, host_out=None, done_flag=None):
+    def __init__(self, hm, heads, K, host_out=None, done_flag=None, sparse=None):
         """``host_out`` (pinned host float32 [B,K,F]) / ``done_flag`` (pinned host int32): the decode also stores the
-        rows straight into host memory and raises the flag when they are complete (no pose heads)"""
+        rows straight into host memory and raises the flag when they are complete (no pose heads).
+        ``sparse`` (round 5, opt-in): ``{'feat': NHWC view of the 64-channel feature map, 'heads': [(name, w1_packed, b1,
+        w2 [c,256], b2)], 'depth_scale', 'zero_tracking'}`` -- these regression heads have no map in ``heads``; they are
+        evaluated at the K winners only (ct_sparse_heads_desc)"""
         lib = _lib.load()
         self.K = K
         B, C, h, w = hm.shape
@@ -278,7 +281,23 @@ class Decoder(object):
                 assert planes_ok(t) and t.shape[1] == _lib.HEAD_CH[name], name
                 d.heads[_lib.HEAD_INDEX[name]] = t.data_ptr()
                 d.head_batch_stride[_lib.HEAD_INDEX[name]] = t.stride(0)
-        self.layout, self.F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX])
+        self.sparse = None
+        if sparse is not None:
+            assert 'hps' not in heads and all(n not in heads for n, *_ in sparse['heads'])
+            sp = _lib.SparseHeadsDesc()
+            feat = sparse['feat']
+            assert feat.C == 64 and (feat.N, feat.H, feat.W) == (B, h, w)
+            sp.feat, sp.ldf, sp.nheads = feat.ptr, feat.ld, len(sparse['heads'])
+            for i, (name, w1, b1, w2, b2) in enumerate(sparse['heads']):
+                assert tuple(w2.shape) == (_lib.HEAD_CH[name], 256) and w2.is_contiguous() and b1.numel() == 256
+                sp.head[i] = _lib.HEAD_INDEX[name]
+                sp.w1[i], sp.b1[i], sp.w2[i], sp.b2[i] = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
+            sp.depth_scale = float(sparse.get('depth_scale', 1.0))
+            sp.zero_tracking = int(bool(sparse.get('zero_tracking', False)))
+            self.sparse = (sp, sparse)                     # (keeps the tensors alive)
+            d.sparse = ctypes.pointer(sp)
+        self.layout, self.F = decode_layout([n for n in heads if n in _lib.HEAD_INDEX] +
+                                            ([n for n, *_ in sparse['heads']] if sparse is not None else []))
         F0 = self.F
         assert lib.ct_decode_row_floats(ctypes.byref(d)) == F0
         self.pose = None
@@ -294,7 +313,8 @@ class Decoder(object):
         nbytes = lib.ct_decode_workspace_bytes(ctypes.byref(d))
         if nbytes == 0:
             _lib.check(1, 'ct_decode_workspace_bytes')
-        self.ws = torch.empty(nbytes // 8, dtype=torch.int64, device=hm.device)
+        # (zeroed: the sparse heads' arrival counters start at 0 and every launch leaves them there)
+        self.ws = torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=hm.device)
         d.out, d.inds = self.out.data_ptr(), self.inds.data_ptr()
         d.out_stride = self.F
         d.workspace, d.workspace_bytes = self.ws.data_ptr(), nbytes

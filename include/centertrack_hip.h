@@ -36,8 +36,9 @@ extern "C" {
 
 /* ABI version of THIS header: bumped whenever a descriptor struct changes layout or a tuning key changes meaning.  A
  * binding compares it with ct_version() of the loaded library before the first descriptor call (centertrack_amd/_lib.py
- * does).  100 = rounds 1-3; 101 = ct_conv_desc.proj_* (fused Tree.project), key "stem_rows", box probes. */
-#define CT_ABI_VERSION 101
+ * does).  100 = rounds 1-3; 101 = ct_conv_desc.proj_* (fused Tree.project), key "stem_rows", box probes;
+ * 102 = ct_decode_desc.sparse (sparse heads). */
+#define CT_ABI_VERSION 102
 
 const char *ct_last_error(void);
 int ct_version(void);                      /* CT_ABI_VERSION the library was built with */
@@ -239,6 +240,23 @@ int ct_nhwc_to_nchw(const float *x, int N, int C, int H, int W, int ldx, float *
 enum { CT_HEAD_REG = 0, CT_HEAD_WH, CT_HEAD_TRACKING, CT_HEAD_LTRB, CT_HEAD_LTRB_AMODAL,
        CT_HEAD_DEP, CT_HEAD_ROT, CT_HEAD_DIM, CT_HEAD_AMODEL_OFFSET, CT_HEAD_NUSCENES_ATT,
        CT_HEAD_VELOCITY, CT_NUM_HEADS };
+/* Sparse heads (round 5, opt-in; no reference equivalent -- the reference computes every head as a dense map,
+ * base_model.py:86-90, and then reads it at K pixels, decode.py:99-180): the regression heads listed here are evaluated
+ * at the K winners of every image only, after the selection, and the packed rows are assembled from those values; their
+ * entries in ct_decode_desc.heads must be NULL.  feat: DEVICE NHWC view of the 64-channel feature map the heads read
+ * (dla.py:631-640), image 0, channel pitch ldf (16-byte aligned, >= 64), images h * w * ldf floats apart.  Per head:
+ * head[i] = CT_HEAD_* id; w1 = conv3x3 64 -> 256 weights in ct_pack_conv_weight layout, b1 [256]; w2 = conv1x1 weights
+ * [c][256] row-major, b2 [c].  The dep head gets the dense epilogue's transform (1 / (sigmoid(v) + 1e-6) - 1) *
+ * depth_scale (detector.py:305-307); zero_tracking != 0 zeroes the tracking output (decode.py:95-96).  With sparse heads
+ * ct_decode's workspace must be ZERO before the first call (it holds arrival counters that every launch leaves at zero). */
+typedef struct ct_sparse_heads_desc {
+    const float *feat; int ldf;
+    int nheads;
+    int head[CT_NUM_HEADS];
+    const float *w1[CT_NUM_HEADS], *b1[CT_NUM_HEADS], *w2[CT_NUM_HEADS], *b2[CT_NUM_HEADS];
+    float depth_scale;
+    int zero_tracking;
+} ct_sparse_heads_desc;
 typedef struct ct_decode_desc {
     const float *hm; int B, C, h, w, K;
     const float *heads[CT_NUM_HEADS];
@@ -254,6 +272,7 @@ typedef struct ct_decode_desc {
      * neither a D2H copy node nor a separate flag kernel behind the decode.  done_counter: DEVICE unsigned, zero before
      * the first launch (the last workgroup resets it).  All three NULL: device rows only. */
     float *host_out; int *done_flag; unsigned *done_counter;
+    const ct_sparse_heads_desc *sparse;    /* HOST pointer, NULL = every head is a dense map (ABI 102) */
 } ct_decode_desc;
 /* row layout: score, cls, xs0, ys0, then for each present field in this order:
  * bbox[4] (if wh|ltrb|ltrb_amodal), bbox_amodal[4] (if ltrb_amodal), tracking[2], dep[1],

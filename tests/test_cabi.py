@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_version_and_errors_without_gpu(lib):
     from centertrack_amd import _lib
     l = _lib.load()
-    assert l.ct_version() == _lib.ABI_VERSION == 101
+    assert l.ct_version() == _lib.ABI_VERSION == 102
     d = _lib.ConvDesc()
     assert l.ct_conv2d(ctypes.byref(d), None) == 1          # CT_ERR_ARG: null pointers
     assert b'null' in l.ct_last_error()
@@ -85,7 +85,9 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
               'ct_pose_desc': (_lib.PoseDesc, ['rows', 'box_col', 'hp_offset', 'out', 'workspace_bytes', 'box_wh', 'box_ltrb',
                                                'box_ltrb_batch_stride']),
               'ct_decode_desc': (_lib.DecodeDesc, ['hm', 'heads', 'out', 'hm_batch_stride', 'out_stride', 'host_out', 'done_flag',
-                                                   'done_counter']),
+                                                   'done_counter', 'sparse']),
+              'ct_sparse_heads_desc': (_lib.SparseHeadsDesc, ['feat', 'ldf', 'nheads', 'head', 'w1', 'b1', 'w2', 'b2',
+                                                              'depth_scale', 'zero_tracking']),
               'ct_heads_desc': (_lib.HeadsDesc, ['x', 'w0_winograd', 'cout', 'out', 'depth_scale']),
               'ct_frame_loop_desc': (_lib.FrameLoopDesc, ['B', 'trackers', 'layout', 'out_thresh', 'host_rows', 'rows_keep',
                                                           'blob_params', 'blob_cap', 'nslots', 'graphs', 'frames',
