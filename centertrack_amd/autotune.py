@@ -37,7 +37,8 @@ def _cache_path():
     return os.environ.get('CENTERTRACK_TUNE_CACHE', '')
 
 
-PINNED_TABLE = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune_table.json')
+# (CENTERTRACK_TUNE_TABLE: another pinned table, for A/B runs of a re-tuned one before it replaces the shipped file)
+PINNED_TABLE = os.environ.get('CENTERTRACK_TUNE_TABLE') or os.path.join(os.path.dirname(os.path.abspath(__file__)), 'tune_table.json')
 
 
 def _read_table(path):

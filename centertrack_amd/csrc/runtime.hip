@@ -198,6 +198,72 @@ extern "C" int ct_calib_launches(int n, int blocks, float *buf, void *stream)
     return CT_OK;
 }
 
+// (4) where the dispatcher puts workgroups: every workgroup records the hardware ids of the CU it runs on (HW_ID: shader
+//     engine / array / CU; XCC_ID: the XCD) and its start / end time (100 MHz), and spins for `spin_ticks` in between.
+//     `lds_bytes` of dynamic LDS cap the workgroups a CU can hold (64 KB: two), like the stem's 249 VGPRs do.  An MI355X
+//     has 32 of 36 physical CUs per XCD enabled; WHICH four are fused off differs from chip to chip, and the dispatcher
+//     hands workgroups to shader engines, not to CUs -- a launch sized "two workgroups per CU" finishes in one round only
+//     if the engines hold equal numbers of CUs.
+__global__ __launch_bounds__(256) void calib_cu_map_kernel(int spin_ticks, unsigned *out)
+{
+    extern __shared__ float cu_map_lds[];
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    if (threadIdx.x == 0) {
+        const unsigned hw = __builtin_amdgcn_s_getreg((31 << 11) | 4);          // HW_REG_HW_ID
+        const unsigned xcc = __builtin_amdgcn_s_getreg((31 << 11) | 20);        // HW_REG_XCC_ID
+        cu_map_lds[0] = 0.f;
+        while (__builtin_amdgcn_s_memrealtime() - t0 < (unsigned long long)spin_ticks) __builtin_amdgcn_s_sleep(8);
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        out[4 * blockIdx.x + 0] = hw;
+        out[4 * blockIdx.x + 1] = xcc;
+        out[4 * blockIdx.x + 2] = (unsigned)t0;
+        out[4 * blockIdx.x + 3] = (unsigned)t1;
+    }
+    __syncthreads();
+}
+
+extern "C" int ct_calib_cu_map(int blocks, int lds_bytes, int spin_ticks, unsigned *out, void *stream)
+{
+    if (blocks <= 0 || lds_bytes < 0 || lds_bytes > 160 * 1024 || spin_ticks < 0 || !out) CT_FAIL_ARG("ct_calib_cu_map: bad arguments");
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(calib_cu_map_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        attr = true;
+    }
+    hipLaunchKernelGGL(calib_cu_map_kernel, dim3(blocks), dim3(256), (size_t)lds_bytes, (hipStream_t)stream, spin_ticks, out);
+    CT_CHECK_LAUNCH("ct_calib_cu_map");
+    return CT_OK;
+}
+
+// (5) per-XCD memory rate: workgroup i copies ITS OWN contiguous chunk of `chunk_bytes` (one 16-byte load in flight per
+//     lane) and records the XCD it ran on and its start / end time.  A launch ends when its slowest workgroup does: an XCD
+//     whose path to memory is slower than its seven siblings' stretches every memory-bound launch of a frame although
+//     the aggregate bandwidth of the chip (probes 2) barely moves.
+__global__ __launch_bounds__(256) void calib_xcd_stream_kernel(const float4 *src, float4 *dst, size_t chunk_vec, unsigned *out)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    const float4 *s = src + (size_t)blockIdx.x * chunk_vec;
+    float4 *d = dst + (size_t)blockIdx.x * chunk_vec;
+    for (size_t i = threadIdx.x; i < chunk_vec; i += 256) d[i] = s[i];
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long t1 = __builtin_amdgcn_s_memrealtime();
+        out[4 * blockIdx.x + 0] = __builtin_amdgcn_s_getreg((31 << 11) | 4);
+        out[4 * blockIdx.x + 1] = __builtin_amdgcn_s_getreg((31 << 11) | 20);
+        out[4 * blockIdx.x + 2] = (unsigned)t0;
+        out[4 * blockIdx.x + 3] = (unsigned)t1;
+    }
+}
+
+extern "C" int ct_calib_xcd_stream(const void *src, void *dst, size_t chunk_bytes, int blocks, unsigned *out, void *stream)
+{
+    if (!src || !dst || !out || blocks <= 0 || (chunk_bytes & 15)) CT_FAIL_ARG("ct_calib_xcd_stream: bad arguments");
+    hipLaunchKernelGGL(calib_xcd_stream_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const float4 *)src, (float4 *)dst,
+                       chunk_bytes / 16, out);
+    CT_CHECK_LAUNCH("ct_calib_xcd_stream");
+    return CT_OK;
+}
+
 // ---- end-of-frame flag in pinned host memory ----
 __global__ void signal_host_kernel(int *flag, int value)
 {

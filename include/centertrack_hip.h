@@ -425,6 +425,13 @@ int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
 int ct_calib_chase(const unsigned *ring, int hops, unsigned start, unsigned long long *out, void *stream);
 int ct_calib_stream(const void *src, void *dst, size_t bytes, int blocks, int inflight, void *stream);
 int ct_calib_launches(int n, int blocks, float *buf, void *stream);
+/* ct_calib_cu_map: `blocks` workgroups of 256 lanes with lds_bytes of dynamic LDS each record {HW_ID, XCC_ID, start, end (100 MHz
+ * ticks)} into out (DEVICE uint32[4 * blocks]) and spin for spin_ticks in between: which CUs exist and how the dispatcher
+ * loads them. */
+int ct_calib_cu_map(int blocks, int lds_bytes, int spin_ticks, unsigned *out, void *stream);
+/* ct_calib_xcd_stream: workgroup i copies chunk i (chunk_bytes, multiple of 16) of src to dst and records {HW_ID, XCC_ID,
+ * start, end}: the memory rate every XCD reaches on its own (out: DEVICE uint32[4 * blocks]). */
+int ct_calib_xcd_stream(const void *src, void *dst, size_t chunk_bytes, int blocks, unsigned *out, void *stream);
 
 /* ---- the host loop of one frame of B streams, natively (round 3) ----------------------------------------------
  * Replaces, for the steady state of the tracking path, the per-frame host work of Detector.run

@@ -11,6 +11,9 @@ predict the class.  Round 5 adds probes of what a latency-bo
   stream_GBps    copy of 1 GiB at one wave per SIMD with one 16-byte load in flight per lane (the regime of the stem and
                  the decode) and at 8 workgroups per CU with four in flight (the bandwidth regime)
   launch_us      dependent kernel boundary inside a captured graph: 200 launches of 1 / 256 workgroups
+  cu_map         hardware ids (XCD / shader engine / CU) and start / end times of every workgroup of three probe launches
+                 (ct_calib_cu_map): how many CUs each shader engine of each XCD holds on THIS chip (32 of 36 per XCD are
+                 enabled; which ones differs), and whether a "two workgroups per CU" launch finishes in one round
   sysfs          clock levels (sclk / mclk / fclk / socclk: active level and the table), partition modes and power cap as
                  the amdgpu driver reports them for the device
   clocks_under_load (bench.py only) the active sclk / mclk / fclk levels sampled every 20 ms while the resident-frame
@@ -63,7 +66,9 @@ def chase(lib, st, device):
     out = torch.zeros(3, dtype=torch.int64, device=device)
     res, mhz = {}, {}
     for name, lines, hops, pinned in (('l1_16KB', 128, 20000, False), ('l2_1MB', 8192, 20000, False),
-                                      ('mall_64MB', 1 << 19, 20000, False), ('hbm_2GiB', 1 << 24, 20000, False),
+                                      ('mall_64MB', 1 << 19, 20000, False), ('mall_128MB', 1 << 20, 20000, False),
+                                      ('mall_192MB', 3 << 19, 20000, False), ('mall_240MB', 15 << 17, 20000, False),
+                                      ('hbm_2GiB', 1 << 24, 20000, False),
                                       ('host_pinned_1MB', 8192, 3000, True)):
         ring = _ring(lines, device, pinned)
         if not pinned:
@@ -82,6 +87,21 @@ def chase(lib, st, device):
         res[name] = round(best[0], 1)
         mhz[name] = round(best[1])
         del ring
+    # producer -> consumer: the ring was just WRITTEN by another kernel (a device copy), no read pass in between -- where
+    # does a kernel find what its predecessor wrote (the situation of every activation tensor of a frame)?
+    for name, lines in (('after_write_8MB', 1 << 16), ('after_write_64MB', 1 << 19)):
+        src = _ring(lines, device)
+        ring = torch.empty_like(src)
+        best = None
+        for rep in range(3):
+            ring.copy_(src)                                       # the producer kernel
+            lib.ct_calib_chase(ctypes.c_void_p(ring.data_ptr()), 20000, (rep * 7919) % lines, ctypes.c_void_p(out.data_ptr()), st)
+            torch.cuda.synchronize()
+            _, ticks, clocks = (int(v) for v in out.tolist())
+            ns = ticks * 10.0 / 20000
+            best = ns if best is None or ns < best else best
+        res[name] = round(best, 1)
+        del ring, src
     return res, mhz
 
 
@@ -117,6 +137,65 @@ def launches(lib, device):
             lib.ct_calib_launches(N, blocks, ctypes.c_void_p(buf.data_ptr()), _lib.stream_ptr())
         ms = _timed(g.replay, 5)
         res['graph_%dwg' % blocks] = round(ms * 1e3 / N, 2)
+    return res
+
+
+def cu_map(lib, st, device):
+    """which CUs exist (per XCD and shader engine) and how a "two workgroups per CU" launch lands on them: 512 workgroups
+    that can only sit two to a CU (64 KB of LDS each) and run 20 us each -- one round (20 us) if the dispatcher can give
+    every CU exactly two, more if some shader engines hold fewer CUs than others"""
+    import collections
+    import torch
+    res = {}
+    for name, blocks, lds, ticks in (('512wg_2_per_cu_20us', 512, 64 * 1024, 2000), ('256wg_1_per_cu_20us', 256, 128 * 1024, 2000),
+                                     ('1024wg_map', 1024, 16 * 1024, 200)):
+        out = torch.zeros(4 * blocks, dtype=torch.int32, device=device)
+        lib.ct_calib_cu_map(blocks, lds, ticks, ctypes.c_void_p(out.data_ptr()), st)      # (first launch: code upload)
+        torch.cuda.synchronize()
+        out.zero_()
+        lib.ct_calib_cu_map(blocks, lds, ticks, ctypes.c_void_p(out.data_ptr()), st)
+        torch.cuda.synchronize()
+        v = out.cpu().numpy().astype('uint32').reshape(blocks, 4)
+        hw, xcc = v[:, 0], v[:, 1] & 0xf
+        cu, sh, se = (hw >> 8) & 0xf, (hw >> 12) & 1, (hw >> 13) & 7
+        key = [(int(x), int(e), int(h), int(c)) for x, e, h, c in zip(xcc, se, sh, cu)]
+        per_cu = collections.Counter(key)
+        per_se = collections.Counter((k[0], k[1], k[2]) for k in per_cu)              # CUs seen per (XCD, SE, SH)
+        t0 = v[:, 2].astype('int64'); t1 = v[:, 3].astype('int64')
+        span = int(((t1 - t0.min()) & 0xffffffff).max())
+        d = {'span_us': round(span / 100.0, 1), 'distinct_cus': len(per_cu),
+             'wgs_per_cu': dict(sorted(collections.Counter(per_cu.values()).items())),
+             'late_starts': int((((t0 - t0.min()) & 0xffffffff) > ticks // 2).sum())}
+        if name == '1024wg_map':
+            d['cus_per_xcd'] = [sum(n for (x, e, h), n in per_se.items() if x == xi) for xi in range(8)]
+            d['cus_per_engine'] = dict(sorted(collections.Counter(per_se.values()).items()))      # {CUs in an (XCD, SE, SH): how many such}
+        res[name] = d
+    return res
+
+
+def xcd_stream(lib, st, device):
+    """per-XCD memory rate: 256 / 2048 workgroups copy 4 MB / 512 KB of their own each (HBM-sized total: 1 GiB) and 256
+    workgroups 64 KB each out of a 16 MiB L2 / Infinity-Cache resident buffer; reported: GB/s of the mean workgroup of every
+    XCD and the slowest-to-fastest XCD ratio of the launch's critical path (the LAST workgroup end of each XCD)"""
+    import torch
+    res = {}
+    a = torch.empty(1 << 28, device=device)
+    b = torch.empty(1 << 28, device=device)
+    for name, blocks, chunk, reps in (('1GiB_256wg', 256, 4 << 20, 2), ('1GiB_2048wg', 2048, 512 << 10, 2), ('16MiB_256wg', 256, 64 << 10, 6)):
+        out = torch.zeros(4 * blocks, dtype=torch.int32, device=device)
+        for _ in range(reps):
+            lib.ct_calib_xcd_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), chunk, blocks, ctypes.c_void_p(out.data_ptr()), st)
+        torch.cuda.synchronize()
+        v = out.cpu().numpy().astype('uint32').reshape(blocks, 4)
+        xcc = v[:, 1] & 0xf
+        t0 = v[:, 2].astype('int64'); t1 = v[:, 3].astype('int64')
+        dur = ((t1 - t0) & 0xffffffff) / 100.0                     # us per workgroup
+        end = ((t1 - t0.min()) & 0xffffffff) / 100.0
+        rate = [round(2.0 * chunk / (dur[xcc == x].mean() * 1e3), 1) if (xcc == x).any() else None for x in range(8)]
+        last = [round(float(end[xcc == x].max()), 1) if (xcc == x).any() else None for x in range(8)]
+        res[name] = {'GBps_per_wg_by_xcd': rate, 'last_end_us_by_xcd': last,
+                     'slowest_over_fastest_xcd': round(max(last) / max(1e-9, min(last)), 3)}
+    del a, b
     return res
 
 
@@ -180,6 +259,55 @@ def sysfs():
     return out
 
 
+def node():
+    """the HOST side of the box: 19 probe calls of round 5 alternated between a fast and a slow state with identical PCI
+    addresses in both (profiles/r05_a_box_probes.jsonl) -- whole nodes differ, not cards.  What the node says about itself:
+    kernel, CPU, amdgpu driver version and the module parameters that change how the memory system is driven (retry
+    faults / XNACK, page-table fragment size, scheduling policy), IOMMU groups, the ISA string HIP reports (xnack+/-)"""
+    out = {}
+    try:
+        import platform
+        out['kernel'] = platform.release()
+    except Exception:
+        pass
+    try:
+        with open('/proc/cpuinfo') as f:
+            for line in f:
+                if line.startswith('model name'):
+                    out['cpu'] = line.split(':', 1)[1].strip()
+                    break
+    except OSError:
+        pass
+    try:
+        import torch
+        out['gcn_arch'] = torch.cuda.get_device_properties(torch.cuda.current_device()).gcnArchName
+    except Exception:
+        pass
+    out['amdgpu_version'] = _read('/sys/module/amdgpu/version', 60)
+    prm = {}
+    for k in ('noretry', 'vm_fragment_size', 'vm_block_size', 'vm_size', 'sched_policy', 'mes', 'hws_max_conc_proc', 'sdma_phase_quantum',
+              'tmz', 'mtype_local', 'use_xgmi_p2p', 'pcie_p2p', 'aspm', 'runpm', 'ppfeaturemask', 'gpu_recovery', 'ras_enable'):
+        v = _read('/sys/module/amdgpu/parameters/' + k, 40)
+        if v is not None:
+            prm[k] = v
+    out['amdgpu_parameters'] = prm
+    try:
+        out['iommu_groups'] = len(os.listdir('/sys/kernel/iommu_groups'))
+    except OSError:
+        out['iommu_groups'] = None
+    out['cmdline'] = (_read('/proc/cmdline', 300) or '')[:300]
+    out['env'] = {k: os.environ[k] for k in ('HSA_XNACK', 'HSA_ENABLE_SDMA', 'HSA_ENABLE_IPC_MODE_LEGACY', 'GPU_MAX_HW_QUEUES') if k in os.environ}
+    try:
+        out['numa_nodes'] = len([d for d in os.listdir('/sys/devices/system/node') if d.startswith('node')])
+        d = _card_dir()
+        out['gpu_numa_node'] = _read(os.path.join(d, 'numa_node'), 10) if d else None
+        out['pcie_link'] = {'speed': _read(os.path.join(d, 'current_link_speed'), 30), 'width': _read(os.path.join(d, 'current_link_width'), 10)} if d else None
+        out['loadavg'] = _read('/proc/loadavg', 60)
+    except OSError:
+        pass
+    return out
+
+
 class ClockSampler(threading.Thread):
     """active sclk / mclk / fclk levels every `period` s while something else runs; summary() -> min / median / max MHz"""
 
@@ -225,7 +353,8 @@ def box_calibration(device=None, probes=True):
            'd2d_1GiB_GBps': round(d2d), 'd2d_16MiB_GBps': round(d2d_small)}
     if probes:
         for key, fn in (('chase', lambda: chase(lib, st, device)), ('stream_GBps', lambda: stream(lib, st, device)),
-                        ('launch_us', lambda: launches(lib, device)), ('sysfs', sysfs)):
+                        ('launch_us', lambda: launches(lib, device)), ('cu_map', lambda: cu_map(lib, st, device)), ('xcd_stream', lambda: xcd_stream(lib, st, device)),
+                        ('sysfs', sysfs), ('node', node)):
             try:
                 v = fn()
                 if key == 'chase':
