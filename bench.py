@@ -327,8 +327,7 @@ def main():
                                       'algorithmic_tflops': o['roofline_conv']['algorithmic_tflops']},
                     'mean_detections_per_frame': o['config']['mean_detections_per_frame'],
                     'plan_hash': o['plan_hash'], 'wall_s': round(time.perf_counter() - t0, 1)})
-                import scenarios as S_
-                if not S_.CONFIGS[name]['flip']:
+                if True:
                     sp = sparse_line(name, streams)
                     if sp.get('active') or 'error' in sp:
                         out['configs'][-1]['sparse_heads'] = sp

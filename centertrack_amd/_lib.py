@@ -79,7 +79,8 @@ class SparseHeadsDesc(ctypes.Structure):
                 ('head', ctypes.c_int * NUM_HEADS),
                 ('w1', ctypes.c_void_p * NUM_HEADS), ('b1', ctypes.c_void_p * NUM_HEADS),
                 ('w2', ctypes.c_void_p * NUM_HEADS), ('b2', ctypes.c_void_p * NUM_HEADS),
-                ('depth_scale', ctypes.c_float), ('zero_tracking', ctypes.c_int)]
+                ('depth_scale', ctypes.c_float), ('zero_tracking', ctypes.c_int),
+                ('flip_B', ctypes.c_int), ('flip_mode', ctypes.c_int * NUM_HEADS)]
 
 
 class DecodeDesc(ctypes.Structure):

@@ -780,8 +780,10 @@ struct SparseArgs {
     const float *w1[CT_NUM_HEADS], *b1[CT_NUM_HEADS], *w2[CT_NUM_HEADS], *b2[CT_NUM_HEADS];
     float depth_scale;
     int zero_tracking;
+    int flip_B;                      // flip_test: image b's mirrored twin is image flip_B + b of feat (0 = off)
+    int flip_mode[CT_NUM_HEADS];     // per sparse head: 0 = image b alone, 1 = (v + v') / 2, 2 = the same with even channels of v' negated
     const unsigned long long *winners;
-    float *partial;                  // [B * tiles][nheads][4][16][8] partial head outputs (one hidden quarter each)
+    float *partial;                  // [B * tiles][nheads][2 passes][4][16][8] partial head outputs (one hidden quarter each)
     unsigned *arrive;                // [B * tiles] arrival counters, zero between launches
     float *out, *host_out;
     int *done_flag; unsigned *done_counter;
@@ -796,7 +798,7 @@ struct SparseArgs {
 // winners are even read.  The partial 1x1 outputs of the four quarters meet in a scratch block; the last workgroup of
 // a winner tile to arrive (agent-scope counter) sums them in quarter order (deterministic), applies bias / transforms
 // and assembles the tile's rows.
-__global__ __launch_bounds__(256) void sparse_heads_kernel(SparseArgs a)
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sparse_heads_kernel(SparseArgs a)
 {
     __shared__ __attribute__((aligned(16))) float A[36 * 256];            // [tap * 4 + slab][16 winners][16 ch], swizzled
     __shared__ __attribute__((aligned(16))) float Hd[16 * 68];            // this quarter's 64 hidden activations per winner
@@ -837,20 +839,26 @@ __global__ __launch_bounds__(256) void sparse_heads_kernel(SparseArgs a)
         wy[tid] = y; wx[tid] = x; wcls[tid] = cls; wscore[tid] = sc;
     }
     __syncthreads();
+    // flip_test (detector.py:311-332): wh / dep / dim / amodel_offset are averaged with the MIRRORED image's value at the
+    // mirrored pixel -- a second pass over that image's patch at (y, w - 1 - x); every other head reads image b alone
+    const int npass = (a.flip_B > 0 && a.flip_mode[hi] != 0) ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
     // ---- the 16 winners' 3x3 x 64 patches: 16 x 9 x 16 float4 items (rows past K and taps outside the map: zero) ----
     {
-        const float *fb = a.feat + (size_t)b * a.feat_bs;
+        const float *fb = a.feat + (size_t)(pass ? a.flip_B + b : b) * a.feat_bs;
         f32x4 pv[9];
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int it = tid + 256 * j;
             const int m = it / 144, rem = it - m * 144;
             const int tap = rem >> 4, q = rem & 15;
-            const int y = wy[m] + tap / 3 - 1, x = wx[m] + tap % 3 - 1;
+            const int cx = pass ? a.w - 1 - wx[m] : wx[m];
+            const int y = wy[m] + tap / 3 - 1, x = cx + tap % 3 - 1;
             const bool ok = y >= 0 && y < a.h && x >= 0 && x < a.w && wy[m] >= 0;
             const f32x4 v = *reinterpret_cast<const f32x4 *>(fb + (ok ? ((size_t)y * a.w + x) * a.ldf + q * 4 : 0));
             pv[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
         }
+        if (pass) __syncthreads();                                // (pass 0's hidden tile / patch reads are done)
 #pragma unroll
         for (int j = 0; j < 9; ++j) {
             const int it = tid + 256 * j;
@@ -886,7 +894,8 @@ __global__ __launch_bounds__(256) void sparse_heads_kernel(SparseArgs a)
             for (int j = 0; j < 32; ++j) sum += hh[j] * w2[j];
         }
         sum += __shfl_xor(sum, 1);
-        if (part == 0) a.partial[((((size_t)tile * a.nheads + hi) * 4 + quarter) * 16 + m) * 8 + c] = sum;
+        if (part == 0) a.partial[(((((size_t)tile * a.nheads + hi) * 2 + pass) * 4 + quarter) * 16 + m) * 8 + c] = sum;
+    }
     }
     // ---- last workgroup of the winner tile: sum the quarters, finish the heads, assemble the rows ----
     __threadfence();
@@ -906,13 +915,21 @@ __global__ __launch_bounds__(256) void sparse_heads_kernel(SparseArgs a)
         const int h2 = i >> 7, m = (i >> 3) & 15, c = i & 7;
         const int hd2 = a.head[h2];
         if (c >= HCH[hd2]) continue;
-        const float *pp = a.partial + (((size_t)tile * a.nheads + h2) * 4 * 16 + m) * 8 + c;
-        float v = __builtin_nontemporal_load(pp);
-        v += __builtin_nontemporal_load(pp + 128);
-        v += __builtin_nontemporal_load(pp + 256);
-        v += __builtin_nontemporal_load(pp + 384);
-        v += a.b2[h2][c];
-        if (hd2 == CT_HEAD_DEP) v = (1.0f / (1.0f / (1.0f + expf(-v)) + 1e-6f) - 1.0f) * a.depth_scale;
+        auto value = [&](int pass) {
+            const float *pp = a.partial + ((((size_t)tile * a.nheads + h2) * 2 + pass) * 4 * 16 + m) * 8 + c;
+            float v = __builtin_nontemporal_load(pp);
+            v += __builtin_nontemporal_load(pp + 128);
+            v += __builtin_nontemporal_load(pp + 256);
+            v += __builtin_nontemporal_load(pp + 384);
+            v += a.b2[h2][c];
+            if (hd2 == CT_HEAD_DEP) v = (1.0f / (1.0f / (1.0f + expf(-v)) + 1e-6f) - 1.0f) * a.depth_scale;
+            return v;
+        };
+        float v = value(0);
+        if (a.flip_B > 0 && a.flip_mode[h2] != 0) {
+            const float v1 = value(1);
+            v = (v + ((a.flip_mode[h2] == 2 && !(c & 1)) ? -v1 : v1)) / 2;     // (a + s * b) / 2 like ct_flip_merge / torch
+        }
         if (hd2 == CT_HEAD_TRACKING && a.zero_tracking) v = 0.0f;
         V[m][hd2 * 8 + c] = v;
     }
@@ -994,7 +1011,7 @@ static size_t sparse_bytes(const ct_decode_desc *d)
 {
     if (!d->sparse) return 0;
     const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
-    return (size_t)d->B * d->K * 8 + ((tiles * 4 + 7) & ~(size_t)7) + tiles * (size_t)d->sparse->nheads * 4 * 16 * 8 * sizeof(float);
+    return (size_t)d->B * d->K * 8 + ((tiles * 4 + 7) & ~(size_t)7) + tiles * (size_t)d->sparse->nheads * 2 * 4 * 16 * 8 * sizeof(float);
 }
 
 extern "C" size_t ct_decode_workspace_bytes(const ct_decode_desc *d)
@@ -1086,6 +1103,9 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
             sa.w2[i] = on ? sp->w2[i] : nullptr; sa.b2[i] = on ? sp->b2[i] : nullptr;
         }
         sa.depth_scale = sp->depth_scale; sa.zero_tracking = sp->zero_tracking;
+        sa.flip_B = sp->flip_B;
+        for (int i = 0; i < CT_NUM_HEADS; ++i) sa.flip_mode[i] = (i < sp->nheads) ? sp->flip_mode[i] : 0;
+        if (sp->flip_B < 0 || (sp->flip_B > 0 && sp->flip_B != d->B)) CT_FAIL_ARG("ct_decode: sparse flip_B must be 0 or B (feat then holds 2 * B images)");
         {
             const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
             unsigned char *base = (unsigned char *)(a2.winners + (size_t)d->B * d->K);

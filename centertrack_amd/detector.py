@@ -158,9 +158,9 @@ class StreamDetector(object):
         self.flip = bool(getattr(opt, 'flip_test', False))
         # opt.sparse_heads (round 5, opt-in, NOT a reference flag): the regression heads are evaluated at the K winners of
         # the decode only instead of as dense maps (ct_sparse_heads_desc) -- same results (the decode reads nothing else of
-        # them, decode.py:99-180), 1/5 of the heads' work.  Not with flip_test (the merge averages maps) or pose heads.
-        self.sparse = (bool(getattr(opt, 'sparse_heads', False)) and not self.flip
-                       and not ({'hps', 'hm_hp'} & set(opt.heads)))
+        # them, decode.py:99-180), 1/5 of the heads' work.  flip_test: hm is merged as a map, the averaged regression heads are
+        # evaluated in both images at the winner and its mirrored pixel.  Not with pose heads (hm_hp is a heat-map).
+        self.sparse = bool(getattr(opt, 'sparse_heads', False)) and not ({'hps', 'hm_hp'} & set(opt.heads))
         self.use_graph = use_graph
         self.trackers = [Tracker(opt) for _ in range(self.B)]
         # native host path (C++ post-process + association incl. the Hungarian / public-detection / pre_dets branches
@@ -243,7 +243,7 @@ class StreamDetector(object):
         ctx['done_flag'] = torch.zeros((16,), dtype=torch.int32).pin_memory()      # (its own cache line)
         sparse = plan.get('sparse')
         if sparse is not None:
-            sparse = dict(sparse, zero_tracking=bool(getattr(opt, 'zero_tracking', False)))
+            sparse = dict(sparse, zero_tracking=bool(getattr(opt, 'zero_tracking', False)), flip=self.flip)
         F = ops.Decoder.row_floats(dec_heads, [n for n, *_ in sparse['heads']] if sparse else None)
         ctx['host_out'] = torch.zeros((merged['hm'].shape[0], opt.K, F), dtype=torch.float32).pin_memory()
         # (round 3: the decode stores its rows straight into the pinned block and raises the end-of-frame flag itself --

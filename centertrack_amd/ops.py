@@ -286,11 +286,14 @@ class Decoder(object):
             assert 'hps' not in heads and all(n not in heads for n, *_ in sparse['heads'])
             sp = _lib.SparseHeadsDesc()
             feat = sparse['feat']
-            assert feat.C == 64 and (feat.N, feat.H, feat.W) == (B, h, w)
+            flip = bool(sparse.get('flip'))
+            assert feat.C == 64 and (feat.N, feat.H, feat.W) == ((2 * B if flip else B), h, w)
+            sp.flip_B = B if flip else 0
             sp.feat, sp.ldf, sp.nheads = feat.ptr, feat.ld, len(sparse['heads'])
             for i, (name, w1, b1, w2, b2) in enumerate(sparse['heads']):
                 assert tuple(w2.shape) == (_lib.HEAD_CH[name], 256) and w2.is_contiguous() and b1.numel() == 256
                 sp.head[i] = _lib.HEAD_INDEX[name]
+                sp.flip_mode[i] = (1 if name in ('wh', 'dep', 'dim') else 2 if name == 'amodel_offset' else 0) if flip else 0
                 sp.w1[i], sp.b1[i], sp.w2[i], sp.b2[i] = w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr()
             sp.depth_scale = float(sparse.get('depth_scale', 1.0))
             sp.zero_tracking = int(bool(sparse.get('zero_tracking', False)))

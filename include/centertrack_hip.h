@@ -256,6 +256,12 @@ typedef struct ct_sparse_heads_desc {
     const float *w1[CT_NUM_HEADS], *b1[CT_NUM_HEADS], *w2[CT_NUM_HEADS], *b2[CT_NUM_HEADS];
     float depth_scale;
     int zero_tracking;
+    /* flip_test (detector.py:311-332): flip_B = B when feat holds 2 * B images (image B + b = the mirrored frame of stream
+     * b), else 0; flip_mode[i]: 0 = the head is read from image b alone (reg, tracking, ltrb*, rot, ...), 1 = averaged
+     * with the mirrored image's value at the mirrored pixel (wh, dep, dim), 2 = the same with the even (x) channels of the
+     * mirrored value negated (amodel_offset) */
+    int flip_B;
+    int flip_mode[CT_NUM_HEADS];
 } ct_sparse_heads_desc;
 typedef struct ct_decode_desc {
     const float *hm; int B, C, h, w, K;

@@ -87,7 +87,7 @@ def test_ctypes_descriptors_match_the_header_layout(tmp_path):
               'ct_decode_desc': (_lib.DecodeDesc, ['hm', 'heads', 'out', 'hm_batch_stride', 'out_stride', 'host_out', 'done_flag',
                                                    'done_counter', 'sparse']),
               'ct_sparse_heads_desc': (_lib.SparseHeadsDesc, ['feat', 'ldf', 'nheads', 'head', 'w1', 'b1', 'w2', 'b2',
-                                                              'depth_scale', 'zero_tracking']),
+                                                              'depth_scale', 'zero_tracking', 'flip_B', 'flip_mode']),
               'ct_heads_desc': (_lib.HeadsDesc, ['x', 'w0_winograd', 'cout', 'out', 'depth_scale']),
               'ct_frame_loop_desc': (_lib.FrameLoopDesc, ['B', 'trackers', 'layout', 'out_thresh', 'host_rows', 'rows_keep',
                                                           'blob_params', 'blob_cap', 'nslots', 'graphs', 'frames',

@@ -22,8 +22,11 @@ def _pair(name, streams, **kw):
     heads = S.HEAD_SETS[cfg['heads']]
     sd = calibrated_state_dict(name, heads)
     dets = []
+    kw = dict(kw)
+    flip = kw.pop('flip_test', cfg['flip'])
     for sparse in (False, True):
-        opt = default_opt(heads, track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], sparse_heads=sparse, **kw)
+        opt = default_opt(heads, track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], sparse_heads=sparse,
+                          flip_test=flip, **kw)
         model = DLASegHIP(heads)
         model.load_state_dict(sd)
         dets.append(StreamDetector(opt, model=model, num_streams=streams))
@@ -31,8 +34,10 @@ def _pair(name, streams, **kw):
 
 
 @pytest.mark.parametrize('name,streams,kw', [('mot17_512', 1, {}), ('mot17_512', 3, {'zero_tracking': True}),
-                                              ('nusc_800x448', 2, {}), ('coco_512', 2, {}), ('mot17_544x960', 1, {})],
-                         ids=['mot', 'mot_x3_zero_tracking', 'nusc_3d_heads', 'coco_80_classes', 'mot_544x960'])
+                                              ('nusc_800x448', 2, {}), ('coco_512', 2, {}), ('mot17_544x960', 1, {}),
+                                              ('kitti_1280x384', 2, {}), ('nusc_800x448', 1, {'flip_test': True})],
+                         ids=['mot', 'mot_x3_zero_tracking', 'nusc_3d_heads', 'coco_80_classes', 'mot_544x960',
+                              'kitti_flip_test', 'nusc_3d_heads_flip_test'])
 def test_sparse_rows_equal_dense_rows(device, name, streams, kw):
     from _parity import scrolled_stream
     cfg, dense, sparse, meta = _pair(name, streams, **kw)
@@ -60,7 +65,8 @@ def test_sparse_rows_equal_dense_rows(device, name, streams, kw):
 
 
 # (streams picked like the dense full-size tests': no oracle score within 1e-5 of a threshold -- checked on the CPU, min 3.6e-4)
-@pytest.mark.parametrize('name,streams,T,seed0', [('mot17_512', 1, 8, 331), ('nusc_800x448', 2, 3, 324), ('coco_512', 2, 3, 324)])
+@pytest.mark.parametrize('name,streams,T,seed0', [('mot17_512', 1, 8, 331), ('nusc_800x448', 2, 3, 324), ('coco_512', 2, 3, 324),
+                                                   ('kitti_1280x384', 2, 2, 317 + 7)])
 def test_sparse_heads_match_oracle_at_full_size(device, name, streams, T, seed0):
     checks, swaps, det = run_config(name, streams, T, seed0=seed0, sparse_heads=True)
     assert det.sparse
@@ -76,7 +82,7 @@ def test_sparse_heads_are_refused_where_they_do_not_apply(device):
     model = DLASegHIP(heads)
     model.load_state_dict(W.make_synthetic_state_dict(heads, seed=3))
     det = StreamDetector(default_opt(heads, flip_test=True, sparse_heads=True), model=model, num_streams=1)
-    assert not det.sparse                        # flip_test merges MAPS (detector.py:311-332): dense heads
+    assert det.sparse                            # flip_test: hm merged as a map, averaged heads evaluated in both images
     pose = StreamDetector(default_opt(W.POSE_HEADS, sparse_heads=True), model=None if False else DLASegHIP(W.POSE_HEADS),
                           num_streams=1)
     assert not pose.sparse
