@@ -103,7 +103,8 @@ def hip_streams(name, plan, B, runs, T):
     cfg = S.CONFIGS[name]
     heads = S.HEAD_SETS[cfg['heads']]
     H, W = cfg['H'], cfg['W']
-    opt = default_opt(heads, track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'])
+    opt = default_opt(heads, track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'],
+                      sparse_heads=bool(os.environ.get('TIE_REPORT_SPARSE_HEADS')))
     model = DLASegHIP(heads)
     model.load_state_dict(calibrated_state_dict(name, heads))
     det = StreamDetector(opt, model=model, num_streams=B)
@@ -327,14 +328,17 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r04_tie_report.json'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r05_tie_report.json'))
     ap.add_argument('--quick', action='store_true', help='a few frames (plumbing check)')
     ap.add_argument('--mot-runs', type=int, default=0, help='runs of the headline plan (32 frames each); 0 = the PLAN default')
     ap.add_argument('--workers', type=int, default=0)
     ap.add_argument('--dump', default='', help='also pickle the raw per-frame outputs of both sides (offline re-analysis)')
     ap.add_argument('--from-dump', default='', help='recompute the report from a pickle written by --dump (no GPU, no oracle runs)')
     ap.add_argument('--threads', type=int, default=8)
+    ap.add_argument('--sparse-heads', action='store_true', help='the HIP side runs with opt.sparse_heads (round 5, opt-in mode)')
     args = ap.parse_args()
+    if args.sparse_heads:
+        os.environ['TIE_REPORT_SPARSE_HEADS'] = '1'
     plan = QUICK if args.quick else list(PLAN)
     if args.mot_runs > 0 and not args.quick:
         plan[0] = (plan[0][0], plan[0][1], args.mot_runs, plan[0][3])
