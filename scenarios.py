@@ -286,8 +286,23 @@ def e2e_mode_cases():
         # 80 classes (COCO): the class-major top-K over 80 maps, then over 8000 candidates
         dict(name='coco80', heads=W.COCO_HEADS, T=4, task='tracking', calibrated=True,
              ref_args=['--pre_hm', '--track_thresh', '0.3'], opt=dict(track_thresh=0.3)),
+        # the BENCHMARKED size: BASELINE configs[1] = MOT heads at 512 x 512, the calibrated weights of the full-size parity
+        # tests (tests/golden/hm_calibration.json: ~40 detections per frame, scores spread), T = 8
+        dict(name='mot_512_full', heads=W.MOT_HEADS, T=8, task='tracking', ref_args=mot, H=512, W=512, orig_h=1024, orig_w=1024,
+             opt=dict(track_thresh=0.4, pre_thresh=0.5), calibration_of='mot17_512', frames_seed=359),
     ]
     return [dict(base, **c) for c in cases]
+
+
+def e2e_mode_calibration(case, golden_dir):
+    """the hm calibration entry of an e2e mode case (None for the single-class MOT cases at small size)"""
+    import json
+    import os
+    if case.get('calibration_of'):
+        with open(os.path.join(golden_dir, 'hm_calibration.json')) as f:
+            return json.load(f)[case['calibration_of']]
+    with open(os.path.join(golden_dir, 'e2e_modes_calibration.json')) as f:
+        return json.load(f).get(case['name'])
 
 
 def e2e_mode_state_dict(case, calibration=None):
@@ -315,7 +330,7 @@ def e2e_mode_frames(case):
     a regular grid of provided detections every ``public_grid`` image px, in the shape
     tools/convert_mot_det_to_results.py:31-56 stores them"""
     from centertrack_amd.image import make_meta
-    g = torch.Generator().manual_seed(case['seed'] + 7)
+    g = torch.Generator().manual_seed(case.get('frames_seed', case['seed'] + 7))      # (weights: case['seed'])
     T = case['T']
     base = torch.randn((3, case['H'], case['W'] + 4 * T), generator=g, dtype=torch.float64).float()
     meta = make_meta(case['H'], case['W'], case['orig_h'], case['orig_w'], down_ratio=4)

@@ -223,12 +223,21 @@ def gen_e2e_modes():
         assert dict(opt.heads) == dict(case['heads']), (opt.heads, case['heads'])
         if case['calibrated']:
             cal[case['name']] = _calibrate_hm(case, opt)
-        det = _ref_detector(opt, e2e_mode_state_dict(case, cal.get(case['name'])))
+        calibration = cal.get(case['name'])
+        if case.get('calibration_of'):                 # the full-size parity tests' weights (hm_calibration.json)
+            with open(os.path.join(HERE, 'hm_calibration.json')) as f:
+                calibration = json.load(f)[case['calibration_of']]
+        det = _ref_detector(opt, e2e_mode_state_dict(case, calibration))
         frames = []
         for t, (images, meta) in enumerate(e2e_mode_frames(case)):
             ret = det.run(_prefetch_dict(images, meta))
             frames.append([{k: np.asarray(v, np.float64).tolist() for k, v in r.items()} for r in ret['results']])
             sc = [float(r['score']) for r in ret['results'] if int(r['age']) == 1]
+            if case.get('calibration_of'):             # full size: a HAND-PICKED stream like the other full-size tests' --
+                gaps = -np.diff(np.sort(np.array(sc))[::-1])        # no rank tie (< 5e-5) and no threshold tie (< 1e-4)
+                edge = min(abs(s_ - th) for s_ in [float(r['score']) for r in ret['results']] for th in (0.4, 0.5))
+                assert (len(gaps) == 0 or gaps.min() > 5e-5) and edge > 1e-4, ('TEST DATA: %s frame %d: rank gap %.1e / '
+                                                                                'threshold distance %.1e: change the seed' % (case['name'], t, gaps.min(), edge))
             assert len(set(sc)) == len(sc), ('TEST DATA: %s frame %d holds two detections with exactly the same score (the '
                                              'order of exact ties in torch.topk is unspecified): change the seed' % (case['name'], t))
         out[case['name']] = frames

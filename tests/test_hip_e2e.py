@@ -78,8 +78,7 @@ def test_detector_modes_match_reference_golden(device, golden_dir, case):
     from centertrack_amd.detector import Detector, default_opt
     from centertrack_amd.model import DLASegHIP
     g = json.load(open(os.path.join(golden_dir, 'e2e_modes.json')))[case['name']]
-    cal = json.load(open(os.path.join(golden_dir, 'e2e_modes_calibration.json'))).get(case['name'])
-    sd = S.e2e_mode_state_dict(case, cal)
+    sd = S.e2e_mode_state_dict(case, S.e2e_mode_calibration(case, golden_dir))
     opt = default_opt(case['heads'], input_h=case['H'], input_w=case['W'], **case['opt'])
     model = DLASegHIP(case['heads'])
     model.load_state_dict(sd)

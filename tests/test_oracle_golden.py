@@ -125,8 +125,7 @@ def test_e2e_modes_match_reference(golden_dir, case):
     uses -- T = 16, Hungarian, max_age 2, public detections with pre_dets / cur_dets, --flip_test, tracking,ddd with calib,
     80 classes -- against the oracle detector: ids / classes / ages identical, values to 1e-4"""
     g = json.load(open(os.path.join(golden_dir, 'e2e_modes.json')))[case['name']]
-    cal = json.load(open(os.path.join(golden_dir, 'e2e_modes_calibration.json'))).get(case['name'])
-    sd = S.e2e_mode_state_dict(case, cal)
+    sd = S.e2e_mode_state_dict(case, S.e2e_mode_calibration(case, golden_dir))
     opt = odet.default_opt(input_h=case['H'], input_w=case['W'], num_classes=case['heads']['hm'], **case['opt'])
     det = odet.Detector(opt, sd, case['heads'])
     assert len(g) == case['T']
