@@ -86,3 +86,61 @@ def test_sparse_heads_are_refused_where_they_do_not_apply(device):
     pose = StreamDetector(default_opt(W.POSE_HEADS, sparse_heads=True), model=None if False else DLASegHIP(W.POSE_HEADS),
                           num_streams=1)
     assert not pose.sparse
+
+
+@pytest.mark.parametrize('B,h,w,K,names,flip', [(1, 24, 40, 37, ('reg', 'wh', 'tracking'), False),
+                                               (3, 17, 30, 100, ('tracking', 'ltrb_amodal', 'dep', 'rot', 'dim', 'amodel_offset'), False),
+                                               (2, 16, 24, 20, ('reg', 'wh', 'dep', 'dim', 'amodel_offset', 'tracking'), True),
+                                               (1, 32, 32, 100, ('wh', 'ltrb', 'nuscenes_att', 'velocity'), False)],
+                         ids=['odd_K', 'ragged_map_3d_heads_x3', 'flip_test', 'ltrb_att_velocity'])
+def test_ct_decode_sparse_against_torch_convolutions(device, B, h, w, K, names, flip):
+    """ct_decode with ct_sparse_heads_desc at the C-ABI level, on random feature maps and random head weights, against
+    plain torch fp32 convolutions evaluated densely on the CPU and gathered at the winners: ragged maps, K not a
+    multiple of 16, winners on the border (zero padding), 8-channel heads, the dep transform, flip_test averaging with the
+    x channels of amodel_offset negated."""
+    import torch.nn.functional as F
+    from centertrack_amd import _lib, ops
+    g = torch.Generator().manual_seed(11 + K)
+    NB = 2 * B if flip else B
+    feat = torch.randn((NB, 64, h, w), generator=g)
+    hm = torch.rand((B, 2, h, w), generator=g)
+    hm[:, :, 0, :] += 0.5                                    # winners on the top border too
+    hm = hm.clamp(0, 0.999)
+    heads = []
+    dense = {}
+    for n in names:
+        c = _lib.HEAD_CH[n]
+        w1 = torch.randn((256, 64, 3, 3), generator=g) * 0.05
+        b1 = torch.randn((256,), generator=g) * 0.1
+        w2 = torch.randn((c, 256), generator=g) * 0.05
+        b2 = torch.randn((c,), generator=g) * 0.1
+        heads.append((n, w1, b1, w2, b2))
+        v = F.conv2d(F.relu(F.conv2d(feat, w1, b1, padding=1)), w2.view(c, 256, 1, 1), b2)
+        if n == 'dep':
+            v = (1.0 / (torch.sigmoid(v) + 1e-6) - 1.0) * 2.0
+        if flip:
+            a, bb = v[:B], torch.flip(v[B:], [3])
+            if n in ('wh', 'dep', 'dim'):
+                v = (a + bb) / 2
+            elif n == 'amodel_offset':
+                bb = bb.clone()
+                bb[:, 0::2] *= -1
+                v = (a + bb) / 2
+            else:
+                v = a
+        dense[n] = v.contiguous()
+    fv = ops.view_from_nchw(feat.to(device))
+    sparse = {'feat': fv, 'flip': flip, 'depth_scale': 2.0,
+              'heads': [(n, ops.pack_weight(w1.to(device)), b1.to(device), w2.to(device).contiguous(), b2.to(device))
+                        for n, w1, b1, w2, b2 in heads]}
+    dec = ops.Decoder(hm.to(device), {}, K, sparse=sparse)
+    got = dec.unpack(dec.run().cpu().numpy())
+    ref = ops.Decoder(hm.to(device), {n: v.to(device) for n, v in dense.items()}, K)
+    want = ref.unpack(ref.run().cpu().numpy())
+    assert sorted(got) == sorted(want)
+    for k in want:
+        if k in ('scores', 'clses', 'xs', 'ys', 'cts'):
+            np.testing.assert_array_equal(got[k], want[k], err_msg=k)
+        else:
+            np.testing.assert_allclose(got[k], want[k], rtol=2e-4, atol=2e-4 * max(1.0, float(np.abs(want[k]).max())), err_msg=k)
+    assert (want['ys'] == 0).any()                            # border winners were part of it
