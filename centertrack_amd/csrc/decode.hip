@@ -784,7 +784,7 @@ struct SparseArgs {
     int flip_mode[CT_NUM_HEADS];     // per sparse head: 0 = image b alone, 1 = (v + v') / 2, 2 = the same with even channels of v' negated
     const unsigned long long *winners;
     float *partial;                  // [B * tiles][nheads][2 passes][4][16][8] partial head outputs (one hidden quarter each)
-    unsigned *arrive;                // [B * tiles] arrival counters, zero between launches
+    unsigned *arrive;                // (reserved: the arrival counters of the first form)
     float *out, *host_out;
     int *done_flag; unsigned *done_counter;
     int B, h, w, K, F, tiles;        // tiles = ceil(K / 16) winner tiles per image
@@ -795,17 +795,13 @@ struct SparseArgs {
 // hidden channels 64 * quarter + 16 * w ...  First version (one workgroup per winner tile, all heads, 16 waves): 68 us at
 // one stream -- seven workgroups each pulling all 2.4 MB of head weights through one CU's L1 (rocprofv3,
 // gpurun_out/r05_e); spread over tiles x heads x quarters every workgroup streams 147 KB, issued in full BEFORE the
-// winners are even read.  The partial 1x1 outputs of the four quarters meet in a scratch block; the last workgroup of
-// a winner tile to arrive (agent-scope counter) sums them in quarter order (deterministic), applies bias / transforms
-// and assembles the tile's rows.
+// winners are even read.  The partial 1x1 outputs of the four quarters meet in a scratch block; sparse_rows_kernel (the
+// next launch) sums them in quarter order (deterministic), applies bias / transforms and assembles the rows.
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sparse_heads_kernel(SparseArgs a)
 {
     __shared__ __attribute__((aligned(16))) float A[36 * 256];            // [tap * 4 + slab][16 winners][16 ch], swizzled
     __shared__ __attribute__((aligned(16))) float Hd[16 * 68];            // this quarter's 64 hidden activations per winner
-    __shared__ float V[16][CT_NUM_HEADS * 8];                             // (last workgroup) head outputs of the 16 winners
-    __shared__ int wy[16], wx[16], wcls[16];
-    __shared__ float wscore[16];
-    __shared__ unsigned last_flag;
+    __shared__ int wy[16], wx[16];
     constexpr int HCH[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -826,17 +822,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     const float bias1 = a.b1[hi][quarter * 64 + wave * 16 + li];
     if (tid < 16) {
         const int r = t * 16 + tid;
-        int y = -4, x = -4, cls = 0;
-        float sc = 0.f;
+        int y = -4, x = -4;
         if (r < a.K) {
             const unsigned long long k = a.winners[(size_t)b * a.K + r];
             const unsigned flat = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
-            cls = (int)(flat / (unsigned)HW);
-            const int p = (int)(flat - (unsigned)cls * (unsigned)HW);
+            const int p = (int)(flat % (unsigned)HW);
             y = p / a.w; x = p - y * a.w;
-            sc = ord2f((unsigned)(k >> 32));
         }
-        wy[tid] = y; wx[tid] = x; wcls[tid] = cls; wscore[tid] = sc;
+        wy[tid] = y; wx[tid] = x;
     }
     __syncthreads();
     // flip_test (detector.py:311-332): wh / dep / dim / amodel_offset are averaged with the MIRRORED image's value at the
@@ -897,53 +890,63 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
         if (part == 0) a.partial[(((((size_t)tile * a.nheads + hi) * 2 + pass) * 4 + quarter) * 16 + m) * 8 + c] = sum;
     }
     }
-    // ---- last workgroup of the winner tile: sum the quarters, finish the heads, assemble the rows ----
-    __threadfence();
-    __syncthreads();
-    if (tid == 0) {
-        const unsigned total = (unsigned)a.nheads * 4u;
-        const unsigned prev = __hip_atomic_fetch_add(a.arrive + tile, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
-        last_flag = (prev == total - 1u) ? 1u : 0u;
-        if (prev == total - 1u) a.arrive[tile] = 0u;             // (ready for the next launch)
-    }
-    __syncthreads();
-    if (!last_flag) return;
-    __threadfence();
-    for (int i = tid; i < 16 * CT_NUM_HEADS * 8; i += 256) (&V[0][0])[i] = 0.f;
-    __syncthreads();
-    for (int i = tid; i < a.nheads * 128; i += 256) {
-        const int h2 = i >> 7, m = (i >> 3) & 15, c = i & 7;
-        const int hd2 = a.head[h2];
-        if (c >= HCH[hd2]) continue;
-        auto value = [&](int pass) {
-            const float *pp = a.partial + ((((size_t)tile * a.nheads + h2) * 2 + pass) * 4 * 16 + m) * 8 + c;
-            float v = __builtin_nontemporal_load(pp);
-            v += __builtin_nontemporal_load(pp + 128);
-            v += __builtin_nontemporal_load(pp + 256);
-            v += __builtin_nontemporal_load(pp + 384);
-            v += a.b2[h2][c];
-            if (hd2 == CT_HEAD_DEP) v = (1.0f / (1.0f / (1.0f + expf(-v)) + 1e-6f) - 1.0f) * a.depth_scale;
-            return v;
-        };
-        float v = value(0);
-        if (a.flip_B > 0 && a.flip_mode[h2] != 0) {
-            const float v1 = value(1);
-            v = (v + ((a.flip_mode[h2] == 2 && !(c & 1)) ? -v1 : v1)) / 2;     // (a + s * b) / 2 like ct_flip_merge / torch
+}
+
+// The partial head outputs of sparse_heads_kernel -> packed rows: one workgroup per image, one lane per winner.  (Round 5's
+// first form let the LAST workgroup of every winner tile do this behind an agent-scope arrival counter: at 32 streams the
+// 1 792 release / acquire fences -- an L2 write-back and invalidate each -- evicted the head weights under every other
+// workgroup: 536 us per launch.  A kernel boundary is the cheaper way to make the partials visible.)
+__global__ __launch_bounds__(128) void sparse_rows_kernel(SparseArgs a)
+{
+    constexpr int HCH[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
+    const int b = blockIdx.x;
+    const int HW = a.h * a.w;
+    for (int r = threadIdx.x; r < a.K; r += blockDim.x) {
+        const unsigned long long k = a.winners[(size_t)b * a.K + r];
+        const unsigned flat = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+        const int cls = (int)(flat / (unsigned)HW);
+        const int p = (int)(flat - (unsigned)cls * (unsigned)HW);
+        const int y = p / a.w, x = p - y * a.w;
+        const float score = ord2f((unsigned)(k >> 32));
+        const int tile = b * a.tiles + (r >> 4), m = r & 15;
+        float V[CT_NUM_HEADS][8];
+#pragma unroll
+        for (int hd = 0; hd < CT_NUM_HEADS; ++hd)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) V[hd][c] = 0.f;
+        for (int h2 = 0; h2 < a.nheads; ++h2) {
+            const int hd2 = a.head[h2];
+            const bool both = a.flip_B > 0 && a.flip_mode[h2] != 0;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c >= HCH[hd2]) continue;
+                auto value = [&](int pass) {
+                    const float *pp = a.partial + ((((size_t)tile * a.nheads + h2) * 2 + pass) * 4 * 16 + m) * 8 + c;
+                    float v = pp[0];                       // quarters summed in order: deterministic
+                    v += pp[128];
+                    v += pp[256];
+                    v += pp[384];
+                    v += a.b2[h2][c];
+                    if (hd2 == CT_HEAD_DEP) v = (1.0f / (1.0f / (1.0f + expf(-v)) + 1e-6f) - 1.0f) * a.depth_scale;
+                    return v;
+                };
+                float v = value(0);
+                if (both) {
+                    const float v1 = value(1);
+                    v = (v + ((a.flip_mode[h2] == 2 && !(c & 1)) ? -v1 : v1)) / 2;     // (a + s * b) / 2 like ct_flip_merge / torch
+                }
+                if (hd2 == CT_HEAD_TRACKING && a.zero_tracking) v = 0.0f;
+                // (hd2 is uniform but not a compile-time constant: a switch keeps V in registers)
+#pragma unroll
+                for (int hd = 0; hd < CT_NUM_HEADS; ++hd)
+                    if (hd == hd2) V[hd][c] = v;
+            }
         }
-        if (hd2 == CT_HEAD_TRACKING && a.zero_tracking) v = 0.0f;
-        V[m][hd2 * 8 + c] = v;
+        float *row = a.out + ((size_t)b * a.K + r) * a.F;
+        float *hrow = a.host_out ? a.host_out + ((size_t)b * a.K + r) * a.F : nullptr;
+        emit_row(row, hrow, a.present, score, cls, (float)x, (float)y, [&](int hd3, int ch) { return V[hd3][ch]; });
     }
-    __syncthreads();
-    if (tid < 16) {
-        const int r = t * 16 + tid;
-        if (r < a.K) {
-            float *row = a.out + ((size_t)b * a.K + r) * a.F;
-            float *hrow = a.host_out ? a.host_out + ((size_t)b * a.K + r) * a.F : nullptr;
-            emit_row(row, hrow, a.present, wscore[tid], wcls[tid], (float)wx[tid], (float)wy[tid],
-                     [&](int hd3, int ch) { return V[tid][hd3 * 8 + ch]; });
-        }
-    }
-    if (a.done_flag) raise_done_flag(a.done_flag, a.done_counter, a.B * a.tiles);
+    if (a.done_flag) raise_done_flag(a.done_flag, a.done_counter, a.B);
 }
 
 const int kHeadCh[CT_NUM_HEADS] = {2, 2, 2, 4, 4, 1, 8, 3, 2, 8, 3};
@@ -1118,6 +1121,8 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
         sa.present = a2.present;
         hipLaunchKernelGGL(sparse_heads_kernel, dim3((unsigned)(d->B * sa.tiles * sp->nheads * 4)), dim3(256), 0, s, sa);
         CT_CHECK_LAUNCH("ct_decode(sparse heads)");
+        hipLaunchKernelGGL(sparse_rows_kernel, dim3((unsigned)d->B), dim3(128), 0, s, sa);
+        CT_CHECK_LAUNCH("ct_decode(sparse rows)");
     }
     return CT_OK;
 }

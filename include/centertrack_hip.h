@@ -247,8 +247,8 @@ enum { CT_HEAD_REG = 0, CT_HEAD_WH, CT_HEAD_TRACKING, CT_HEAD_LTRB, CT_HEAD_LTRB
  * (dla.py:631-640), image 0, channel pitch ldf (16-byte aligned, >= 64), images h * w * ldf floats apart.  Per head:
  * head[i] = CT_HEAD_* id; w1 = conv3x3 64 -> 256 weights in ct_pack_conv_weight layout, b1 [256]; w2 = conv1x1 weights
  * [c][256] row-major, b2 [c].  The dep head gets the dense epilogue's transform (1 / (sigmoid(v) + 1e-6) - 1) *
- * depth_scale (detector.py:305-307); zero_tracking != 0 zeroes the tracking output (decode.py:95-96).  With sparse heads
- * ct_decode's workspace must be ZERO before the first call (it holds arrival counters that every launch leaves at zero). */
+ * depth_scale (detector.py:305-307); zero_tracking != 0 zeroes the tracking output (decode.py:95-96).  Two launches behind
+ * the selection: the heads' partial products at the winners, then the rows (+ host copy + end-of-frame flag). */
 typedef struct ct_sparse_heads_desc {
     const float *feat; int ldf;
     int nheads;
