@@ -72,10 +72,13 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 // pixel over the 8 blocks; the partial sums of the 4 channel quads (lanes) and the 2 n-tiles (waves) are added in a
 // fixed order, then bias, sigmoid / depth transform (detector.py:300-308) and ONE NCHW store per output value.  The
 // 256-channel intermediate (84 MB per frame at 512x512 with 5 heads) is neither written nor read back.
+#ifndef CT_NB_WAVES
+#define CT_NB_WAVES 3       // waves per SIMD the NB > 1 shapes (fused heads) are compiled for (variant builds: 4 = 128 VGPRs)
+#endif
 template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
 // (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
 __global__ __launch_bounds__(256 * KS)
-__attribute__((amdgpu_waves_per_eu(NB > 1 ? 3 : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
+__attribute__((amdgpu_waves_per_eu(NB > 1 ? CT_NB_WAVES : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
 void wino_conv_kernel(WinoArgs a)
 {
     static_assert(NB == 1 || (!MULTI && KS == 1), "NB > 1 is a single-chunk, unsplit shape");
