@@ -39,6 +39,14 @@ def decode_cases():
              B=1, h=24, w=32, K=60, seed=7, hps_std=1.0),
         dict(name='pose_amodal_24x32', heads=OrderedDict(list(W.POSE_HEADS.items()) + [('ltrb_amodal', 4)]),
              B=1, h=24, w=32, K=60, seed=8),
+        # round 5: the output grids of the BENCHMARKED configurations (BASELINE configs 3-5 and the reference's own MOT size):
+        # 80 classes x 16 384 pixels (the multi-slice selection), 112 x 200 with the 3D heads, the wide 96 x 320 KITTI grid,
+        # the ragged 136 x 240 grid of 544 x 960 (seeds picked so that no two of an image's K winners score exactly the same:
+        # torch.topk's order among exact ties is unspecified, the generator refuses such data)
+        dict(name='coco_128x128', distinct_hm=True, heads=W.COCO_HEADS, B=2, h=128, w=128, K=100, seed=9),
+        dict(name='nusc_112x200', distinct_hm=True, heads=W.NUSC_HEADS, B=2, h=112, w=200, K=100, seed=10),
+        dict(name='kitti_96x320', distinct_hm=True, heads=W.KITTI_HEADS, B=2, h=96, w=320, K=100, seed=11),
+        dict(name='mot_136x240', distinct_hm=True, heads=W.MOT_HEADS, B=1, h=136, w=240, K=100, seed=12),
     ]
 
 
@@ -50,7 +58,12 @@ def make_head_maps(case):
     out = OrderedDict()
     for name, c in case['heads'].items():
         if name in ('hm', 'hm_hp'):
-            v = torch.rand((B, c, h, w), generator=g, dtype=torch.float64)
+            if case.get('distinct_hm'):
+                # millions of U(0,1) draws rounded to fp32 collide among the top K; ranks of a random permutation do not
+                n = B * c * h * w
+                v = ((torch.randperm(n, generator=g).double() + 0.5) / n).view(B, c, h, w)
+            else:
+                v = torch.rand((B, c, h, w), generator=g, dtype=torch.float64)
             out[name] = (v ** 2 * 0.98 + 0.001).float()
         elif name in ('reg', 'hp_offset'):
             out[name] = torch.rand((B, c, h, w), generator=g, dtype=torch.float64).float()

@@ -81,6 +81,9 @@ def gen_decode():
         inp = {k: v.clone() for k, v in maps.items()}
         with torch.no_grad():
             ret = generic_decode(inp, K=case['K'], opt=opt)
+        for b in range(case['B']):
+            sc = ret['scores'][b].numpy()
+            assert len(set(sc.tolist())) == len(sc), 'TEST DATA: %s image %d: two winners with exactly the same score' % (case['name'], b)
         for k, v in ret.items():
             out['%s.%s' % (case['name'], k)] = v.numpy()
     np.savez_compressed(os.path.join(HERE, 'decode.npz'), **out)
