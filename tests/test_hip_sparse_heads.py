@@ -73,6 +73,18 @@ def test_sparse_heads_match_oracle_at_full_size(device, name, streams, T, seed0)
     assert sum(c.frames for c in checks) == T * streams
 
 
+@pytest.mark.parametrize('name,streams,sample,T', [('mot17_512', 16, (0, 8, 15), 3), ('nusc_800x448', 8, (0, 7), 3),
+                                                    ('kitti_1280x384', 4, (0, 3), 2)])
+def test_sparse_heads_on_the_benchmarked_many_stream_plans(device, name, streams, sample, T):
+    """the many-stream launch plans (other conv tiles, Winograd raw-sum offset convs; tests/test_hip_plans.py) with sparse
+    heads against the oracle: streams nobody picked, so a stream that meets a threshold tie is compared up to that frame"""
+    from _parity import RANK_TIE_UNPICKED
+    checks, swaps, det = run_config(name, streams, T, sample=sample, on_threshold_tie='stop', min_tracks=5,
+                                    rank_tie=RANK_TIE_UNPICKED, sparse_heads=True)
+    assert det.sparse
+    assert sum(c.frames for c in checks) >= (2 * T * len(sample) + 2) // 3
+
+
 def test_sparse_heads_are_refused_where_they_do_not_apply(device):
     import scenarios as S
     from centertrack_amd import weights as W
