@@ -103,8 +103,9 @@ def test_sparse_heads_are_refused_where_they_do_not_apply(device):
 @pytest.mark.parametrize('B,h,w,K,names,flip', [(1, 24, 40, 37, ('reg', 'wh', 'tracking'), False),
                                                (3, 17, 30, 100, ('tracking', 'ltrb_amodal', 'dep', 'rot', 'dim', 'amodel_offset'), False),
                                                (2, 16, 24, 20, ('reg', 'wh', 'dep', 'dim', 'amodel_offset', 'tracking'), True),
-                                               (1, 32, 32, 100, ('wh', 'ltrb', 'nuscenes_att', 'velocity'), False)],
-                         ids=['odd_K', 'ragged_map_3d_heads_x3', 'flip_test', 'ltrb_att_velocity'])
+                                               (1, 32, 32, 100, ('wh', 'ltrb', 'nuscenes_att', 'velocity'), False),
+                                               (2, 40, 40, 300, ('reg', 'wh', 'tracking'), False)],
+                         ids=['odd_K', 'ragged_map_3d_heads_x3', 'flip_test', 'ltrb_att_velocity', 'K_300'])
 def test_ct_decode_sparse_against_torch_convolutions(device, B, h, w, K, names, flip):
     """ct_decode with ct_sparse_heads_desc at the C-ABI level, on random feature maps and random head weights, against
     plain torch fp32 convolutions evaluated densely on the CPU and gathered at the winners: ragged maps, K not a
