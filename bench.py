@@ -57,7 +57,7 @@ PEAK_HBM_GBS = 8000.0
 SWEEP_FRAMES = 5             # timed frames per thread count of the cpu_baseline sweep
 
 
-def parse():
+def build_parser():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=20)
@@ -85,7 +85,11 @@ def parse():
                     help='opt.sparse_heads: regression heads evaluated at the K decode winners only (opt-in product mode, '
                          'never the headline: the reference computes dense maps)')
     ap.add_argument('--no-box-probes', action='store_true', help='box_calibration without the latency / clock probes')
-    return ap.parse_args()
+    return ap
+
+
+def parse():
+    return build_parser().parse_args()
 
 
 def kernel_pass(model, plan, reps=10):

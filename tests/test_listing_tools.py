@@ -66,3 +66,31 @@ def test_rounds_residency_by_registers_lds_and_workgroup_size():
     assert rounds.per_cu(52, 0, 81920, 256)[0] == 2           # LDS-bound
     assert rounds.per_cu(164, 0, 0, 512)[0] == 1              # 8-wave workgroups at 3 waves per SIMD: one fits
     assert rounds.per_cu(96, 0, 0, 1024)[0] == 1              # 16-wave workgroups: 5 waves per SIMD, 4 needed per workgroup
+
+
+def test_bench_flags_used_by_the_collection_scripts_exist():
+    """tools/collect_profiles.sh / sweep_configs.sh / calls/*.sh drive bench.py with flags; a renamed flag would only show
+    on the GPU box, minutes into a paid call.  Every `--flag` those scripts pass must parse, and the configurations the
+    default line appends must exist."""
+    import glob
+    import importlib
+    import re
+    import sys
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), '..'))
+    sys.path.insert(0, root)
+    bench = importlib.import_module('bench')
+    import scenarios as S
+    assert all(name in S.CONFIGS and streams >= 1 for name, streams in bench.EXTRA_CONFIGS)
+    flags = set()
+    for path in glob.glob(os.path.join(root, 'tools', '*.sh')) + glob.glob(os.path.join(root, 'tools', 'calls', '*.sh')):
+        text = open(path).read()
+        uses_b = re.search(r'^\s*B="python (\$R/)?bench\.py', text, re.M) is not None
+        for line in text.splitlines():
+            direct = re.search(r'(?<![a-z])bench\.py', line) is not None
+            via_b = uses_b and re.match(r'\s*(CENTERTRACK_\w+=\S+ )*\$B ', line) is not None
+            if direct or via_b:
+                flags.update(re.findall(r'(--[a-z][a-z0-9-]+)', line))
+    flags -= {'--kernel-trace', '--stats', '--pmc', '--output-format', '--timeout'}
+    known = {a.option_strings[0] for a in bench.build_parser()._actions if a.option_strings}
+    missing = sorted(f for f in flags if f not in known)
+    assert not missing, 'bench.py does not know %s' % missing
