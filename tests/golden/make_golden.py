@@ -276,6 +276,34 @@ def gen_model_full():
           {k: v.shape for k, v in out.items()})
 
 
+def gen_opts():
+    """the reference's own parsed option namespaces (opts().parse + update_dataset_info_and_set_heads, opts.py) for the
+    experiments' command lines, as plain JSON: the GPU tests build the drop-in Detector from THESE (every attribute name the
+    reference defines, none the drop-in invents) on a box where the reference does not exist"""
+    out = {}
+    for name, task, classes, args in (
+            ('mot', 'tracking', 1, ['--pre_hm', '--ltrb_amodal', '--track_thresh', '0.4', '--pre_thresh', '0.5',
+                                    '--input_h', '128', '--input_w', '160']),            # experiments/mot17_half.sh:5 (small input)
+            ('kitti_flip', 'tracking', 3, ['--pre_hm', '--track_thresh', '0.4', '--flip_test', '--input_h', '128', '--input_w', '160']),
+            ('nusc_ddd', 'tracking,ddd', 10, ['--pre_hm', '--track_thresh', '0.1', '--input_h', '128', '--input_w', '224']),
+            ('mot_hungarian_public', 'tracking', 1, ['--pre_hm', '--ltrb_amodal', '--track_thresh', '0.4', '--pre_thresh', '0.5',
+                                                     '--hungarian', '--public_det', '--load_results', 'x', '--max_age', '2',
+                                                     '--input_h', '128', '--input_w', '160'])):
+        o = ref_opt(args, classes, task)
+        d = {}
+        for k, v in sorted(vars(o).items()):
+            if isinstance(v, (bool, int, float, str)) or v is None:
+                d[k] = v
+            elif isinstance(v, (list, tuple)) and all(isinstance(x, (bool, int, float, str)) for x in v):
+                d[k] = list(v)
+            elif isinstance(v, dict):
+                d[k] = {kk: (list(vv) if isinstance(vv, (list, tuple)) else vv) for kk, vv in v.items()}
+        out[name] = d
+    with open(os.path.join(HERE, 'ref_opts.json'), 'w') as f:
+        json.dump(out, f, indent=0)              # (no sort_keys: opt.heads keeps the reference's insertion order)
+    print('ref_opts.json', {k: len(v) for k, v in out.items()})
+
+
 def gen_pre_hm():
     """reference Detector._get_additional_inputs + meta transforms"""
     import detector as ref_detector
@@ -342,7 +370,7 @@ def gen_writers():
 
 
 if __name__ == '__main__':
-    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers', 'poseflip', 'e2emodes', 'modelfull']
+    which = sys.argv[1:] or ['model', 'decode', 'post', 'tracker', 'prehm', 'e2e', 'writers', 'poseflip', 'e2emodes', 'modelfull', 'opts']
     if 'model' in which:
         gen_model()
     if 'decode' in which:
@@ -363,3 +391,5 @@ if __name__ == '__main__':
         gen_e2e_modes()
     if 'modelfull' in which:
         gen_model_full()
+    if 'opts' in which:
+        gen_opts()

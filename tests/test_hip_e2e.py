@@ -565,3 +565,29 @@ def test_native_loop_with_helper_threads_equals_python_loop(device, monkeypatch)
             assert len(x) == len(y) and len(x) > 0
             for f in ('tracking_id', 'score', 'bbox', 'ct', 'class', 'age', 'active', 'row'):
                 np.testing.assert_array_equal(x[f], y[f])
+
+
+@pytest.mark.parametrize('name,case_name', [('mot', 'mot_t16'), ('kitti_flip', 'kitti_flip'), ('nusc_ddd', 'nusc_ddd')])
+def test_detector_built_from_the_references_own_opt_namespace(device, golden_dir, name, case_name):
+    """``Detector(opt)`` with ``opt`` = the namespace the REFERENCE's parser produces for the experiment's command line
+    (tests/golden/ref_opts.json: ``opts().parse(...)`` + ``update_dataset_info_and_set_heads``, every one of its 150
+    attributes under the reference's own name, none added) -- what demo.py / test.py hand over -- reproduces the reference's
+    results of that mode (tests/golden/e2e_modes.json)."""
+    import types
+    from collections import OrderedDict
+    import scenarios as S
+    from centertrack_amd.detector import Detector
+    from centertrack_amd.model import DLASegHIP
+    ref = json.load(open(os.path.join(golden_dir, 'ref_opts.json')))[name]
+    opt = types.SimpleNamespace(**ref)
+    opt.heads = OrderedDict(ref['heads'])
+    case = [c for c in S.e2e_mode_cases() if c['name'] == case_name][0]
+    assert dict(opt.heads) == dict(case['heads']) and (opt.input_h, opt.input_w) == (case['H'], case['W'])
+    model = DLASegHIP(opt.heads)
+    model.load_state_dict(S.e2e_mode_state_dict(case, S.e2e_mode_calibration(case, golden_dir)))
+    det = Detector(opt, model=model)
+    g = json.load(open(os.path.join(golden_dir, 'e2e_modes.json')))[case_name]
+    for t, (images, meta) in enumerate(S.e2e_mode_frames(case)):
+        if t >= 4:
+            break
+        _check_frame(det.run(images, dict(meta))['results'], g[t], t, name)

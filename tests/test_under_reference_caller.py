@@ -37,3 +37,23 @@ def test_multi_scale_is_refused_not_truncated():
     d._init_host(types.SimpleNamespace(test_scales=[1.0]))
     with pytest.raises(_lib.CTError, match='one test scale'):
         d._init_host(types.SimpleNamespace(test_scales=[1.0, 1.5]))
+
+
+def test_every_option_the_dropin_reads_is_one_the_reference_defines(golden_dir=os.path.join(HERE, 'golden')):
+    """static drop-in check: every ``opt.<name>`` / ``getattr(opt, '<name>', ...)`` in the detector, model and tracker
+    modules is an attribute of the namespace the REFERENCE's parser produces (tests/golden/ref_opts.json, 150 attributes),
+    except the handful this package adds on purpose -- and those must all be optional (read through getattr with a default)"""
+    import re
+    with open(os.path.join(golden_dir, 'ref_opts.json')) as f:
+        ref = json.load(f)
+    names = set.intersection(*[set(v) for v in ref.values()])
+    ours_optional = {'device', 'sparse_heads', 'device_pre_process', 'flip_idx'}
+    pkg = os.path.join(HERE, '..', 'centertrack_amd')
+    plain, optional = set(), set()
+    for fn in ('detector.py', 'model.py', 'tracker.py', 'post_process.py', 'decode.py'):
+        src = open(os.path.join(pkg, fn)).read()
+        plain |= set(re.findall(r'\bopt\.([a-zA-Z_][a-zA-Z0-9_]*)', src))
+        optional |= set(re.findall(r"getattr\((?:self\.)?opt, '([a-zA-Z_][a-zA-Z0-9_]*)'", src))
+    unknown = sorted((plain | optional) - names - ours_optional)
+    assert not unknown, 'options the reference does not define: %s' % unknown
+    assert not ((plain - optional) & ours_optional - {'device'}), 'package-specific options must be optional'
