@@ -252,10 +252,17 @@ def sysfs():
         if t is not None:
             out[k] = t
     for h in glob.glob(os.path.join(d, 'hwmon', 'hwmon*')):
-        for k in ('power1_cap', 'power1_average', 'power1_input', 'freq1_input', 'freq2_input', 'temp1_input'):
+        for k in ('power1_cap', 'power1_average', 'power1_input', 'freq1_input', 'freq2_input'):
             t = _read(os.path.join(h, k), 40)
             if t is not None:
                 out[k] = t
+        # every temperature sensor the card exposes (edge / junction / memory ...), milli-degrees C: a memory stack that
+        # runs hot refreshes more often -- a candidate for the slow state that the clocks would not show
+        for tp in sorted(glob.glob(os.path.join(h, 'temp*_input'))):
+            label = _read(tp.replace('_input', '_label'), 20) or os.path.basename(tp)[:-6]
+            t = _read(tp, 20)
+            if t is not None:
+                out['temp_' + label] = t
     return out
 
 
