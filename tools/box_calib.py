@@ -2,7 +2,8 @@
 """What box did a measurement run on?  ``python tools/box_calib.py`` prints one JSON line; ``bench.py`` embeds the same
 dict as ``box_calibration``.  The MI355X boxes of the pool run the one-stream frame 16 % apart while their fp32 MFMA
 loops agree to 0.3 %; rounds 3/4 recorded only the MFMA rate and the device-to-device copy bandwidth, which did not
-predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for:
+predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for (none of
+them separated the two states over 27 calls -- DESIGN.md section 4 -- they stay in the line as the record):
 
   chase_ns       dependent-load latency of ONE lane through a random ring of 128-byte lines (ct_calib_chase): 16 KB
                  (the CU's L1), 1 MB (one XCD's L2), 64 MB (Infinity Cache), 2 GiB (HBM) and 1 MB of PINNED HOST memory
@@ -267,8 +268,9 @@ def sysfs():
 
 
 def node():
-    """the HOST side of the box: 19 probe calls of round 5 alternated between a fast and a slow state with identical PCI
-    addresses in both (profiles/r05_a_box_probes.jsonl) -- whole nodes differ, not cards.  What the node says about itself:
+    """the HOST side of the box: the probe calls of round 5 alternated between a fast and a slow state with identical PCI
+    addresses in both (profiles/r05_a_box_probes.jsonl); nothing below separated the states either (both host kernels seen
+    were slow once), it is recorded so that a future difference is on file.  What the node says about itself:
     kernel, CPU, amdgpu driver version and the module parameters that change how the memory system is driven (retry
     faults / XNACK, page-table fragment size, scheduling policy), IOMMU groups, the ISA string HIP reports (xnack+/-)"""
     out = {}
