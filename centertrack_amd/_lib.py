@@ -172,7 +172,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
            'ct_tracker_step_public', 'ct_tracker_step_dets', 'ct_transform_points',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
-           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_calib_chase', 'ct_calib_stream', 'ct_calib_launches', 'ct_calib_cu_map', 'ct_calib_xcd_stream', 'ct_flip_merge', 'ct_flip_images',
+           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_calib_chase', 'ct_calib_chase_many', 'ct_calib_write', 'ct_calib_ifetch', 'ct_calib_stream', 'ct_calib_launches', 'ct_calib_cu_map', 'ct_calib_xcd_stream', 'ct_flip_merge', 'ct_flip_images',
            'ct_frame_loop_create', 'ct_frame_loop_destroy', 'ct_frame_loop_submit', 'ct_frame_loop_wait', 'ct_frame_loop_finish',
            'ct_frame_loop_finish_submit', 'ct_frame_loop_upload', 'ct_frame_loop_pending_slot', 'ct_frame_loop_in_flight',
            'ct_frame_loop_forget_upload', 'ct_frame_loop_prestage', 'ct_stem_forward_parts', 'ct_signal_host']
@@ -271,6 +271,9 @@ def load():
     lib.ct_calib_mfma.argtypes = [i, i, p, p]
     lib.ct_calib_chase.argtypes = [p, i, ctypes.c_uint, p, p]
     lib.ct_calib_stream.argtypes = [p, p, sz, i, i, p]
+    lib.ct_calib_chase_many.argtypes = [p, i, ctypes.c_uint, i, p, p]
+    lib.ct_calib_write.argtypes = [p, sz, i, i, i, p, p]
+    lib.ct_calib_ifetch.argtypes = [i, p, p]
     lib.ct_calib_launches.argtypes = [i, i, p, p]
     lib.ct_calib_cu_map.argtypes = [i, i, i, p, p]
     lib.ct_calib_xcd_stream.argtypes = [p, p, sz, i, p, p]

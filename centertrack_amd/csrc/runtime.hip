@@ -152,6 +152,79 @@ extern "C" int ct_calib_chase(const unsigned *ring, int hops, unsigned start, un
     return CT_OK;
 }
 
+// (1b) the same ring followed by MANY lanes at once (every lane of `blocks` x 256 starts at its own line): dependent random
+//      64-byte accesses under load -- what a gather-heavy launch sees, as opposed to one lane on an idle fabric.
+__global__ __launch_bounds__(256) void calib_chase_many_kernel(const unsigned *ring, int hops, unsigned nlines, unsigned *out)
+{
+    const unsigned gid = blockIdx.x * 256 + threadIdx.x;
+    unsigned idx = (unsigned)(((unsigned long long)gid * 2654435761ull) % nlines);
+    for (int i = 0; i < hops; ++i) idx = ring[(size_t)idx * 32];
+    if (idx == 0xffffffffu) out[gid] = idx;
+}
+
+extern "C" int ct_calib_chase_many(const unsigned *ring, int hops, unsigned nlines, int blocks, unsigned *out, void *stream)
+{
+    if (!ring || hops <= 0 || nlines == 0 || blocks <= 0 || !out) CT_FAIL_ARG("ct_calib_chase_many: bad arguments");
+    hipLaunchKernelGGL(calib_chase_many_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, ring, hops, nlines, out);
+    CT_CHECK_LAUNCH("ct_calib_chase_many");
+    return CT_OK;
+}
+
+// (1c) write side: ONE lane stores to a new 128-byte line and waits for the acknowledgement (s_waitcnt 0) before the next
+//      store -- the store round trip every launch pays at its end (a kernel retires when its last store is acknowledged);
+//      and `blocks` x 256 lanes streaming 16-byte stores with no loads at all (fill = 1).
+__global__ void calib_write_ack_kernel(float *buf, int hops, unsigned long long *out)
+{
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    for (int i = 0; i < hops; ++i) {
+        __builtin_nontemporal_store(1.0f + i, buf + (size_t)i * 32);
+        __builtin_amdgcn_s_waitcnt(0);
+    }
+    out[0] = __builtin_amdgcn_s_memrealtime() - t0;
+}
+
+__global__ __launch_bounds__(256) void calib_fill_kernel(float4 *dst, size_t n)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    const float4 v = make_float4(1.f, 2.f, 3.f, 4.f);
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += stride) dst[i] = v;
+}
+
+extern "C" int ct_calib_write(void *buf, size_t bytes, int hops, int blocks, int fill, unsigned long long *out, void *stream)
+{
+    if (!buf || (bytes & 15) || (!fill && (!out || hops <= 0 || (size_t)hops * 128 > bytes)) || (fill && blocks <= 0))
+        CT_FAIL_ARG("ct_calib_write: bad arguments");
+    if (fill)
+        hipLaunchKernelGGL(calib_fill_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (float4 *)buf, bytes / 16);
+    else
+        hipLaunchKernelGGL(calib_write_ack_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, (float *)buf, hops, out);
+    CT_CHECK_LAUNCH("ct_calib_write");
+    return CT_OK;
+}
+
+// (1d) instruction fetch: 16 384 independent-ish VALU instructions in a straight line (64 KB of code, more than the 64 KB
+//      instruction cache two CUs share once the prologue is counted), executed once by every wave of `blocks` workgroups --
+//      a launch of big straight-line code (the stem, decode stage 2) starts with a cold instruction cache every time.
+#define CT_REP4(x) x x x x
+#define CT_REP16(x) CT_REP4(CT_REP4(x))
+#define CT_REP256(x) CT_REP16(CT_REP16(x))
+#define CT_REP4096(x) CT_REP16(CT_REP256(x))
+__global__ __launch_bounds__(256) void calib_ifetch_kernel(float *out, float seed)
+{
+    float a = seed + threadIdx.x, b = seed * 0.5f, c = seed * 0.25f, d = seed * 0.125f;
+    CT_REP4096(asm volatile("v_add_f32 %0, %0, %4\n v_add_f32 %1, %1, %4\n v_add_f32 %2, %2, %4\n v_add_f32 %3, %3, %4"
+                            : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "v"(seed));)
+    if (a + b + c + d == 12345.678f) out[blockIdx.x * 256 + threadIdx.x] = a;
+}
+
+extern "C" int ct_calib_ifetch(int blocks, float *out, void *stream)
+{
+    if (blocks <= 0 || !out) CT_FAIL_ARG("ct_calib_ifetch: bad arguments");
+    hipLaunchKernelGGL(calib_ifetch_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, out, 1.0f);
+    CT_CHECK_LAUNCH("ct_calib_ifetch");
+    return CT_OK;
+}
+
 // (2) streaming copy at a chosen occupancy: `blocks` workgroups of `threads` lanes, each lane moves 16-byte vectors with
 //     `inflight` loads issued before the first store -- 256 x 256 x 1 is "one wave per SIMD, one load in flight", the
 //     regime of the frame's latency-bound launches; 2048 x 256 x 4 is the bandwidth regime.

@@ -429,7 +429,16 @@ int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
  * flight per lane.  ct_calib_launches: n dependent launches of a `blocks`-workgroup kernel over buf (DEVICE
  * float[blocks * 256]). */
 int ct_calib_chase(const unsigned *ring, int hops, unsigned start, unsigned long long *out, void *stream);
+/* ct_calib_chase_many: the same ring (nlines lines) followed by every lane of blocks x 256 from its own start line (out: DEVICE
+ * uint32[blocks * 256], never written in practice). */
+int ct_calib_chase_many(const unsigned *ring, int hops, unsigned nlines, int blocks, unsigned *out, void *stream);
 int ct_calib_stream(const void *src, void *dst, size_t bytes, int blocks, int inflight, void *stream);
+/* ct_calib_write: fill = 0: one lane stores to `hops` consecutive 128-byte lines of buf, waiting for every store's
+ * acknowledgement; out[0] (DEVICE uint64) = elapsed 100 MHz ticks.  fill = 1: blocks x 256 lanes stream 16-byte stores over
+ * `bytes` (no loads). */
+/* ct_calib_ifetch: blocks x 256 lanes run 16 384 straight-line VALU instructions (64 KB of code) once: instruction-fetch path. */
+int ct_calib_ifetch(int blocks, float *out, void *stream);
+int ct_calib_write(void *buf, size_t bytes, int hops, int blocks, int fill, unsigned long long *out, void *stream);
 int ct_calib_launches(int n, int blocks, float *buf, void *stream);
 /* ct_calib_cu_map: `blocks` workgroups of 256 lanes with lds_bytes of dynamic LDS each record {HW_ID, XCC_ID, start, end (100 MHz
  * ticks)} into out (DEVICE uint32[4 * blocks]) and spin for spin_ticks in between: which CUs exist and how the dispatcher

@@ -2,8 +2,9 @@
 """What box did a measurement run on?  ``python tools/box_calib.py`` prints one JSON line; ``bench.py`` embeds the same
 dict as ``box_calibration``.  The MI355X boxes of the pool run the one-stream frame 16 % apart while their fp32 MFMA
 loops agree to 0.3 %; rounds 3/4 recorded only the MFMA rate and the device-to-device copy bandwidth, which did not
-predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for (none of
-them separated the two states over 27 calls -- DESIGN.md section 4 -- they stay in the line as the record):
+predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for.  Over 45
+calls every DATA-path probe read the same in both states; the one that differs is instruction fetch
+(``launch_us.ifetch_64KB_code_256wg``: 39 us fast, 56 us slow -- DESIGN.md section 4):
 
   chase_ns       dependent-load latency of ONE lane through a random ring of 128-byte lines (ct_calib_chase): 16 KB
                  (the CU's L1), 1 MB (one XCD's L2), 64 MB (Infinity Cache), 2 GiB (HBM) and 1 MB of PINNED HOST memory
@@ -11,7 +12,8 @@ them separated the two states over 27 calls -- DESIGN.md section 4 -- they stay 
   shader_mhz     s_memtime clocks / s_memrealtime ticks of those one-lane kernels: the shader clock a nearly idle chip runs
   stream_GBps    copy of 1 GiB at one wave per SIMD with one 16-byte load in flight per lane (the regime of the stem and
                  the decode) and at 8 workgroups per CU with four in flight (the bandwidth regime)
-  launch_us      dependent kernel boundary inside a captured graph: 200 launches of 1 / 256 workgroups
+  launch_us      dependent kernel boundary inside a captured graph: 200 launches of 1 / 256 workgroups; ``ifetch_64KB_code_*``:
+                 64 KB of straight-line code run once per wave by 256 / 1024 workgroups (cold instruction cache)
   cu_map         hardware ids (XCD / shader engine / CU) and start / end times of every workgroup of three probe launches
                  (ct_calib_cu_map): how many CUs each shader engine of each XCD holds on THIS chip (32 of 36 per XCD are
                  enabled; which ones differs), and whether a "two workgroups per CU" launch finishes in one round
@@ -103,6 +105,17 @@ def chase(lib, st, device):
             best = ns if best is None or ns < best else best
         res[name] = round(best, 1)
         del ring, src
+    # ... and under LOAD: every lane of 256 / 1024 workgroups follows the ring from its own line -- Mlines/s of dependent random
+    # 128-byte-line accesses (the single lane above sees an idle fabric; a slow lease serves the SAME traffic more slowly)
+    for name, lines in (('mall_64MB', 1 << 19), ('hbm_2GiB', 1 << 24)):
+        ring = _ring(lines, device)
+        ring.sum().item()
+        sink = torch.zeros(1024 * 256, dtype=torch.int32, device=device)
+        for blocks in (256, 1024):
+            hops = 2000
+            ms = _timed(lambda: lib.ct_calib_chase_many(ctypes.c_void_p(ring.data_ptr()), hops, lines, blocks, ctypes.c_void_p(sink.data_ptr()), st), 2)
+            res['loaded_%s_%dwg_Mlines_per_s' % (name, blocks)] = round(blocks * 256 * hops / ms / 1e3)
+        del ring
     return res, mhz
 
 
@@ -115,6 +128,22 @@ def stream(lib, st, device):
     for name, blocks, inflight in (('1GiB_1wave_per_simd_1load', 256, 1), ('1GiB_8wg_per_cu_4loads', 2048, 4)):
         ms = _timed(lambda: lib.ct_calib_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n * 4, blocks, inflight, st), 3)
         res[name] = round(2.0 * n * 4 / ms / 1e6)
+    # the write side alone: the store round trip of one lane (a launch retires when its last store is acknowledged) and
+    # store-only streaming at one wave per SIMD / eight workgroups per CU
+    out = torch.zeros(2, dtype=torch.int64, device=device)
+    hops = 20000
+    best = None
+    for rep in range(3):
+        lib.ct_calib_write(ctypes.c_void_p(b.data_ptr()), n * 4, hops, 1, 0, ctypes.c_void_p(out.data_ptr()), st)
+        torch.cuda.synchronize()
+        ns = int(out[0].item()) * 10.0 / hops
+        best = ns if best is None or ns < best else best
+    res['store_ack_ns_one_lane'] = round(best, 1)
+    for name, blocks in (('1GiB_fill_1wave_per_simd', 256), ('1GiB_fill_8wg_per_cu', 2048)):
+        ms = _timed(lambda: lib.ct_calib_write(ctypes.c_void_p(b.data_ptr()), n * 4, 0, blocks, 1, None, st), 3)
+        res[name] = round(n * 4 / ms / 1e6)
+    ms = _timed(lambda: lib.ct_calib_write(ctypes.c_void_p(b.data_ptr()), (1 << 22) * 4, 0, 256, 1, None, st), 20)
+    res['16MiB_fill_1wave_per_simd'] = round((1 << 22) * 4 / ms / 1e6)
     m = 1 << 22           # 16 MiB: L2 / Infinity-Cache resident
     ms = _timed(lambda: lib.ct_calib_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), m * 4, 256, 1, st), 20)
     res['16MiB_1wave_per_simd_1load'] = round(2.0 * m * 4 / ms / 1e6)
@@ -127,6 +156,11 @@ def launches(lib, device):
     from centertrack_amd import _lib
     buf = torch.zeros(256 * 256, device=device)
     res = {}
+    # 64 KB of straight-line code run once per wave (cold instruction cache at every launch): us per launch, 256 / 1024 workgroups
+    for blocks in (256, 1024):
+        st0 = _lib.stream_ptr()
+        ms = _timed(lambda: lib.ct_calib_ifetch(blocks, ctypes.c_void_p(buf.data_ptr()), st0), 10)
+        res['ifetch_64KB_code_%dwg' % blocks] = round(ms * 1e3, 2)
     N = 200
     for blocks in (1, 256):
         side = torch.cuda.Stream()

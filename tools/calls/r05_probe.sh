@@ -7,5 +7,5 @@ import json
 j = json.loads([l for l in open('$O/bench_$TAG.json') if l.startswith('{')][-1])
 b = j['box_calibration']
 print('$TAG', j['value'], 'fps dev', j['device_ms_per_frame_batch'], 'dcn', j['roofline']['total_ms'], 'conv', j['roofline_conv']['total_ms'], b['sysfs'].get('dir'))
-print(b["node"]["kernel"], {k: v for k, v in b["sysfs"].items() if k.startswith("temp_") or k.startswith("power1")})
+print({k: v for k, v in b["launch_us"].items()})
 P
