@@ -2,7 +2,7 @@
 """What box did a measurement run on?  ``python tools/box_calib.py`` prints one JSON line; ``bench.py`` embeds the same
 dict as ``box_calibration``.  The MI355X boxes of the pool run the one-stream frame 16 % apart while their fp32 MFMA
 loops agree to 0.3 %; rounds 3/4 recorded only the MFMA rate and the device-to-device copy bandwidth, which did not
-predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for.  Over 45
+predict the class.  Round 5 adds probes of what a latency-bound launch actually waits for.  Over 47
 calls every DATA-path probe read the same in both states; the one that differs is instruction fetch
 (``launch_us.ifetch_64KB_code_256wg``: 39 us fast, 56 us slow -- DESIGN.md section 4):
 
