@@ -1046,7 +1046,7 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
                 CT_FAIL_ARG("ct_decode: sparse head %d is incomplete", i);
             if (d->heads[sp->head[i]]) CT_FAIL_ARG("ct_decode: head %d is both dense and sparse", sp->head[i]);
         }
-        if (d->done_flag && !d->done_counter) CT_FAIL_ARG("ct_decode: done_flag needs done_counter");
+        if (sp->flip_B < 0 || (sp->flip_B > 0 && sp->flip_B != d->B)) CT_FAIL_ARG("ct_decode: sparse flip_B must be 0 or B (feat then holds 2 * B images)");
     }
     if (!d->workspace || d->workspace_bytes < need) {
         ct_set_error("ct_decode: needs %zu workspace bytes, got %zu", need, d->workspace_bytes);
@@ -1108,7 +1108,6 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
         sa.depth_scale = sp->depth_scale; sa.zero_tracking = sp->zero_tracking;
         sa.flip_B = sp->flip_B;
         for (int i = 0; i < CT_NUM_HEADS; ++i) sa.flip_mode[i] = (i < sp->nheads) ? sp->flip_mode[i] : 0;
-        if (sp->flip_B < 0 || (sp->flip_B > 0 && sp->flip_B != d->B)) CT_FAIL_ARG("ct_decode: sparse flip_B must be 0 or B (feat then holds 2 * B images)");
         {
             const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
             unsigned char *base = (unsigned char *)(a2.winners + (size_t)d->B * d->K);
