@@ -3,11 +3,14 @@
 
 Run in the build container only (needs /root/reference):
 
-    python tests/golden/make_kitti_gt.py [--check]
+    python tests/golden/make_kitti_gt.py [--split val_half|full] [--check]
 
 Input: the KITTI tracking ground truth the reference ships for its evaluator,
 ``src/tools/eval_kitti_track/data/tracking/label_02_val_half/*.txt`` (21 sequences, 4 030 frames, ~30 k boxes of
-real trajectories) -- the only real tracking data in the checkout.  Every frame's GT boxes are turned into
+real trajectories; the split its KITTI experiments are scored on, experiments/kitti_half.sh) and -- ``--split full`` ->
+``kitti_gt_tracks_full.npz`` -- ``label_02/*.txt``, the 21 COMPLETE training videos (8 029 frames by the evaluator's
+count, ~65 k label rows: the train halves are their first halves, so this is all the real tracking data in the
+checkout).  Every frame's GT boxes are turned into
 the detections ``Detector.run`` would hand to ``Tracker.step`` (utils/tracker.py:28): ``score``, ``class``
 (datasets/kitti_tracking.py:19: Pedestrian 1, Car 2, Cyclist 3), ``bbox``, ``ct`` = box centre, ``tracking`` =
 previous-frame GT centre - current centre (the displacement head's target, generic_dataset.py:409-411), all
@@ -59,18 +62,25 @@ def label_dir(ref):
     return os.path.join(ref, 'src', 'tools', 'eval_kitti_track', 'data', 'tracking')
 
 
-def read_sequences(ref):
+SPLITS = {  # name -> (seqmap, label directory, fixture): evaluate_tracking.py:99-100, 120-124
+    'val_half': ('evaluate_trackingval_half.seqmap', 'label_02_val_half', 'kitti_gt_tracks.npz'),
+    'full': ('evaluate_tracking.seqmap', 'label_02', 'kitti_gt_tracks_full.npz'),
+}
+
+
+def read_sequences(ref, split='val_half'):
     """[(name, n_frames, {frame: [(gt_id, type, x1, y1, x2, y2)]})] in seqmap order (evaluate_tracking.py:103-108)"""
     root = label_dir(ref)
     seqs = []
-    with open(os.path.join(root, 'evaluate_trackingval_half.seqmap')) as f:
+    seqmap, labels, _ = SPLITS[split]
+    with open(os.path.join(root, seqmap)) as f:
         for line in f:
             p = line.split(' ')
             if len(p) < 4:
                 continue
             name, n = '%04d' % int(p[0]), int(p[3]) - int(p[2]) + 1
             frames = {}
-            with open(os.path.join(root, 'label_02_val_half', name + '.txt')) as g:
+            with open(os.path.join(root, labels, name + '.txt')) as g:
                 for row in g:
                     q = row.split(' ')
                     frames.setdefault(int(q[0]), []).append(
@@ -169,7 +179,9 @@ def main():
     ref = ref_import.install()
     import types
     from utils.tracker import Tracker          # the reference's own class
-    seqs = read_sequences(ref)
+    split = sys.argv[sys.argv.index('--split') + 1] if '--split' in sys.argv else 'val_half'
+    fixture = os.path.join(HERE, SPLITS[split][2])
+    seqs = read_sequences(ref, split)
     out = {'seq_names': np.array([int(s[0]) for s in seqs], np.int32)}
     sets = {}
     for kind in ('clean', 'noisy'):
@@ -187,13 +199,13 @@ def main():
         out[name + '.tracks'], out[name + '.ptr'] = rows, optr
         print(name, 'tracks', rows.shape, 'ids', int(rows[:, 0].max()), 'carried', int((rows[:, 3] < 0).sum()))
     if '--check' in sys.argv:          # re-run of the reference against the committed fixture, nothing written
-        have = np.load(os.path.join(HERE, 'kitti_gt_tracks.npz'))
+        have = np.load(fixture)
         bad = [k for k in out if k not in have or not np.array_equal(have[k], out[k])] + \
               [k for k in have.files if k not in out]
         print('CHECK', 'FAILED ' + ','.join(bad) if bad else 'OK: %d arrays identical' % len(out))
         sys.exit(1 if bad else 0)
-    np.savez_compressed(os.path.join(HERE, 'kitti_gt_tracks.npz'), **out)
-    print('kitti_gt_tracks.npz', os.path.getsize(os.path.join(HERE, 'kitti_gt_tracks.npz')), 'bytes')
+    np.savez_compressed(fixture, **out)
+    print(os.path.basename(fixture), os.path.getsize(fixture), 'bytes')
 
 
 if __name__ == '__main__':

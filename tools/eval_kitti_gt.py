@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Recipe: hot path's tracks -> on-disk KITTI tracking files -> the REFERENCE's evaluator.
 
-    python tools/eval_kitti_gt.py [mode ...] [--out DIR] [--write-golden]
+    python tools/eval_kitti_gt.py [mode ...] [--split val_half|full] [--out DIR] [--write-golden]
 
 Build container only (the evaluator and its ground truth live in /root/reference).  For each mode of
 tests/golden/kitti_gt_tracks.npz (tests/golden/make_kitti_gt.py: detections derived from the reference's KITTI
@@ -11,7 +11,10 @@ as ``{image_id: [items]}`` the way test.py:109 collects ``Detector.run(...)['res
 datasets/kitti_tracking.py:51-97) and scored by ``src/tools/eval_kitti_track/evaluate_tracking.py`` run UNMODIFIED
 as a subprocess in ``<reference>/src`` exactly like ``KITTITracking.run_eval`` does (kitti_tracking.py:99-102:
 ``python tools/eval_kitti_track/evaluate_tracking.py <dir>/results_kitti_tracking/ val_half``).  The evaluator's
-summary files are parsed into a dict; ``--write-golden`` stores them as tests/golden/kitti_gt_eval.json."""
+summary files are parsed into a dict; ``--write-golden`` stores them as tests/golden/kitti_gt_eval.json.
+``--split full``: the 21 complete training videos (``label_02``, kitti_gt_tracks_full.npz), scored the way the evaluator
+scores a run without a split argument (evaluate_tracking.py:975: ``split_version = ''`` -> ``evaluate_tracking.seqmap``,
+``label_02``) -> tests/golden/kitti_gt_eval_full.json."""
 import json
 import os
 import subprocess
@@ -74,16 +77,17 @@ def track_mode(gold, mode):
     return results, videos, v2i
 
 
-def evaluate(modes, out_dir, ref='/root/reference'):
+def evaluate(modes, out_dir, ref='/root/reference', split='val_half'):
+    import make_kitti_gt as G
     from centertrack_amd import results_io
-    gold = dict(np.load(os.path.join(REPO, 'tests', 'golden', 'kitti_gt_tracks.npz')))
+    gold = dict(np.load(os.path.join(REPO, 'tests', 'golden', G.SPLITS[split][2])))
     res = {}
     for mode in modes:
         d = os.path.join(out_dir, mode)
         os.makedirs(d, exist_ok=True)
         results, videos, v2i = track_mode(gold, mode)
         rdir = results_io.save_kitti_tracking_results(results, d, videos, v2i)
-        p = subprocess.run([sys.executable, 'tools/eval_kitti_track/evaluate_tracking.py', rdir + '/', 'val_half'],
+        p = subprocess.run([sys.executable, 'tools/eval_kitti_track/evaluate_tracking.py', rdir + '/'] + ([split] if split != 'full' else []),
                            cwd=os.path.join(ref, 'src'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
         if p.returncode != 0 or 'Thank you for participating' not in p.stdout:
             raise RuntimeError('reference evaluator failed on %s:\n%s' % (rdir, p.stdout[-2000:]))
@@ -94,23 +98,29 @@ def evaluate(modes, out_dir, ref='/root/reference'):
 def main():
     import tempfile
     import make_kitti_gt as G
-    args = [a for a in sys.argv[1:] if not a.startswith('--')]
+    split = 'val_half'
+    argv = list(sys.argv[1:])
+    if '--split' in argv:
+        split = argv[argv.index('--split') + 1]
+        argv.remove(split)
+    args = [a for a in argv if not a.startswith('--')]
     modes = args or [m[0] for m in G.MODES]
     out = None
     if '--out' in sys.argv:
         out = sys.argv[sys.argv.index('--out') + 1]
         modes = [m for m in modes if m != out]
     with tempfile.TemporaryDirectory() as tmp:
-        res = evaluate(modes, out or tmp)
+        res = evaluate(modes, out or tmp, split=split)
     for mode, r in res.items():
         for c, s in r.items():
             print('%-30s %-10s MOTA %.4f MOTP %.4f recall %.4f precision %.4f FP %d FN %d IDs %d frag %d' % (
                 mode, c, s['MOTA'], s['MOTP'], s['recall'], s['precision'], s['false positives'], s['missed'],
                 s['id-switches'], s['fragmentations']))
     if '--write-golden' in sys.argv:
-        with open(os.path.join(REPO, 'tests', 'golden', 'kitti_gt_eval.json'), 'w') as f:
+        name = 'kitti_gt_eval.json' if split == 'val_half' else 'kitti_gt_eval_%s.json' % split
+        with open(os.path.join(REPO, 'tests', 'golden', name), 'w') as f:
             json.dump(res, f, indent=1, sort_keys=True)
-        print('tests/golden/kitti_gt_eval.json written')
+        print('tests/golden/%s written' % name)
 
 
 if __name__ == '__main__':
