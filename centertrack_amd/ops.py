@@ -316,7 +316,7 @@ class Decoder(object):
         nbytes = lib.ct_decode_workspace_bytes(ctypes.byref(d))
         if nbytes == 0:
             _lib.check(1, 'ct_decode_workspace_bytes')
-        # (zeroed: the sparse heads' arrival counters start at 0 and every launch leaves them there)
+        # (zeroed: the block holds a reserved counter area besides the keys -- nothing in it is ever read uninitialised)
         self.ws = torch.zeros(nbytes // 8 + 1, dtype=torch.int64, device=hm.device)
         d.out, d.inds = self.out.data_ptr(), self.inds.data_ptr()
         d.out_stride = self.F
