@@ -21,6 +21,11 @@ import types
 
 import numpy as np
 
+# /root/reference is read-only for this project: importing its modules must not leave __pycache__ directories in it
+# (this process and every child process it starts)
+sys.dont_write_bytecode = True
+os.environ['PYTHONDONTWRITEBYTECODE'] = '1'
+
 REF = os.environ.get('CENTERTRACK_REFERENCE', '/root/reference')
 REPO = os.path.abspath(os.path.join(os.path.dirname(__file__), '..', '..'))
 

@@ -88,7 +88,8 @@ def evaluate(modes, out_dir, ref='/root/reference', split='val_half'):
         results, videos, v2i = track_mode(gold, mode)
         rdir = results_io.save_kitti_tracking_results(results, d, videos, v2i)
         p = subprocess.run([sys.executable, 'tools/eval_kitti_track/evaluate_tracking.py', rdir + '/'] + ([split] if split != 'full' else []),
-                           cwd=os.path.join(ref, 'src'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                           cwd=os.path.join(ref, 'src'), stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True,
+                           env=dict(os.environ, PYTHONDONTWRITEBYTECODE='1'))      # (nothing is written into the reference tree)
         if p.returncode != 0 or 'Thank you for participating' not in p.stdout:
             raise RuntimeError('reference evaluator failed on %s:\n%s' % (rdir, p.stdout[-2000:]))
         res[mode] = {c: parse_summary(os.path.join(rdir, 'summary_%s.txt' % c)) for c in ('car', 'pedestrian')}
