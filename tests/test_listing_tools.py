@@ -3,7 +3,10 @@ instruction streams alone?) and tools/occupancy.py (registers / LDS / waves per 
 import os
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', 'tools'))
+ROOT = os.path.abspath(os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
+sys.path.insert(0, os.path.join(ROOT, 'tools'))
+if ROOT not in sys.path:
+    sys.path.insert(1, ROOT)
 
 LISTING = '''
 \t.type\t_Z1aPf,@function
@@ -94,3 +97,25 @@ def test_bench_flags_used_by_the_collection_scripts_exist():
     known = {a.option_strings[0] for a in bench.build_parser()._actions if a.option_strings}
     missing = sorted(f for f in flags if f not in known)
     assert not missing, 'bench.py does not know %s' % missing
+
+
+def test_box_state_classification_from_the_instruction_fetch_probe():
+    """bench.py's ``box_calibration.state``: the recorded leases fall into their classes, anything else is not forced into one
+    (profiles/r05_a_box_probes.jsonl calls 39-48: nine fast leases 38.8-40.1 us, the slow one 56.5 us)"""
+    import json
+    from tools import box_calib
+    rows = [json.loads(l) for l in open(os.path.join(ROOT, 'profiles', 'r05_a_box_probes.jsonl'))]
+    seen = {'fast': 0, 'slow': 0}
+    for r in rows:
+        if 'ifetch_64KB_code_256wg' not in (r.get('launch_us') or {}):
+            assert box_calib.fetch_state(r.get('launch_us'))['instruction_fetch'] == 'unknown'
+            continue
+        st = box_calib.fetch_state(r['launch_us'])
+        want = 'slow' if r['device_ms'] > 1.03 else 'fast'
+        assert st['instruction_fetch'] == want, (r['call'], st)
+        lo, hi = st['expect_device_ms_mot17_512']
+        assert lo <= r['device_ms'] <= hi, (r['call'], r['device_ms'], st)
+        seen[want] += 1
+    assert seen['fast'] >= 9 and seen['slow'] >= 1
+    assert box_calib.fetch_state({'ifetch_64KB_code_256wg': 47.0})['instruction_fetch'] == 'between'
+    assert box_calib.fetch_state({'error': 'x'})['instruction_fetch'] == 'unknown'

@@ -406,7 +406,25 @@ def box_calibration(device=None, probes=True):
                     res[key] = v
             except Exception as e:       # a probe must never cost the bench line
                 res[key] = {'error': repr(e)}
+        res['state'] = fetch_state(res.get('launch_us'))
     return res
+
+
+IFETCH_FAST_US, IFETCH_SLOW_US = (38.8, 40.1), 56.5      # profiles/r05_a_box_probes.jsonl: nine fast leases, one slow one
+
+
+def fetch_state(launch_us):
+    """which of the pool's two per-lease states this process runs in, as far as the one probe that differs between them can
+    tell: the instruction-fetch probe at one wave per SIMD.  The threshold is the midpoint of what was
+    measured; a figure between the two clusters is reported as such, not forced into a class."""
+    v = (launch_us or {}).get('ifetch_64KB_code_256wg') if isinstance(launch_us, dict) else None
+    if not isinstance(v, (int, float)):
+        return {'instruction_fetch': 'unknown'}
+    lo, hi = IFETCH_FAST_US[1] * 1.05, IFETCH_SLOW_US * 0.92
+    cls = 'fast' if v <= lo else 'slow' if v >= hi else 'between'
+    return {'instruction_fetch': cls, 'ifetch_64KB_code_256wg_us': v, 'fast_leases_us': list(IFETCH_FAST_US), 'slow_lease_us': IFETCH_SLOW_US,
+            'expect_device_ms_mot17_512': {'fast': [0.933, 0.954], 'slow': [1.074, 1.133]}.get(cls),
+            'note': 'per-lease state of the box, not of the code: DESIGN.md section 4 "The box classes"'}
 
 
 if __name__ == '__main__':
