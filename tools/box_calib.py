@@ -406,7 +406,10 @@ def box_calibration(device=None, probes=True):
                     res[key] = v
             except Exception as e:       # a probe must never cost the bench line
                 res[key] = {'error': repr(e)}
-        res['state'] = fetch_state(res.get('launch_us'))
+        try:
+            res['state'] = fetch_state(res.get('launch_us'))
+        except Exception as e:
+            res['state'] = {'error': repr(e)}
     return res
 
 
