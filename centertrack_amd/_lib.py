@@ -57,7 +57,8 @@ class DcnDesc(ctypes.Structure):
                 ('w_off_packed', ctypes.c_void_p), ('b_off', ctypes.c_void_p),
                 ('up_w', ctypes.c_void_p), ('up_f', ctypes.c_int), ('up_skip', ctypes.c_void_p), ('up_lds', ctypes.c_int),
                 ('up_y', ctypes.c_void_p), ('up_ldy', ctypes.c_int),
-                ('om_partial', ctypes.c_void_p), ('om_partial_bytes', ctypes.c_size_t)]
+                ('om_partial', ctypes.c_void_p), ('om_partial_bytes', ctypes.c_size_t),
+                ('w_off_winograd', ctypes.c_void_p)]
 
 
 CT_MAX_FUSED_HEADS = 8
@@ -160,7 +161,7 @@ class FrameStepArgs(ctypes.Structure):
 CT_FRAME_DEVICE, CT_FRAME_HOST, CT_FRAME_IN_PLACE, CT_FRAME_UPLOADED = range(4)
 
 
-ABI_VERSION = 102       # CT_ABI_VERSION of include/centertrack_hip.h
+ABI_VERSION = 103       # CT_ABI_VERSION of include/centertrack_hip.h
 
 EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_elems', 'ct_pack_conv_weight',
            'ct_packed_winograd_elems', 'ct_pack_winograd_weight', 'ct_conv2d',
@@ -172,7 +173,7 @@ EXPORTS = ['ct_last_error', 'ct_version', 'ct_set_tuning', 'ct_packed_weight_ele
            'ct_tracker_id_count', 'ct_tracker_get_tracks', 'ct_tracker_step', 'ct_tracker_prehm_params', 'ct_linear_assignment', 'ct_tracker_set_mode', 'ct_tracker_init_tracks',
            'ct_tracker_step_public', 'ct_tracker_step_dets', 'ct_transform_points',
            'ct_preprocess_image', 'ct_preprocess_lut', 'ct_preprocess_device', 'ct_graph_begin', 'ct_graph_end', 'ct_graph_launch', 'ct_graph_destroy',
-           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_calib_mfma', 'ct_calib_chase', 'ct_calib_chase_many', 'ct_calib_write', 'ct_calib_ifetch', 'ct_calib_stream', 'ct_calib_launches', 'ct_calib_cu_map', 'ct_calib_xcd_stream', 'ct_flip_merge', 'ct_flip_images',
+           'ct_memcpy_async', 'ct_memset_async', 'ct_stream_synchronize', 'ct_flip_merge', 'ct_flip_images',
            'ct_frame_loop_create', 'ct_frame_loop_destroy', 'ct_frame_loop_submit', 'ct_frame_loop_wait', 'ct_frame_loop_finish',
            'ct_frame_loop_finish_submit', 'ct_frame_loop_upload', 'ct_frame_loop_pending_slot', 'ct_frame_loop_in_flight',
            'ct_frame_loop_forget_upload', 'ct_frame_loop_prestage', 'ct_stem_forward_parts', 'ct_signal_host']
@@ -268,15 +269,6 @@ def load():
     lib.ct_stream_synchronize.argtypes = [p]
     lib.ct_memset_async.argtypes = [p, i, sz, p]
     lib.ct_signal_host.argtypes = [p, i, p]
-    lib.ct_calib_mfma.argtypes = [i, i, p, p]
-    lib.ct_calib_chase.argtypes = [p, i, ctypes.c_uint, p, p]
-    lib.ct_calib_stream.argtypes = [p, p, sz, i, i, p]
-    lib.ct_calib_chase_many.argtypes = [p, i, ctypes.c_uint, i, p, p]
-    lib.ct_calib_write.argtypes = [p, sz, i, i, i, p, p]
-    lib.ct_calib_ifetch.argtypes = [i, p, p]
-    lib.ct_calib_launches.argtypes = [i, i, p, p]
-    lib.ct_calib_cu_map.argtypes = [i, i, i, p, p]
-    lib.ct_calib_xcd_stream.argtypes = [p, p, sz, i, p, p]
     lib.ct_flip_merge.argtypes = [ctypes.POINTER(FlipHead), i, p, i, i, i, i, p]
     lib.ct_flip_images.argtypes = [p, p, sz, i, p]
     lib.ct_frame_loop_create.restype = p

@@ -32,6 +32,14 @@ enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUN
        CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_HEADS_ORDER, CT_TUNE_STEM_ROWS, CT_TUNE_COUNT };
 int ct_tune_get(int key);
 void ct_affine_inverse(const double *trans, double *M);   // host_preprocess.cpp
+// wino_mfma.hip: the offset/mask convs of up to 4 DCN layers in one Winograd launch, K-split over 64-channel chunks into
+// raw partial maps part[Cin/64][N,H,W,32] (dcn_mfma.hip's CT_DCN_OFFSETS phase)
+struct ct_wino_off_layer {
+    const float *x; int N, H, W, Cin, ldx;
+    const float *w_winograd;     // ct_pack_winograd_weight(conv_offset_mask.weight [27,Cin,3,3])
+    float *part;
+};
+int ct_wino_offsets_group(const ct_wino_off_layer *layers, int n, void *stream);
 
 // XCD-aware decode of the linear workgroup id into (cout block, pixel-tile index).  Workgroups are dealt to
 // the 8 XCDs round-robin (id % 8) and each XCD has its own 4 MB L2, so with `per` = coutBlocks / 8 > 0

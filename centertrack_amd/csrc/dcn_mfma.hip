@@ -69,6 +69,12 @@ struct DcnGroup {
 #define CT_OFF_PD 2       // B prefetch distance of the offset/mask conv tiles (variant builds: tools/build_variant.py)
 #endif
 CT_DEFINE_STAMPS(dcn)       // (tools/dcn_phases.py; expands to nothing in the shipped build)
+// Ablations of the MAIN loop (variant builds of tools/build_variant.py ONLY; results are wrong, the timing says which resource
+// bounds a step): 1 = no corner loads (the gather path), 2 = no MFMAs, 4 = no weight loads in the loop, 8 = no barrier,
+// 16 = no A-fragment reads from LDS
+#ifndef CT_ABL
+#define CT_ABL 0
+#endif
 
 template <int BM, int WN, bool FUSE, int NKK = 2>
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
@@ -275,6 +281,13 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
         gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
         const float *base = xin + chunk * (16 * NKK) + gk0 * 16 + gq * 4;
+        if (CT_ABL & 1) {
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) cv[slot][kk][c] = f32x4{(float)o.x, (float)o.y, (float)(o.z + kk), (float)(o.w + c)};
+            return;
+        }
 #pragma unroll
         for (int kk = 0; kk < GK; ++kk) {
             cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * SSTR * 16);
@@ -325,9 +338,17 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 #pragma unroll
             for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-                for (int mt = 0; mt < WM; ++mt)
-                    af[kk][mt] = *reinterpret_cast<const f32x4 *>(lds_g + P * BUF + kk * SLAB + aoff[mt]);
-            load_b(bq[P ^ 1], c1, t1);
+                for (int mt = 0; mt < WM; ++mt) {
+                    if (CT_ABL & 16) af[kk][mt] = f32x4{(float)s, 1.f, 2.f, (float)(kk + mt)};
+                    else af[kk][mt] = *reinterpret_cast<const f32x4 *>(lds_g + P * BUF + kk * SLAB + aoff[mt]);
+                }
+            if (!(CT_ABL & 4)) load_b(bq[P ^ 1], c1, t1);
+            else if (P == 0) {
+#pragma unroll
+                for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                    for (int nt = 0; nt < WN; ++nt) bq[1][kk][nt] = bq[0][kk][nt];
+            }
             // slot P held step s, already blended into LDS buffer P by the previous iteration
             gather_load(P, c2, t2);
             // step s+1's A tile (corners loaded one step ago); past the last step this blends the clamped re-fetch
@@ -347,14 +368,16 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 #pragma unroll
                     for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-                        for (int nt = 0; nt < WN; ++nt)
-                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][mt][e], bq[P][kk][nt][e],
+                        for (int nt = 0; nt < WN; ++nt) {
+                            if (CT_ABL & 2) asm volatile("" : "+v"(acc[mt][nt]) : "v"(af[kk][mt][e]), "v"(bq[P][kk][nt][e]));
+                            else acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][mt][e], bq[P][kk][nt][e],
                                                                               acc[mt][nt], 0, 0, 0);
+                        }
             __builtin_amdgcn_sched_barrier(0x386);
 #pragma unroll
             for (int kk = 0; kk < GK; ++kk)
                 *reinterpret_cast<f32x4 *>(lds_g + (P ^ 1) * BUF + (gk0 + kk * SSTR) * SLAB + lslot) = v[kk];
-            __syncthreads();
+            if (!(CT_ABL & 8)) __syncthreads();
             __builtin_amdgcn_sched_barrier(0);                   // (steps are scheduled one by one)
         };
         // Both steps of an iteration sit in ONE basic block and an odd last step is peeled: with a branch between them
@@ -442,7 +465,7 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     if (d->fuse_offset < 0 || d->fuse_offset > 3) CT_FAIL_ARG("ct_dcn_v2: fuse_offset=%d (0 .. 3)", d->fuse_offset);
     p->fuse = d->fuse_offset == 1;
     p->parts = d->fuse_offset == 2 ? d->Cin / 64 : (d->fuse_offset == 3 ? 1 : 0);
-    if (d->fuse_offset && (!d->b_off || (d->fuse_offset != 3 && !d->w_off_packed)))
+    if (d->fuse_offset && (!d->b_off || (d->fuse_offset != 3 && !d->w_off_packed && !(d->fuse_offset == 2 && d->w_off_winograd))))
         CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs w_off_packed and b_off");
     if (d->fuse_offset && d->Cin % 64) CT_FAIL_ARG("ct_dcn_v2: fuse_offset needs Cin %% 64 == 0 (got %d)", d->Cin);
     if (p->parts) {
@@ -710,9 +733,17 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         DcnGroup og;
         og.n = 0;
         long oblocks = 0;
+        ct_wino_off_layer wl[DCN_MAX_GROUP];
+        int nw = 0;
         for (int i = 0; i < n; ++i) {
             const ct_dcn_desc *d = descs + i;
             if (d->fuse_offset != 2) continue;            // (3: another launch wrote the raw sums)
+            if (d->w_off_winograd) {                      // Winograd form: all such layers of the group in one launch (wino_mfma.hip)
+                ct_wino_off_layer &l = wl[nw++];
+                l.x = d->x; l.N = d->N; l.H = d->H; l.W = d->W; l.Cin = d->Cin; l.ldx = d->ldx;
+                l.w_winograd = d->w_off_winograd; l.part = d->om_partial;
+                continue;
+            }
             DcnArgs &a = og.p[og.n];
             a = g.p[i];
             a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 2); a.coutBlocks = 1;
@@ -729,6 +760,10 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
             for (int i = og.n; i < DCN_MAX_GROUP; ++i) og.p[i] = og.p[0];
             hipLaunchKernelGGL((dcn_mfma_kernel<32, 1, true>), dim3((unsigned)oblocks), dim3(256), lds_bytes(32, true, true), s, og);
             CT_CHECK_LAUNCH("ct_dcn_v2(offset/mask conv)");
+        }
+        if (nw > 0) {
+            const int rc = ct_wino_offsets_group(wl, nw, stream);
+            if (rc != CT_OK) return rc;
         }
     }
     const dim3 grid((unsigned)blocks);

@@ -75,11 +75,11 @@ __device__ __forceinline__ void bt_row(int r, int &i1, int &i2, float &s2)
 #ifndef CT_NB_WAVES
 #define CT_NB_WAVES 3       // waves per SIMD the NB > 1 shapes (fused heads) are compiled for (variant builds: 4 = 128 VGPRs)
 #endif
+// The workgroup body, shared by the plain launch (wino_conv_kernel) and the grouped partial launch (wino_offsets_kernel):
+// `bid` = workgroup index inside its layer, `nblocks` = workgroups of the layer, `chunk0` = first 64-channel chunk this
+// workgroup contracts (the K-split-through-partial-maps form runs one chunk per workgroup), `ydst` = output base.
 template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
-// (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
-__global__ __launch_bounds__(256 * KS)
-__attribute__((amdgpu_waves_per_eu(NB > 1 ? CT_NB_WAVES : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
-void wino_conv_kernel(WinoArgs a)
+__device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsigned nblocks, const int chunk0, float *const ydst)
 {
     static_assert(NB == 1 || (!MULTI && KS == 1), "NB > 1 is a single-chunk, unsplit shape");
     static_assert(!HEADS || (NB == 8 && WM == 1 && WN == 2), "the fused heads run on 64 px x 8 blocks of 32 couts");
@@ -96,13 +96,12 @@ void wino_conv_kernel(WinoArgs a)
     const int wave = wv & 3, kp = wv >> 2;
     const int li = lane & 15, lg = lane >> 4;
 
-    int bid = blockIdx.x;
     int cb;
     if (HEADS && a.headMajor) {
         // every head has its own 1 MB of Winograd weights: with the head as the SLOWEST index the workgroups resident
         // at any time work on <= 3 heads (3 MB per XCD L2 of 4 MB) instead of cycling through all of them (5.2 MB for
         // the five MOT heads: every XCD kept re-streaming the weights, 119 MB of fetches per launch in round 2)
-        const int per_head = (int)(gridDim.x / (unsigned)a.coutBlocks);
+        const int per_head = (int)(nblocks / (unsigned)a.coutBlocks);
         cb = bid / per_head;
         bid -= cb * per_head;
     } else {
@@ -135,7 +134,7 @@ void wino_conv_kernel(WinoArgs a)
     }
     f32x4 stage[W_NR];
     auto stage_load = [&](int chunk) {
-        const int coff = chunk * 64;
+        const int coff = (chunk0 + chunk) * 64;
 #pragma unroll
         for (int r = 0; r < W_NR; ++r) {
             const bool ok = goff[r] >= 0;
@@ -186,7 +185,7 @@ void wino_conv_kernel(WinoArgs a)
             for (int j = 0; j < 8; ++j) hacc[h2][j] = 0.0f;
     }
     const bool wide = (a.epi.Cout % 4 == 0) && (a.epi.ldy % 4 == 0) && (!a.epi.res || a.epi.ldr % 4 == 0) &&
-                      (((uintptr_t)a.epi.y & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
+                      (((uintptr_t)ydst & 15) == 0) && (!a.epi.res || ((uintptr_t)a.epi.res & 15) == 0);
     const int wr = kp * 4 + wave;                   // this wave's slot in the exchange buffer
     // epilogue operands of the (q, m-tile, n-tile) jobs this wave finalises (BN scale / shift of 4 couts), loaded before
     // the main loop (ct_common.h, ct_load_scale_shift: a ~1 us round trip off the end of every workgroup)
@@ -251,7 +250,7 @@ void wino_conv_kernel(WinoArgs a)
     // step s of a chunk (for this wave) = (slab kp*SPK + (s>>2), column c = s&3); position = wave*4 + c
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int s) {
         const int c = s & 3, kk = kp * SPK + (s >> 2);
-        const size_t slab = (size_t)(wave * 4 + c) * NCH16 + (size_t)min(chunk, a.nchunks - 1) * 4 + kk;
+        const size_t slab = (size_t)(wave * 4 + c) * NCH16 + (size_t)(chunk0 + min(chunk, a.nchunks - 1)) * 4 + kk;
 #pragma unroll
         for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
     };
@@ -424,7 +423,7 @@ void wino_conv_kernel(WinoArgs a)
                         f32x4 o;
 #pragma unroll
                         for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_plain(a.epi, raw[i], sc4[i], sh4[i], r4[i]);
-                        *reinterpret_cast<f32x4 *>(a.epi.y + pix * a.epi.ldy + c4) = o;
+                        *reinterpret_cast<f32x4 *>(ydst + pix * a.epi.ldy + c4) = o;
                     }
                 }
             } else if (co < a.epi.Cout) {
@@ -440,7 +439,7 @@ void wino_conv_kernel(WinoArgs a)
                         if (oy < a.epi.Ho && ox < a.epi.Wo) {
                             const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
                             const float r = a.epi.res ? a.epi.res[pix * a.epi.ldr + co] : 0.0f;
-                            a.epi.y[pix * a.epi.ldy + co] = ct_epilogue_plain(a.epi, p ? y1[ee] : y0[ee], sc, sh, r);
+                            ydst[pix * a.epi.ldy + co] = ct_epilogue_plain(a.epi, p ? y1[ee] : y0[ee], sc, sh, r);
                         }
                     }
                 }
@@ -491,6 +490,46 @@ void wino_conv_kernel(WinoArgs a)
         }
     }
     if (HEADS) { CT_STAMP(6); CT_STAMP_RT(7); }
+}
+
+template <int WM, int WN, int KS, bool MULTI, int NB = 1, bool HEADS = false>
+// (the single-chunk 256-thread shapes need 136 VGPRs unconstrained: capped at 128 = 4 waves per SIMD, no spills)
+__global__ __launch_bounds__(256 * KS)
+__attribute__((amdgpu_waves_per_eu(NB > 1 ? CT_NB_WAVES : ((!MULTI && KS == 1 && WM * WN <= 2) ? 4 : KS))))
+void wino_conv_kernel(WinoArgs a)
+{
+    wino_body<WM, WN, KS, MULTI, NB, HEADS>(a, (int)blockIdx.x, gridDim.x, 0, a.epi.y);
+}
+
+// Grouped PARTIAL launch (round 6; ct_dcn_v2_group, phase CT_DCN_OFFSETS, layers with ct_dcn_desc.w_off_winograd): the
+// offset/mask convs (DCN.conv_offset_mask, 3x3 Cin -> 27; dla.py:513 -> upstream dcn_v2.py) of up to four independent
+// layers in ONE launch, K-split over 64-channel chunks through partial maps: one workgroup = one 64-pixel Winograd block
+// x ONE chunk of ONE layer, whatever Cin -- 16 MFMA steps each, so the workgroups of a 512-channel layer at 16 x 16 and of a
+// 64-channel layer at 128 x 128 take the same time and a slot's convs fill the chip together.  Raw sums (no bias, no
+// sigmoid: the DCN launch applies both while it sums the chunks, fuse_offset == 2), channel pitch 32 (the packed
+// weights are zero past channel 27).  At 4 streams the per-layer conv launches this replaces cost 10-18 us each (16 per
+// frame batch: 218 of the 952 us of the DCN sequence, profiles/r06_a_dcn_slots_b4.txt).
+struct WinoGroup {
+    WinoArgs p[4];
+    int first[5];
+    int tiles[4];                 // workgroups per chunk of layer i
+    int n;
+};
+
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void wino_offsets_kernel(WinoGroup g)
+{
+    int bid = blockIdx.x;
+    int pi = 0;
+#pragma unroll
+    for (int i = 1; i < 4; ++i)
+        if (i < g.n && bid >= g.first[i]) pi = i;
+    const WinoArgs &a = g.p[pi];
+    bid -= g.first[pi];
+    const int tiles = g.tiles[pi];
+    const int split = bid / tiles;
+    bid -= split * tiles;
+    float *ydst = a.epi.y + (size_t)split * a.N * a.H * a.W * 32;
+    wino_body<1, 2, 1, false>(a, bid, (unsigned)tiles, split, ydst);
 }
 
 // U[pos][co][ci] = (G g G^T)[r][c], G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]]
@@ -597,6 +636,42 @@ int ct_conv2d_winograd(const ct_conv_desc *d, void *stream)
     }
     CT_CHECK_LAUNCH("ct_conv2d(winograd)");
     return rc;
+}
+
+// called by ct_dcn_v2_group (dcn_mfma.hip), phase CT_DCN_OFFSETS, for the layers that carry Winograd offset weights
+int ct_wino_offsets_group(const ct_wino_off_layer *L, int n, void *stream)
+{
+    if (n < 1 || n > 4) CT_FAIL_ARG("ct_wino_offsets_group: 1..4 layers");
+    WinoGroup g;
+    long blocks = 0;
+    for (int i = 0; i < n; ++i) {
+        const ct_wino_off_layer &l = L[i];
+        if (!l.x || !l.w_winograd || !l.part || l.Cin % 64 || l.Cin <= 0 || l.ldx % 4 || ((uintptr_t)l.x & 15) || ((uintptr_t)l.part & 15))
+            CT_FAIL_ARG("ct_wino_offsets_group: layer %d: bad arguments", i);
+        WinoArgs &a = g.p[i];
+        a.x = l.x; a.up = l.w_winograd;
+        a.N = l.N; a.H = l.H; a.W = l.W; a.Cin = l.Cin; a.ldx = l.ldx;
+        a.tilesX = ct_cdiv(l.W, 16); a.tilesY = ct_cdiv(l.H, 4); a.coutBlocks = 1; a.xcdPer = 0; a.headMajor = 0;
+        a.NT = 2; a.nchunks = 1;
+        a.epi.scale = nullptr; a.epi.shift = nullptr; a.epi.res = nullptr; a.epi.y = l.part;
+        a.epi.ldr = 0; a.epi.ldy = 32; a.epi.Cout = 32; a.epi.Ho = l.H; a.epi.Wo = l.W;
+        a.epi.flags = 0; a.epi.sig_lo = a.epi.sig_hi = 0; a.epi.dep_lo = a.epi.dep_hi = 0; a.epi.depth_scale = 1.0f;
+        a.hw2 = nullptr; a.hb2 = nullptr; a.hout = nullptr; a.hctot = 0;
+        for (int j = 0; j < CT_MAX_FUSED_HEADS; ++j) { a.hcout[j] = 0; a.hcoff[j] = 0; }
+        g.tiles[i] = l.N * a.tilesX * a.tilesY;
+        g.first[i] = (int)blocks;
+        blocks += (long)g.tiles[i] * (l.Cin / 64);
+        if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_wino_offsets_group: grid too large");
+    }
+    for (int i = n; i <= 4; ++i) g.first[i] = (int)blocks;
+    for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.tiles[i] = g.tiles[0]; }
+    g.n = n;
+    using C = WCfg<1>;
+    const size_t patch = sizeof(float) * (size_t)C::BUF;
+    const size_t exch = sizeof(float) * (size_t)(4 * 2 * 2 * 256 + 4 * 32 * 16);
+    hipLaunchKernelGGL(wino_offsets_kernel, dim3((unsigned)blocks), dim3(256), patch > exch ? patch : exch, (hipStream_t)stream, g);
+    CT_CHECK_LAUNCH("ct_dcn_v2(offset/mask convs, Winograd)");
+    return CT_OK;
 }
 
 // The heads of the network in one launch (ct_heads_desc): conv3x3 64 -> 256 + bias + ReLU -> conv1x1 256 -> c + bias (+ the

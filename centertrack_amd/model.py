@@ -551,7 +551,9 @@ class DLASegHIP(torch.nn.Module):
         is computed inside the DCN launch for Cin <= fuse_max_cin -- every workgroup of a split-K layer then repeats
         it over ALL input channels, 47 % of a 256-channel layer's time at one stream -- else ahead of the slot: K-split
         over 64-channel chunks in ONE CT_DCN_OFFSETS launch for all layers of the slot (split_offsets = 1, one
-        workgroup per 32-pixel tile and chunk whatever Cin) or by one conv launch per layer (0); every workgroup
+        workgroup per 32-pixel tile and chunk whatever Cin; split_offsets = 3, round 6: the same launch as Winograd
+        F(2x2,3x3) tiles, one workgroup per 64-pixel block and chunk) or by one conv launch per layer (0; 2: a Winograd
+        launch per layer writing raw sums); every workgroup
         contracts chunks_per_split 32-channel chunks, in steps of 16 * nkk channels (nkk = 2 / 4: 16 / 32 MFMAs per
         wave between barriers).  knobs[4] (round 3) = chunks per split of the SMALL slots: at one stream the three `proj`
         slots hold 256 .. 384 workgroups of 18 (chunk, tap) steps each on 768 workgroup slots -- one wave per SIMD,
@@ -624,7 +626,9 @@ class DLASegHIP(torch.nn.Module):
             own = ly.fused or part is not None
             dd = ops.make_dcn_desc(ly.x, om, pk['w'], ly.cout, pk['scale'], pk['shift'], True, ly.out, up=ly.up,
                                    split_k=ly.splits, algo=3264, om_partial=part, raw_offsets=raw,
-                                   w_off=pk['w_off'] if own else None, b_off=pk['b_off'] if own else None)
+                                   w_off=pk['w_off'] if own else None, b_off=pk['b_off'] if own else None,
+                                   # split_offsets == 3 (round 6): the slot's K-split OFFSETS launch in its Winograd form
+                                   w_off_wino=pk['w_off_wino'] if (split_offsets == 3 and not ly.fused) else None)
             need_c = ctypes.c_size_t(0)
             _lib.check(lib.ct_dcn_v2_group_plan(ctypes.byref(dd), ctypes.byref(need_c), None), 'DCN layer ' + ly.name)
             need = need_c.value
@@ -648,6 +652,10 @@ class DLASegHIP(torch.nn.Module):
         out = []
 
         def group(lys, phases, tag):
+            if phases == _lib.CT_DCN_MAIN:
+                # longest workgroups first (round 6): the dispatcher hands out workgroups in id order, so the layer whose
+                # workgroups run the most (chunk, tap) steps starts first and the short ones fill the tail of the launch
+                lys = sorted(lys, key=lambda ly: -((ly.x.C // 32 + ly.splits - 1) // ly.splits))
             for i in range(0, len(lys), 4):
                 part = lys[i:i + 4]
                 arr = (_lib.DcnDesc * len(part))()
@@ -757,7 +765,7 @@ class DLASegHIP(torch.nn.Module):
         for fuse_max in (0, 64, 128, 256):
             for cps in (2, 4, 8):
                 for nkk in (2, 4):
-                    for so in ((1, 2) if fuse_max < 256 else (1,)):
+                    for so in ((1, 2, 3) if fuse_max < 256 else (1,)):
                         small = [t for t, w in self._dcn_slot_sizes(layers, produced0, N, cps).items() if w < SMALL_SLOT_WGS]
                         for cs, un in (((0, 0), (0, 2)) + tuple((c, u) for c in (2, 1) if c < cps for u in (0, 1, 2)) if small
                                        else ((0, 0), (0, 2))):

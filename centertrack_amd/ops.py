@@ -145,7 +145,7 @@ def conv2d(x, wp, Cout, ks, stride=1, out=None, **kw):
 
 
 def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, split_k=0, algo=0, w_off=None,
-                  b_off=None, up=None, om_partial=None, raw_offsets=False):
+                  b_off=None, up=None, om_partial=None, raw_offsets=False, w_off_wino=None):
     """``w_off`` (packed conv_offset_mask weight) + ``b_off`` given: the offset/mask conv runs inside the DCN
     launch (``om`` may be None) -- or, with ``om_partial`` (a float buffer of ct_dcn_v2_offsets_bytes), K-split by
     the CT_DCN_OFFSETS launch; otherwise ``om`` is the precomputed NHWC offset/mask map."""
@@ -158,6 +158,8 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
         if om_partial is not None:
             d.fuse_offset = 3 if raw_offsets else 2          # (3: another launch writes the raw sums into om_partial)
             d.om_partial, d.om_partial_bytes = om_partial.data_ptr(), om_partial.numel() * om_partial.element_size()
+            if w_off_wino is not None and not raw_offsets:    # (the OFFSETS launch runs this layer's chunks as Winograd tiles)
+                d.w_off_winograd = w_off_wino.data_ptr()
     if up is not None:                 # (upsample_weight [4f^2,C], f, skip view, output view): fused IDAUp step
         w_up, f, skip, up_out = up
         d.up_w, d.up_f, d.up_skip, d.up_lds = w_up.data_ptr(), f, skip.ptr, skip.ld
@@ -174,7 +176,7 @@ def make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, workspace=None, spli
 
 
 def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_k=0, algo=0, w_off=None, b_off=None,
-           up=None, split_offsets=False):
+           up=None, split_offsets=False, w_off_wino=None):
     lib = _lib.load()
     if out is None:
         out = new_view(x.N, x.H, x.W, Cout, x.buf.device)
@@ -182,7 +184,7 @@ def dcn_v2(x, om, wp, Cout, scale=None, shift=None, relu=False, out=None, split_
     if split_offsets:
         part = torch.empty((x.C // 64) * x.N * x.H * x.W * 32, dtype=torch.float32, device=x.buf.device)
     d = make_dcn_desc(x, om, wp, Cout, scale, shift, relu, out, split_k=split_k, algo=algo, w_off=w_off, b_off=b_off,
-                      up=up, om_partial=part)
+                      up=up, om_partial=part, w_off_wino=w_off_wino if split_offsets else None)
     ws = None
     if split_k != 1:
         need = lib.ct_dcn_v2_workspace_bytes(ctypes.byref(d))

@@ -37,8 +37,9 @@ extern "C" {
 /* ABI version of THIS header: bumped whenever a descriptor struct changes layout or a tuning key changes meaning.  A
  * binding compares it with ct_version() of the loaded library before the first descriptor call (centertrack_amd/_lib.py
  * does).  100 = rounds 1-3; 101 = ct_conv_desc.proj_* (fused Tree.project), key "stem_rows", box probes;
- * 102 = ct_decode_desc.sparse (sparse heads). */
-#define CT_ABI_VERSION 102
+ * 102 = ct_decode_desc.sparse (sparse heads); 103 = the ct_calib_* box probes left this header and the library (they are
+ * diagnostics of the measuring box: tools/micro/probes.hip -> tools/micro/libct_probes.so). */
+#define CT_ABI_VERSION 103
 
 const char *ct_last_error(void);
 int ct_version(void);                      /* CT_ABI_VERSION the library was built with */
@@ -172,6 +173,11 @@ typedef struct ct_dcn_desc {
      * it directly from the partials (`y` is then never written), otherwise `y` holds the DCN output. */
     const float *up_w; int up_f; const float *up_skip; int up_lds; float *up_y; int up_ldy;
     float *om_partial; size_t om_partial_bytes; /* fuse_offset == 2: [Cin/64][N,H,W,32] floats, 3: [N,H,W,32] = ct_dcn_v2_offsets_bytes(d) */
+    const float *w_off_winograd;                /* (ABI 103) fuse_offset == 2 only, optional: conv_offset_mask.weight packed by
+                                                   ct_pack_winograd_weight.  The CT_DCN_OFFSETS launch then runs the K-split
+                                                   offset/mask convs of ALL such layers of the group as ONE Winograd F(2x2,3x3)
+                                                   launch (one workgroup per 64-pixel block and 64-channel chunk, 2.25x fewer
+                                                   MFMAs than the direct form); same partial maps, same consumer */
 } ct_dcn_desc;
 int ct_dcn_v2(const ct_dcn_desc *d, void *stream);
 size_t ct_dcn_v2_workspace_bytes(const ct_dcn_desc *d);
@@ -417,37 +423,6 @@ int ct_stream_synchronize(void *stream);
  * behind its last copy node, it lets the host see the end of the frame by polling a cache line instead of waiting in
  * the runtime (ct_frame_loop_wait) -- and independently of work that was enqueued behind the graph for the next frame. */
 int ct_signal_host(int *flag, int value, void *stream);
-/* Box calibration (diagnostics; no reference equivalent): `blocks` workgroups of 4 waves each run `iters` rounds of 16
- * independent-chain v_mfma_f32_16x16x4_f32 on registers -- the sustained fp32 MFMA rate of the box a bench line was
- * measured on (bench.py's "box_calibration").  out: DEVICE float[>= blocks * 256] (never written in practice). */
-int ct_calib_mfma(int blocks, int iters, float *out, void *stream);
-/* Box probes (round 5, diagnostics): what separates the "fast" from the "slow" boxes of a pool on the latency-bound
- * launches of a one-stream frame.  ct_calib_chase: ONE lane follows `hops` dependent loads through `ring` (uint32 index
- * of the next 128-byte line at every line start; a random cycle built by the caller; DEVICE memory of the footprint
- * under test or PINNED HOST memory); out (DEVICE uint64[3]) = last index, elapsed 100 MHz ticks, elapsed shader clocks.
- * ct_calib_stream: copy `bytes` (multiple of 16) with `blocks` workgroups of 256 lanes and 1 or 4 16-byte loads in
- * flight per lane.  ct_calib_launches: n dependent launches of a `blocks`-workgroup kernel over buf (DEVICE
- * float[blocks * 256]). */
-int ct_calib_chase(const unsigned *ring, int hops, unsigned start, unsigned long long *out, void *stream);
-/* ct_calib_chase_many: the same ring (nlines lines) followed by every lane of blocks x 256 from its own start line (out: DEVICE
- * uint32[blocks * 256], never written in practice). */
-int ct_calib_chase_many(const unsigned *ring, int hops, unsigned nlines, int blocks, unsigned *out, void *stream);
-int ct_calib_stream(const void *src, void *dst, size_t bytes, int blocks, int inflight, void *stream);
-/* ct_calib_write: fill = 0: one lane stores to `hops` consecutive 128-byte lines of buf, waiting for every store's
- * acknowledgement; out[0] (DEVICE uint64) = elapsed 100 MHz ticks.  fill = 1: blocks x 256 lanes stream 16-byte stores over
- * `bytes` (no loads). */
-/* ct_calib_ifetch: blocks x 256 lanes run 16 384 straight-line VALU instructions (64 KB of code) once: instruction-fetch path. */
-int ct_calib_ifetch(int blocks, float *out, void *stream);
-int ct_calib_write(void *buf, size_t bytes, int hops, int blocks, int fill, unsigned long long *out, void *stream);
-int ct_calib_launches(int n, int blocks, float *buf, void *stream);
-/* ct_calib_cu_map: `blocks` workgroups of 256 lanes with lds_bytes of dynamic LDS each record {HW_ID, XCC_ID, start, end (100 MHz
- * ticks)} into out (DEVICE uint32[4 * blocks]) and spin for spin_ticks in between: which CUs exist and how the dispatcher
- * loads them. */
-int ct_calib_cu_map(int blocks, int lds_bytes, int spin_ticks, unsigned *out, void *stream);
-/* ct_calib_xcd_stream: workgroup i copies chunk i (chunk_bytes, multiple of 16) of src to dst and records {HW_ID, XCC_ID,
- * start, end}: the memory rate every XCD reaches on its own (out: DEVICE uint32[4 * blocks]). */
-int ct_calib_xcd_stream(const void *src, void *dst, size_t chunk_bytes, int blocks, unsigned *out, void *stream);
-
 /* ---- the host loop of one frame of B streams, natively (round 3) ----------------------------------------------
  * Replaces, for the steady state of the tracking path, the per-frame host work of Detector.run
  * (src/lib/detector.py:139-165: process -> post_process -> merge_outputs -> tracker.step -> pre_images = images, and

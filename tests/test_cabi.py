@@ -36,7 +36,7 @@ def test_every_declared_symbol_is_exported(lib):
 def test_version_and_errors_without_gpu(lib):
     from centertrack_amd import _lib
     l = _lib.load()
-    assert l.ct_version() == _lib.ABI_VERSION == 102
+    assert l.ct_version() == _lib.ABI_VERSION == 103
     d = _lib.ConvDesc()
     assert l.ct_conv2d(ctypes.byref(d), None) == 1          # CT_ERR_ARG: null pointers
     assert b'null' in l.ct_last_error()

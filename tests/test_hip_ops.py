@@ -387,6 +387,26 @@ def test_dcn_with_split_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, al
     _close(out.to_nchw(), y, msg='DCN with K-split offset conv')
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k', [(1, 12, 20, 64, 64, 3264, 1), (2, 9, 21, 128, 64, 0, 2),
+                                                       (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8),
+                                                       (3, 17, 30, 128, 128, 43264, 2), (1, 7, 33, 256, 128, 64, 1)])
+def test_dcn_with_winograd_split_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, algo, split_k):
+    """fuse_offset = 2 with ct_dcn_desc.w_off_winograd (round 6): the K-split conv_offset_mask of the CT_DCN_OFFSETS launch
+    as Winograd F(2x2,3x3) tiles -- one workgroup per 64-pixel block and 64-channel chunk, raw partial maps -- summed + bias
+    + mask sigmoid by the main launch == upstream DCN.forward (oracle); ragged maps, odd sizes, several images"""
+    from centertrack_amd import ops
+    from oracle import dcn_v2 as odcn
+    x = F.relu(_rand(N, Cin, H, W, seed=240))
+    w, b = _rand(Cout, Cin, 3, 3, seed=241, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=242)
+    wo, bo = _rand(27, Cin, 3, 3, seed=243, scale=0.6 * (Cin * 9) ** -0.5), _rand(27, seed=244, scale=0.3)
+    y = odcn.dcn_forward(x, w, b, wo, bo)
+    wod = wo.to(device)
+    out = ops.dcn_v2(ops.view_from_nchw(x.to(device)), None, ops.pack_weight(w.to(device)), Cout, shift=b.to(device),
+                     algo=algo, split_k=split_k, w_off=ops.pack_weight(wod), b_off=bo.to(device),
+                     split_offsets=True, w_off_wino=ops.pack_winograd(wod))
+    _close(out.to_nchw(), y, msg='DCN with Winograd K-split offset conv')
+
+
 @pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k,conv_algo', [(1, 12, 20, 64, 64, 3264, 1, 202),
                                                                  (2, 9, 21, 128, 64, 43264, 2, 206),
                                                                  (1, 8, 8, 256, 256, 32128, 4, 0)])

@@ -6,7 +6,7 @@ predict the class.  Round 5 adds probes of what a latency-bo
 calls every DATA-path probe read the same in both states; the one that differs is instruction fetch
 (``launch_us.ifetch_64KB_code_256wg``: 39 us fast, 56 us slow -- DESIGN.md section 4):
 
-  chase_ns       dependent-load latency of ONE lane through a random ring of 128-byte lines (ct_calib_chase): 16 KB
+  chase_ns       dependent-load latency of ONE lane through a random ring of 128-byte lines (ctp_chase): 16 KB
                  (the CU's L1), 1 MB (one XCD's L2), 64 MB (Infinity Cache), 2 GiB (HBM) and 1 MB of PINNED HOST memory
                  (the PCIe round trip the decode's row stores and the end-of-frame flag see)
   shader_mhz     s_memtime clocks / s_memrealtime ticks of those one-lane kernels: the shader clock a nearly idle chip runs
@@ -15,7 +15,7 @@ calls every DATA-path probe read the same in both states; the one that differs i
   launch_us      dependent kernel boundary inside a captured graph: 200 launches of 1 / 256 workgroups; ``ifetch_64KB_code_*``:
                  64 KB of straight-line code run once per wave by 256 / 1024 workgroups (cold instruction cache)
   cu_map         hardware ids (XCD / shader engine / CU) and start / end times of every workgroup of three probe launches
-                 (ct_calib_cu_map): how many CUs each shader engine of each XCD holds on THIS chip (32 of 36 per XCD are
+                 (ctp_cu_map): how many CUs each shader engine of each XCD holds on THIS chip (32 of 36 per XCD are
                  enabled; which ones differs), and whether a "two workgroups per CU" launch finishes in one round
   sysfs          clock levels (sclk / mclk / fclk / socclk: active level and the table), partition modes and power cap as
                  the amdgpu driver reports them for the device
@@ -81,7 +81,7 @@ def chase(lib, st, device):
         for rep in range(3):
             # every repetition CONTINUES the chain where the last one stopped: re-walking the same 20 000 lines (2.5 MB)
             # would find them in the L2 whatever the footprint (the first version of this probe did: 90 ns "HBM")
-            lib.ct_calib_chase(ctypes.c_void_p(ring.data_ptr()), hops, start, ctypes.c_void_p(out.data_ptr()), st)
+            lib.ctp_chase(ctypes.c_void_p(ring.data_ptr()), hops, start, ctypes.c_void_p(out.data_ptr()), st)
             torch.cuda.synchronize()
             start, ticks, clocks = (int(v) for v in out.tolist())
             ns = ticks * 10.0 / hops
@@ -98,7 +98,7 @@ def chase(lib, st, device):
         best = None
         for rep in range(3):
             ring.copy_(src)                                       # the producer kernel
-            lib.ct_calib_chase(ctypes.c_void_p(ring.data_ptr()), 20000, (rep * 7919) % lines, ctypes.c_void_p(out.data_ptr()), st)
+            lib.ctp_chase(ctypes.c_void_p(ring.data_ptr()), 20000, (rep * 7919) % lines, ctypes.c_void_p(out.data_ptr()), st)
             torch.cuda.synchronize()
             _, ticks, clocks = (int(v) for v in out.tolist())
             ns = ticks * 10.0 / 20000
@@ -113,7 +113,7 @@ def chase(lib, st, device):
         sink = torch.zeros(1024 * 256, dtype=torch.int32, device=device)
         for blocks in (256, 1024):
             hops = 2000
-            ms = _timed(lambda: lib.ct_calib_chase_many(ctypes.c_void_p(ring.data_ptr()), hops, lines, blocks, ctypes.c_void_p(sink.data_ptr()), st), 2)
+            ms = _timed(lambda: lib.ctp_chase_many(ctypes.c_void_p(ring.data_ptr()), hops, lines, blocks, ctypes.c_void_p(sink.data_ptr()), st), 2)
             res['loaded_%s_%dwg_Mlines_per_s' % (name, blocks)] = round(blocks * 256 * hops / ms / 1e3)
         del ring
     return res, mhz
@@ -126,7 +126,7 @@ def stream(lib, st, device):
     b = torch.empty(n, device=device)
     res = {}
     for name, blocks, inflight in (('1GiB_1wave_per_simd_1load', 256, 1), ('1GiB_8wg_per_cu_4loads', 2048, 4)):
-        ms = _timed(lambda: lib.ct_calib_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n * 4, blocks, inflight, st), 3)
+        ms = _timed(lambda: lib.ctp_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), n * 4, blocks, inflight, st), 3)
         res[name] = round(2.0 * n * 4 / ms / 1e6)
     # the write side alone: the store round trip of one lane (a launch retires when its last store is acknowledged) and
     # store-only streaming at one wave per SIMD / eight workgroups per CU
@@ -134,18 +134,18 @@ def stream(lib, st, device):
     hops = 20000
     best = None
     for rep in range(3):
-        lib.ct_calib_write(ctypes.c_void_p(b.data_ptr()), n * 4, hops, 1, 0, ctypes.c_void_p(out.data_ptr()), st)
+        lib.ctp_write(ctypes.c_void_p(b.data_ptr()), n * 4, hops, 1, 0, ctypes.c_void_p(out.data_ptr()), st)
         torch.cuda.synchronize()
         ns = int(out[0].item()) * 10.0 / hops
         best = ns if best is None or ns < best else best
     res['store_ack_ns_one_lane'] = round(best, 1)
     for name, blocks in (('1GiB_fill_1wave_per_simd', 256), ('1GiB_fill_8wg_per_cu', 2048)):
-        ms = _timed(lambda: lib.ct_calib_write(ctypes.c_void_p(b.data_ptr()), n * 4, 0, blocks, 1, None, st), 3)
+        ms = _timed(lambda: lib.ctp_write(ctypes.c_void_p(b.data_ptr()), n * 4, 0, blocks, 1, None, st), 3)
         res[name] = round(n * 4 / ms / 1e6)
-    ms = _timed(lambda: lib.ct_calib_write(ctypes.c_void_p(b.data_ptr()), (1 << 22) * 4, 0, 256, 1, None, st), 20)
+    ms = _timed(lambda: lib.ctp_write(ctypes.c_void_p(b.data_ptr()), (1 << 22) * 4, 0, 256, 1, None, st), 20)
     res['16MiB_fill_1wave_per_simd'] = round((1 << 22) * 4 / ms / 1e6)
     m = 1 << 22           # 16 MiB: L2 / Infinity-Cache resident
-    ms = _timed(lambda: lib.ct_calib_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), m * 4, 256, 1, st), 20)
+    ms = _timed(lambda: lib.ctp_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), m * 4, 256, 1, st), 20)
     res['16MiB_1wave_per_simd_1load'] = round(2.0 * m * 4 / ms / 1e6)
     del a, b
     return res
@@ -159,17 +159,17 @@ def launches(lib, device):
     # 64 KB of straight-line code run once per wave (cold instruction cache at every launch): us per launch, 256 / 1024 workgroups
     for blocks in (256, 1024):
         st0 = _lib.stream_ptr()
-        ms = _timed(lambda: lib.ct_calib_ifetch(blocks, ctypes.c_void_p(buf.data_ptr()), st0), 10)
+        ms = _timed(lambda: lib.ctp_ifetch(blocks, ctypes.c_void_p(buf.data_ptr()), st0), 10)
         res['ifetch_64KB_code_%dwg' % blocks] = round(ms * 1e3, 2)
     N = 200
     for blocks in (1, 256):
         side = torch.cuda.Stream()
         with torch.cuda.stream(side):
-            lib.ct_calib_launches(4, blocks, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(side.cuda_stream))
+            lib.ctp_launches(4, blocks, ctypes.c_void_p(buf.data_ptr()), ctypes.c_void_p(side.cuda_stream))
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
-            lib.ct_calib_launches(N, blocks, ctypes.c_void_p(buf.data_ptr()), _lib.stream_ptr())
+            lib.ctp_launches(N, blocks, ctypes.c_void_p(buf.data_ptr()), _lib.stream_ptr())
         ms = _timed(g.replay, 5)
         res['graph_%dwg' % blocks] = round(ms * 1e3 / N, 2)
     return res
@@ -185,10 +185,10 @@ def cu_map(lib, st, device):
     for name, blocks, lds, ticks in (('512wg_2_per_cu_20us', 512, 64 * 1024, 2000), ('256wg_1_per_cu_20us', 256, 128 * 1024, 2000),
                                      ('1024wg_map', 1024, 16 * 1024, 200)):
         out = torch.zeros(4 * blocks, dtype=torch.int32, device=device)
-        lib.ct_calib_cu_map(blocks, lds, ticks, ctypes.c_void_p(out.data_ptr()), st)      # (first launch: code upload)
+        lib.ctp_cu_map(blocks, lds, ticks, ctypes.c_void_p(out.data_ptr()), st)      # (first launch: code upload)
         torch.cuda.synchronize()
         out.zero_()
-        lib.ct_calib_cu_map(blocks, lds, ticks, ctypes.c_void_p(out.data_ptr()), st)
+        lib.ctp_cu_map(blocks, lds, ticks, ctypes.c_void_p(out.data_ptr()), st)
         torch.cuda.synchronize()
         v = out.cpu().numpy().astype('uint32').reshape(blocks, 4)
         hw, xcc = v[:, 0], v[:, 1] & 0xf
@@ -219,7 +219,7 @@ def xcd_stream(lib, st, device):
     for name, blocks, chunk, reps in (('1GiB_256wg', 256, 4 << 20, 2), ('1GiB_2048wg', 2048, 512 << 10, 2), ('16MiB_256wg', 256, 64 << 10, 6)):
         out = torch.zeros(4 * blocks, dtype=torch.int32, device=device)
         for _ in range(reps):
-            lib.ct_calib_xcd_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), chunk, blocks, ctypes.c_void_p(out.data_ptr()), st)
+            lib.ctp_xcd_stream(ctypes.c_void_p(a.data_ptr()), ctypes.c_void_p(b.data_ptr()), chunk, blocks, ctypes.c_void_p(out.data_ptr()), st)
         torch.cuda.synchronize()
         v = out.cpu().numpy().astype('uint32').reshape(blocks, 4)
         xcc = v[:, 1] & 0xf
@@ -379,18 +379,20 @@ class ClockSampler(threading.Thread):
 def box_calibration(device=None, probes=True):
     import torch
     from centertrack_amd import _lib
-    lib = _lib.load()
+    from tools.micro import probes
+    lib = probes.load()                   # (tools/micro/libct_probes.so: the probes are not part of the product ABI)
+    plib = _lib.load()
     st = _lib.stream_ptr()
     device = device if device is not None else torch.device('cuda', torch.cuda.current_device())
     out = torch.zeros(1 << 20, device=device)
     iters, blocks = 50000, 512
-    ms = _timed(lambda: lib.ct_calib_mfma(blocks, iters, ctypes.c_void_p(out.data_ptr()), st))
+    ms = _timed(lambda: lib.ctp_mfma(blocks, iters, ctypes.c_void_p(out.data_ptr()), st))
     mfma = blocks * 4 * iters * 16 * 2.0 * 16 * 16 * 4 / ms / 1e9
     a = torch.empty(1 << 28, device=device)
     b = torch.empty(1 << 28, device=device)
-    d2d = 2.0 * a.numel() * 4 / _timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), a.numel() * 4, 0, st), 5) / 1e6
+    d2d = 2.0 * a.numel() * 4 / _timed(lambda: plib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), a.numel() * 4, 0, st), 5) / 1e6
     n = 1 << 22
-    d2d_small = 2.0 * n * 4 / _timed(lambda: lib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), n * 4, 0, st), 50) / 1e6
+    d2d_small = 2.0 * n * 4 / _timed(lambda: plib.ct_memcpy_async(b.data_ptr(), a.data_ptr(), n * 4, 0, st), 50) / 1e6
     del a, b
     res = {'device': torch.cuda.get_device_name(device), 'mfma_f32_tflops': round(mfma, 1),
            'd2d_1GiB_GBps': round(d2d), 'd2d_16MiB_GBps': round(d2d_small)}

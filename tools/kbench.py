@@ -141,11 +141,11 @@ def main():
              ('4x32x64/1', dict(algo=43264, split=1)), ('4x32x64/2', dict(algo=43264, split=2)), ('4x32x64/4', dict(algo=43264, split=4)),
              ('4x32x128/1', dict(algo=432128, split=1)), ('4x32x128/4', dict(algo=432128, split=4)),
              ('4F32x64/1', dict(algo=43264, split=1, fuse=1)), ('4F32x64/2', dict(algo=43264, split=2, fuse=1))]
-    if args.no_conv:       # (the DCN study of round 2: 4- vs 8-wave workgroups)
+    if args.no_conv and not args.dvariant:       # (the DCN study of round 2: 4- vs 8-wave workgroups)
         dvars = [v for v in dvars if v[0] in ('32x64/1', '32x64/2', '32x64/4', 'F32x64/1', 'F32x64/2', '32x128/1', '32x128/4') or v[0].startswith('4')]
     dcns = [c for c in dcns if args.dcn_layers in c[0]]
     if args.dvariant:
-        dvars = [v for v in dvars if v[0] == args.dvariant]
+        dvars = [v for v in dvars if v[0] in args.dvariant.split(',')]
     print('%-24s %3s %8s |' % ('layer', 'n', 'GFLOP') + ''.join(' %12s' % v[0] for v in dvars))
     dtot = {v[0]: 0.0 for v in dvars}
     for name, cnt, H, Cin, Cout in dcns:
