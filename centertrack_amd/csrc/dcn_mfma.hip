@@ -76,6 +76,31 @@ CT_DEFINE_STAMPS(dcn)       // (tools/dcn_phases.py; expands to nothing in the s
 #define CT_ABL 0
 #endif
 
+// sigmoid of the mask channels (upstream dcn_v2.py: mask = torch.sigmoid(mask)): v_exp_f32 + v_rcp_f32, 1 ulp each -- the
+// table build runs once per workgroup on the same SIMD lanes the MFMAs use, so its instruction count is kernel time
+__device__ __forceinline__ float dcn_mask_sigmoid(float v) { return __builtin_amdgcn_rcpf(1.0f + __expf(-v)); }
+
+// bilinear blend of the four corners' channel quads, w[c] = corner weight x mask: ((w0 c0 + w1 c1) + w2 c2) + w3 c3 per
+// channel (the order of the scalar expression), written on channel PAIRS so that every operation is one packed
+// instruction (v_pk_mul_f32 / v_pk_fma_f32: two lanes' worth of work in the issue slot of one) -- 8 instead of 12-13
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ f32x4 dcn_blend(const f32x4 w, const f32x4 (&c)[4])
+{
+    // (written as instructions: left to the compiler the same expression comes out as 4 v_mul + 4 v_fma + 4 v_pk_fma; the
+    //  weight pair (w0, w1) / (w2, w3) is one 64-bit operand whose low or high half op_sel broadcasts to both lanes)
+    const f32x2 w01 = w.lo, w23 = w.hi;
+    f32x2 lo, hi;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(lo) : "v"(w01), "v"(c[0].lo));
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(hi) : "v"(w01), "v"(c[0].hi));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(lo) : "v"(w01), "v"(c[1].lo));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(hi) : "v"(w01), "v"(c[1].hi));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(lo) : "v"(w23), "v"(c[2].lo));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel_hi:[0,1,1]" : "+v"(hi) : "v"(w23), "v"(c[2].hi));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(lo) : "v"(w23), "v"(c[3].lo));
+    asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(hi) : "v"(w23), "v"(c[3].hi));
+    return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
 template <int BM, int WN, bool FUSE, int NKK = 2>
 __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 {
@@ -152,7 +177,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float v = sum[e] + b;
-                if (co >= 18) v = 1.0f / (1.0f + expf(-v));
+                if (co >= 18) v = dcn_mask_sigmoid(v);
                 om_lds[(mt * 16 + (lane >> 4) * 4 + e) * 32 + co] = v;
             }
         };
@@ -165,19 +190,22 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     const int li = lane & 15, lg = lane >> 4;
     const int nt0 = cb * (WGN * WN) + wn * WN;
     const int NCH16 = a.Cin >> 4;
-    // branch-free B fragment loads (n-tiles past the padded Cout clamp to the last valid tile)
-    const float *bptr[WN];
+    // B fragment loads through a buffer descriptor (round 6): the per-lane part of the address is a constant VGPR (n-tiles past
+    // the padded Cout clamp to the last valid tile), the (tap, slab) part an SGPR offset -- no vector instruction per step.
+    // On this part fp32 MFMAs and vector instructions do not overlap on a SIMD (profiles/r06_b_dcn_loop_ablations_b8.txt:
+    // the launch takes MFMA time PLUS the time of everything else), so every VALU instruction of a step is paid in full.
+    const int slab_bytes = a.NT << 10;                          // one (tap, 16-channel slab): NT fragments of 1 KiB
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, 9 * NCH16 * slab_bytes, 0x00020000);
+    int bvo[WN];
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;
+    for (int nt = 0; nt < WN; ++nt) bvo[nt] = (min(nt0 + nt, a.NT - 1) << 10) + (lane << 4);
     auto load_b = [&](f32x4 (&b)[NKK][WN], int chunk, int tap) {
+        const int so = (tap * NCH16 + chunk * NKK) * slab_bytes;          // (uniform)
 #pragma unroll
-        for (int kk = 0; kk < NKK; ++kk) {
-            const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
+        for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
             for (int nt = 0; nt < WN; ++nt)
-                b[kk][nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
-        }
+                b[kk][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo[nt], so + kk * slab_bytes, 0));
     };
     // (chunk, tap) of a step index (chunk-outer / tap-inner order keeps the 9 taps' footprint of a chunk in L1),
     // clamped to the last valid step (extra fetches are never used)
@@ -203,17 +231,21 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         if (!a.ws) ct_load_scale_shift(a.epi, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
     }
 
-    // ---- sampling table: (pixel m, tap k) -> 4 corner offsets + 4 weights (mask folded in) ----
-    // (all offset/mask loads of a thread are issued before any of them is used: one round trip)
+    // ---- sampling table: (pixel m, tap k) -> 4 corner BYTE offsets + 4 weights (mask folded in) ----
+    // (all offset/mask loads of a thread are issued before any of them is used: one round trip; a wave whose lanes hold no
+    //  entry in a pass skips it -- 288 entries on 256 threads: the second pass is wave 0's alone)
     {
-        constexpr int TI = (BM * 9 + NTHR - 1) / NTHR;
+        constexpr int E = BM * 9;
+        constexpr int TI = (E + NTHR - 1) / NTHR;
+        const int ldx4 = a.ldx * 4, rowb = a.W * ldx4;
         float tdy[TI], tdx[TI], tmk[TI];
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+            if (wave * 64 + NTHR * i >= E) continue;                 // (uniform)
             const int it = tid + NTHR * i;
             const int m = it / 9, k = it - m * 9;
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
-            const bool in = it < BM * 9 && oy < a.H && ox < a.W;
+            const bool in = it < E && oy < a.H && ox < a.W;
             if (parts) {
                 // partial sums of the K-split offset conv: chunk order, then the bias (and the mask's sigmoid)
                 const size_t plane = (size_t)a.N * a.H * a.W * 32;
@@ -227,7 +259,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                 }
                 tdy[i] = dy + a.b_off[2 * kk];
                 tdx[i] = dx + a.b_off[2 * kk + 1];
-                tmk[i] = 1.0f / (1.0f + expf(-(mk + a.b_off[18 + kk])));
+                tmk[i] = dcn_mask_sigmoid(mk + a.b_off[18 + kk]);
                 continue;
             }
             const float *omp = fuse ? om_lds + (in ? m * 32 : 0) : omn + (in ? ((size_t)oy * a.W + ox) * a.ldom : 0);
@@ -237,25 +269,28 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
+            if (wave * 64 + NTHR * i >= E) continue;                 // (uniform)
             const int it = tid + NTHR * i;
-            if (it >= BM * 9) continue;
+            if (it >= E) continue;
             const int m = it / 9, k = it - m * 9;
+            const int ky = (k * 11) >> 5, kx = k - 3 * ky;            // k / 3, k % 3 for k < 9
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);   // m < BM
             int o[4] = {0, 0, 0, 0};
             float wgt[4] = {0.f, 0.f, 0.f, 0.f};
             if (oy < a.H && ox < a.W) {
                 const float dy = tdy[i], dx = tdx[i], mk = tmk[i];
-                const float ys = (float)(oy - 1 + k / 3) + dy;
-                const float xs = (float)(ox - 1 + k % 3) + dx;
+                const float ys = (float)(oy - 1 + ky) + dy;
+                const float xs = (float)(ox - 1 + kx) + dx;
                 if (ys > -1.0f && xs > -1.0f && ys < (float)a.H && xs < (float)a.W) {
                     const float yf = floorf(ys), xf = floorf(xs);
-                    const int y0 = (int)yf, x0 = (int)xf, y1 = y0 + 1, x1 = x0 + 1;
+                    const int y0 = (int)yf, x0 = (int)xf;
                     const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
-                    const bool vy0 = y0 >= 0, vy1 = y1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x1 <= a.W - 1;
-                    if (vy0 && vx0) { o[0] = (y0 * a.W + x0) * a.ldx; wgt[0] = hy * hx * mk; }
-                    if (vy0 && vx1) { o[1] = (y0 * a.W + x1) * a.ldx; wgt[1] = hy * lx * mk; }
-                    if (vy1 && vx0) { o[2] = (y1 * a.W + x0) * a.ldx; wgt[2] = ly * hx * mk; }
-                    if (vy1 && vx1) { o[3] = (y1 * a.W + x1) * a.ldx; wgt[3] = ly * lx * mk; }
+                    const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x0 + 1 <= a.W - 1;
+                    const int base = (y0 * a.W + x0) * ldx4;         // (only the valid corners use it)
+                    if (vy0 && vx0) { o[0] = base; wgt[0] = hy * hx * mk; }
+                    if (vy0 && vx1) { o[1] = base + ldx4; wgt[1] = hy * lx * mk; }
+                    if (vy1 && vx0) { o[2] = base + rowb; wgt[2] = ly * hx * mk; }
+                    if (vy1 && vx1) { o[3] = base + rowb + ldx4; wgt[3] = ly * lx * mk; }
                 }
             }
             *reinterpret_cast<int4 *>(tab_off + it * 4) = make_int4(o[0], o[1], o[2], o[3]);
@@ -273,14 +308,21 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     const int gk0 = (BM == 64) ? 0 : ((tl >> 2) & 1);
     const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);   // float offset inside a slab
     float *lds_g = lds_a;
+    // the corners come through a buffer descriptor of this image: table byte offset + the lane's (slab, quad) constant in the
+    // vector offset (one add per corner), the chunk in the scalar offset, the slab in the immediate
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xin), 0, (int)((((unsigned)a.H * a.W - 1u) * a.ldx + a.Cin) * 4u), 0x00020000);
+    const int tconst = (gk0 * 16 + gq * 4) * 4;
+    const int taddr = gm * (9 * 16);                             // byte offset of this pixel's first table entry
     // two gather stages in flight (register slots 0/1): the corner loads of step s+2 are issued
     // before the MFMAs of step s and consumed (blend + LDS store) after the MFMAs of step s+1
     f32x4 cv[2][GK][4];
     f32x4 gw[2];
     auto gather_load = [&](int slot, int chunk, int tap) {
-        const int4 o = *reinterpret_cast<const int4 *>(tab_off + (gm * 9 + tap) * 4);
-        gw[slot] = *reinterpret_cast<const f32x4 *>(tab_w + (gm * 9 + tap) * 4);
-        const float *base = xin + chunk * (16 * NKK) + gk0 * 16 + gq * 4;
+        const int ta = taddr + tap * 16;
+        const int4 o = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(tab_off) + ta);
+        gw[slot] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(tab_w) + ta);
+        const int so = chunk * (16 * NKK * 4);
         if (CT_ABL & 1) {
 #pragma unroll
             for (int kk = 0; kk < GK; ++kk)
@@ -290,17 +332,16 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         }
 #pragma unroll
         for (int kk = 0; kk < GK; ++kk) {
-            cv[slot][kk][0] = *reinterpret_cast<const f32x4 *>(base + o.x + kk * SSTR * 16);
-            cv[slot][kk][1] = *reinterpret_cast<const f32x4 *>(base + o.y + kk * SSTR * 16);
-            cv[slot][kk][2] = *reinterpret_cast<const f32x4 *>(base + o.z + kk * SSTR * 16);
-            cv[slot][kk][3] = *reinterpret_cast<const f32x4 *>(base + o.w + kk * SSTR * 16);
+            cv[slot][kk][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.x + tconst + kk * SSTR * 64, so, 0));
+            cv[slot][kk][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.y + tconst + kk * SSTR * 64, so, 0));
+            cv[slot][kk][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.z + tconst + kk * SSTR * 64, so, 0));
+            cv[slot][kk][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.w + tconst + kk * SSTR * 64, so, 0));
         }
     };
     auto gather_store = [&](int slot, int buf) {
 #pragma unroll
         for (int kk = 0; kk < GK; ++kk) {
-            const f32x4 v = gw[slot][0] * cv[slot][kk][0] + gw[slot][1] * cv[slot][kk][1] +
-                            gw[slot][2] * cv[slot][kk][2] + gw[slot][3] * cv[slot][kk][3];
+            const f32x4 v = dcn_blend(gw[slot], cv[slot][kk]);
             *reinterpret_cast<f32x4 *>(lds_g + buf * BUF + (gk0 + kk * SSTR) * SLAB + lslot) = v;
         }
     };
@@ -356,8 +397,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
             f32x4 v[GK];
 #pragma unroll
             for (int kk = 0; kk < GK; ++kk)
-                v[kk] = gw[P ^ 1][0] * cv[P ^ 1][kk][0] + gw[P ^ 1][1] * cv[P ^ 1][kk][1] +
-                        gw[P ^ 1][2] * cv[P ^ 1][kk][2] + gw[P ^ 1][3] * cv[P ^ 1][kk][3];
+                v[kk] = dcn_blend(gw[P ^ 1], cv[P ^ 1][kk]);
             // keep these global loads ahead of this step's MFMAs (hipcc otherwise sinks them to their
             // first use and exposes the full latency): neither VMEM nor MFMA may cross
             __builtin_amdgcn_sched_barrier(0x386);
@@ -395,21 +435,27 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     CT_STAMP_VAL(8, pi);
     CT_STAMP_VAL(9, nmax);
     if (a.ws) {
+        // raw tiles / split-K partials: buffer stores -- the lane's (pixel, cout) offset once per n-tile, row and pixel steps as
+        // scalar offsets; lanes past the map's edge or the padded Cout get an out-of-range offset the hardware drops
         const size_t Mtot = (size_t)a.N * a.H * a.W;
         float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(wsp, 0, (int)(Mtot * a.wsCout * 4), 0x00020000);
+        const int pixb = a.wsCout * 4, rowb2 = a.W * pixb;
+        const int oyb = oy0 + wm * WM;
+        const int px0 = ox0 + lg * 4;
 #pragma unroll
-        for (int mt = 0; mt < WM; ++mt) {
-            const int oy = oy0 + wm * WM + mt;
-            if (oy >= a.H) continue;
+        for (int nt = 0; nt < WN; ++nt) {
+            const int co = (nt0 + nt) * 16 + li;
+            const int vbase = (((n * a.H + oyb) * a.W + px0) * a.wsCout + co) * 4;
+            int vo[4];
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt) {
-                const int co = (nt0 + nt) * 16 + li;
-                if (co >= a.wsCout) continue;
+            for (int e = 0; e < 4; ++e) vo[e] = (co < a.wsCout && px0 + e < a.W) ? vbase : (int)0x80000000;
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int ox = ox0 + lg * 4 + e;
-                    if (ox < a.W) wsp[(((size_t)n * a.H + oy) * a.W + ox) * a.wsCout + co] = acc[mt][nt][e];
-                }
+            for (int mt = 0; mt < WM; ++mt) {
+                if (oyb + mt >= a.H) continue;                      // (uniform)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][e]), srs, vo[e], mt * rowb2 + e * pixb, 0);
             }
         }
     } else {
@@ -423,6 +469,16 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     CT_STAMP_RT(7);
 }
 
+// Measured and dropped in round 6 (profiles/r06_c_kbench_ws_b8.txt, r06_d_ws_ablations_b8.txt, r06_e_priorities_b8.txt): a
+// warp-specialised form of this kernel -- 64 px x 64 couts, four "matrix" waves that only read A / B fragments one step ahead
+// and issue MFMAs, four "gather" waves that gather, blend and write the A tile two steps ahead, one barrier per step; parity
+// green, 92 VGPRs.  64 -> 64 @ 128 x 128 x 8 streams: 146-148 us against 110-117 us for the 4-wave kernel.  The ablations say
+// why: without the MFMAs it takes 71 us, the MFMAs need 61.5 us, together 146 -- the gather waves make no progress while the
+// matrix wave of their SIMD issues (an fp32 MFMA runs on the SIMD's fp32 lanes: v_mfma_f32_16x16x4_f32 is 64 FLOP / clk / SIMD,
+// the vector rate, and vector instructions of OTHER waves do not slip in between), so specialisation serialises the gather
+// latency behind every MFMA burst instead of hiding it; s_setprio on either role changed nothing.  What a step costs on
+// this part is MFMA cycles PLUS 4 cycles per vector instruction, whichever wave issues it -- hence the instruction diet of
+// the kernel above (buffer addressing, packed blend, one-pass table) rather than a different division of labour.
 // Measured and dropped in round 2 (tools/kbench.py, profiles/r02_kbench_dcn_*.txt; every variant was parity-green):
 //   * 8 waves per workgroup, two K groups in phase (same steps, summed through LDS) and in ANTI-phase (one group's
 //     MFMAs beside the other's gather / blend / weight loads per barrier interval): 64->64 @128x128 x 8 streams 142-144

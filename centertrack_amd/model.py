@@ -26,7 +26,6 @@ WINOGRAD = os.environ.get('CENTERTRACK_WINOGRAD', '1') != '0'
 FUSE_HEADS = os.environ.get('CENTERTRACK_FUSE_HEADS', '1') != '0'
 FOLD_POOL = os.environ.get('CENTERTRACK_FOLD_POOL', '1') != '0'       # 2x2 max-pools as side outputs of the stride-2 convs
 FUSE_PROJ = os.environ.get('CENTERTRACK_FUSE_PROJ', '1') != '0'       # Tree.project computed by the tree1.conv1 launch (round 4)
-DCN_TILE64 = os.environ.get('CENTERTRACK_DCN_TILE64', '0') == '1'     # (A/B switch)
 
 
 def _fold_bn(sd, p):
@@ -663,8 +662,6 @@ class DLASegHIP(torch.nn.Module):
                 for j, ly in enumerate(part):
                     ctypes.memmove(ctypes.byref(arr[j]), ctypes.byref(ly.desc[0]), ctypes.sizeof(_lib.DcnDesc))
                     arr[j].algo = 43264 if ly.nkk == 4 else 3264
-                    if DCN_TILE64 and not any(l2.fused for l2 in part):      # (experiment: 64-pixel tiles, un-fused slots)
-                        arr[j].algo = 64
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
@@ -751,10 +748,11 @@ class DLASegHIP(torch.nn.Module):
         key = 'dcnplan4:%d,%d,%d' % (N, H, W)
         key3 = 'dcnplan3:%d,%d,%d' % (N, H, W)          # (round-2 tables: four knobs, no fine-split slots)
         autotune._load_file()
-        if key in autotune._CACHE:
+        retune = os.environ.get('CENTERTRACK_DCN_RETUNE', '0') == '1'      # (tools/retune_dcn.py: measure again)
+        if key in autotune._CACHE and not retune:
             knobs = tuple(int(v) for v in autotune._CACHE[key][:-1])
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
-        if key3 in autotune._CACHE and os.environ.get('CENTERTRACK_DCN_RETUNE', '0') != '1':
+        if key3 in autotune._CACHE and not retune:
             knobs = tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0, 0)
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         best = None

@@ -298,6 +298,7 @@ DCN_CASES = [
     (2, 7, 19, 128, 96, 3.0, 1, 43264),   # ... ragged, out-of-range taps
     (1, 6, 16, 256, 256, 1.0, 2, 432128), # ... 128 couts + split-K (2 units of 64 channels per split)
     (1, 4, 4, 512, 256, 1.0, 0, 43264),   # ... heuristic split-K
+    (3, 17, 30, 128, 64, 1.0, 4, 3264),   # one chunk per split (9 steps: odd), odd map, three images
 ]
 
 
@@ -389,7 +390,8 @@ def test_dcn_with_split_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, al
 
 @pytest.mark.parametrize('N,H,W,Cin,Cout,algo,split_k', [(1, 12, 20, 64, 64, 3264, 1), (2, 9, 21, 128, 64, 0, 2),
                                                        (1, 8, 8, 256, 256, 32128, 4), (1, 6, 6, 512, 256, 3264, 8),
-                                                       (3, 17, 30, 128, 128, 43264, 2), (1, 7, 33, 256, 128, 64, 1)])
+                                                       (3, 17, 30, 128, 128, 43264, 2), (1, 7, 33, 256, 128, 64, 1),
+                                                       (2, 17, 30, 128, 64, 128, 2)])
 def test_dcn_with_winograd_split_offset_conv_is_DCN_module(device, N, H, W, Cin, Cout, algo, split_k):
     """fuse_offset = 2 with ct_dcn_desc.w_off_winograd (round 6): the K-split conv_offset_mask of the CT_DCN_OFFSETS launch
     as Winograd F(2x2,3x3) tiles -- one workgroup per 64-pixel block and 64-channel chunk, raw partial maps -- summed + bias
@@ -569,6 +571,66 @@ def test_dcn_group_launch_equals_single_launches(device, galgo):
     again = results()
     for i in range(NL):
         assert torch.equal(again[i], single[i].to_nchw()), 'separate phases, layer %d' % i
+
+
+def test_dcn_group_launch_with_winograd_offsets(device):
+    """ct_dcn_v2_group with the Winograd OFFSETS launch (round 6): three independent layers -- offset/mask map read from HBM +
+    IDAUp step behind split-K; K-split offset conv as Winograd tiles (w_off_winograd) with four K splits; the same unsplit
+    -- in ONE OFFSETS, ONE MAIN and ONE FINISH launch == the oracle, and bit-identical to the same layers launched alone"""
+    import ctypes
+    from centertrack_amd import _lib, ops
+    from oracle import dcn_v2 as odcn
+    lib = _lib.load()
+    specs = [dict(N=1, H=6, W=10, Cin=128, Cout=64, split=2, offs='map', f=2),
+             dict(N=2, H=5, W=17, Cin=256, Cout=128, split=4, offs='wino', f=0),
+             dict(N=1, H=12, W=20, Cin=64, Cout=64, split=1, offs='wino', f=0)]
+    descs, keep, want, single, outs = [], [], [], [], []
+    for i, sp in enumerate(specs):
+        N, H, W, Cin, Cout = sp['N'], sp['H'], sp['W'], sp['Cin'], sp['Cout']
+        x = F.relu(_rand(N, Cin, H, W, seed=360 + i))
+        w, b = _rand(Cout, Cin, 3, 3, seed=370 + i, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=380 + i)
+        wo, bo = _rand(27, Cin, 3, 3, seed=390 + i, scale=0.5 * (Cin * 9) ** -0.5), _rand(27, seed=400 + i, scale=0.3)
+        scale = torch.rand(Cout, generator=torch.Generator().manual_seed(410 + i)) + 0.5
+        y = F.relu(odcn.dcn_forward(x, w, None, wo, bo) * scale.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+        xv = ops.view_from_nchw(x.to(device))
+        wod = wo.to(device)
+        wp, wop, wow = ops.pack_weight(w.to(device)), ops.pack_weight(wod), ops.pack_winograd(wod)
+        sc_d, b_d, bo_d = scale.to(device), b.to(device), bo.to(device)
+        om = None
+        if sp['offs'] == 'map':
+            om = ops.conv2d(xv, wop, 27, 3, 1, shift=bo_d, sig=(18, 27), out=ops.new_view(N, H, W, 32, device))
+        up = up1 = None
+        out = ops.new_view(N, H, W, Cout, device)
+        if sp['f']:
+            f = sp['f']
+            wup, skip = _rand(Cout, 1, 2 * f, 2 * f, seed=420 + i), _rand(N, Cout, H * f, W * f, seed=430 + i)
+            y = F.conv_transpose2d(y, wup, None, stride=f, padding=f // 2, groups=Cout) + skip
+            wt, sv = ops.upsample_weight(wup.to(device)), ops.view_from_nchw(skip.to(device))
+            up = (wt, f, sv, ops.new_view(N, H * f, W * f, Cout, device))
+            up1 = (wt, f, sv, ops.new_view(N, H * f, W * f, Cout, device))
+        want.append(y)
+        wino = sp['offs'] == 'wino'
+        fuse_kw = dict(w_off=wop, b_off=bo_d) if wino else {}
+        part = torch.empty((Cin // 64) * N * H * W * 32, device=device) if wino else None
+        d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sp['split'], algo=3264, up=up, om_partial=part,
+                              w_off_wino=wow if wino else None, **fuse_kw)
+        assert bool(d.w_off_winograd) == wino
+        need = lib.ct_dcn_v2_group_workspace_bytes(ctypes.byref(d))
+        ws = torch.empty(max(need, 4) // 4, device=device)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), need
+        descs.append(d)
+        outs.append(up[3] if up is not None else out)
+        keep += [xv, wp, wop, wow, sc_d, b_d, bo_d, om, up, ws, out, part]
+        one = ops.dcn_v2(xv, om, wp, Cout, sc_d, b_d, relu=True, split_k=sp['split'], algo=3264, up=up1, split_offsets=wino,
+                         w_off_wino=wow if wino else None, **fuse_kw)
+        single.append(up1[3] if up1 is not None else one)
+    arr = (_lib.DcnDesc * len(specs))(*descs)
+    _lib.check(lib.ct_dcn_v2_group(arr, len(specs), _lib.CT_DCN_OFFSETS | _lib.CT_DCN_MAIN | _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'group')
+    torch.cuda.synchronize()
+    for i in range(len(specs)):
+        got = outs[i].to_nchw()
+        _close(got, want[i], msg='group layer %d vs oracle' % i)
+        assert torch.equal(got, single[i].to_nchw()), 'group layer %d vs single launch' % i
 
 
 @pytest.mark.parametrize('with_img,with_hm,shape', [(True, True, (2, 24, 40)), (True, False, (1, 16, 32)),

@@ -142,3 +142,27 @@ def test_restatements_match_the_upstream_build():
         np.testing.assert_allclose(odcn.dcn_v2_conv(x, off, mask, w, b).numpy(), want, atol=2e-5, rtol=1e-5)
         np.testing.assert_allclose(dcn_v2_c.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy()), want,
                                    atol=2e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize('scale,H,W,Ci,Co,seed', [(0.5, 9, 11, 6, 7, 0), (3.0, 12, 10, 4, 6, 1), (12.0, 8, 8, 3, 5, 2)])
+def test_restatements_match_torchvision_deform_conv2d(scale, H, W, Ci, Co, seed):
+    """Auto-skipping THIRD-PARTY pin of SURVEY row a6: `torchvision.ops.deform_conv2d(x, offset, w, b,
+    padding=1, mask=mask)` is the public equivalent of upstream DCNv2 (same (dy, dx)-interleaved offset channels, same
+    modulation) -- what `dla.py:513-518` computes through `DCN`.  torchvision is not installed in this image
+    (the test skips); on any image that has the wheel it pins the three restatements to code none of them was derived from."""
+    tv = pytest.importorskip('torchvision')
+    from torchvision.ops import deform_conv2d
+    from oracle import dcn_v2_gridsample as gs
+    g = torch.Generator().manual_seed(500 + seed)
+    x = torch.randn((2, Ci, H, W), generator=g)
+    w = torch.randn((Co, Ci, 3, 3), generator=g)
+    b = torch.randn((Co,), generator=g)
+    off = torch.randn((2, 18, H, W), generator=g) * scale
+    mask = torch.rand((2, 9, H, W), generator=g)
+    want = deform_conv2d(x, off, w, b, padding=1, mask=mask).numpy()
+    tol = 1e-5 * max(1.0, float(np.abs(want).max()))
+    np.testing.assert_allclose(odcn.dcn_v2_conv(x, off, mask, w, b).numpy(), want, rtol=0, atol=tol)
+    np.testing.assert_allclose(gs.dcn_v2_conv(x, off, mask, w, b).numpy(), want, rtol=0, atol=tol)
+    yc = dcn_v2_c.dcn_v2_conv(x.numpy(), off.numpy(), mask.numpy(), w.numpy(), b.numpy())
+    np.testing.assert_allclose(yc, want, rtol=0, atol=tol)
+    assert tv is not None

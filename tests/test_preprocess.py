@@ -175,3 +175,21 @@ def test_imread_bgr_is_cv2_imread_for_lossless_files(tmp_path):
     gray = np.random.RandomState(4).randint(0, 256, (9, 11)).astype(np.uint8)
     Image.fromarray(gray).save(tmp_path / 'g.png')                 # (cv2.imread's default flag also yields 3 channels)
     np.testing.assert_array_equal(imread_bgr(tmp_path / 'g.png'), np.repeat(gray[:, :, None], 3, 2))
+
+
+@pytest.mark.parametrize('h,w,inp_h,inp_w', [(360, 480, 128, 160), (375, 1242, 96, 320), (120, 90, 64, 64), (33, 47, 64, 96)])
+def test_warp_is_cv2_warpAffine_bit_for_bit(h, w, inp_h, inp_w):
+    """Auto-skipping THIRD-PARTY pin of SURVEY rows a2 / f1: the reference's own call,
+    `cv2.warpAffine(image, trans_input, (inp_width, inp_height), flags=cv2.INTER_LINEAR)` followed by
+    `((inp / 255. - mean) / std).transpose(2, 0, 1)` (detector.py:218-224), against ct_preprocess_image on the crop of
+    `_transform_scale` and on a rotated map.  cv2 is not installed in this image (the test skips); where it is, the
+    fixed-point restatement of host, device and oracle is pinned to OpenCV itself."""
+    cv2 = pytest.importorskip('cv2')
+    rs = np.random.RandomState(h * 7 + w)
+    img = rs.randint(0, 256, (h, w, 3)).astype(np.uint8)
+    meta = make_meta(inp_h, inp_w, h, w)
+    rot = get_affine_transform(np.array([w / 2., h / 2.], np.float32), max(h, w) * 0.7, 25, [inp_w, inp_h])
+    for t in (meta['trans_input'], rot):
+        ref = cv2.warpAffine(img, np.asarray(t, np.float64), (inp_w, inp_h), flags=cv2.INTER_LINEAR)
+        np.testing.assert_array_equal(_run(img, t, inp_w, inp_h), _norm(ref))
+        np.testing.assert_array_equal(oimage.pre_process_image(img, t, inp_w, inp_h, MEAN, STD), _norm(ref))

@@ -1,13 +1,14 @@
 #!/usr/bin/env python
-"""Re-measure the DCN schedule knobs (`dcnplan4:N,H,W`, five knobs since round 3) for every (streams, size) the pinned table holds and write the
+"""Re-measure the DCN schedule knobs (`dcnplan4:N,H,W`, six knobs; round 6 added offset mode 3) for every (streams, size) the pinned table holds and write the
 merged table: run on the GPU box with CENTERTRACK_TUNE_CACHE=<out.json>; the conv entries of the pinned table are
-kept, `dcnplan2:*` / `dcnplan3:*` entries dropped.  Optional further arguments: N,H,W shapes to restrict the run to.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
+kept, older `dcnplan3:*` / `dcnplan4:*` entries of a re-measured shape dropped.  Optional further arguments: N,H,W shapes to restrict the run to.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
 import json
 import os
 import sys
 
 out = sys.argv[1]
 os.environ['CENTERTRACK_TUNE_CACHE'] = out
+os.environ['CENTERTRACK_DCN_RETUNE'] = '1'
 os.environ.setdefault('CENTERTRACK_TUNE_VERBOSE', '')
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import torch  # noqa: E402
@@ -36,8 +37,9 @@ for (N, H, Wd) in shapes:
     torch.cuda.empty_cache()
 merged = {k: list(v) for k, v in table.items() if not k.startswith('dcnplan')}       # (the cache file holds un-pinned keys only)
 merged.update({k: list(v) for k, v in autotune._CACHE.items() if not k.startswith(('dcnplan2:', 'dcnplan3:'))})
-if len(sys.argv) > 2:       # partial run: keep the round-2 schedules of the other shapes
-    merged.update({k: list(v) for k, v in table.items() if k.startswith('dcnplan3:') and k.replace('dcnplan3', 'dcnplan4') not in merged})
+# shapes that were not re-measured keep their older schedules
+done = {k.split(':')[1] for k in merged if k.startswith('dcnplan4:')}
+merged.update({k: list(v) for k, v in table.items() if k.startswith('dcnplan') and k.split(':')[1] not in done})
 with open(out, 'w') as f:
     json.dump(dict(sorted(merged.items())), f, indent=0)
 print('%d keys -> %s' % (len(merged), out))
