@@ -267,7 +267,10 @@ def cpu_baseline(cfg, heads, sd, frames_cpu, metas, opt_kw, nframes, sweep):
 
 # BASELINE.json configs[2..4] at their per-GPU batch + the reference's own MOT input size (datasets/mot.py:15): measured by
 # the DEFAULT invocation after the headline and appended to its line as "configs"  -- never `value`
-EXTRA_CONFIGS = (('kitti_1280x384', 4), ('coco_512', 4), ('nusc_800x448', 4), ('mot17_544x960', 1))
+# BASELINE configs 3-5 at their per-GPU batch, the reference's own MOT size, and the 32-stream end points of north_star's
+# synthetic sweep (driver-witnessed instead of builder-only); (name, streams, timed steps or 0 = --extra-steps)
+EXTRA_CONFIGS = (('kitti_1280x384', 4, 0), ('coco_512', 4, 0), ('nusc_800x448', 4, 0), ('mot17_544x960', 1, 0),
+                 ('mot17_512', 32, 3), ('nusc_800x448', 32, 3))
 
 
 def main():
@@ -284,7 +287,23 @@ def main():
     torch.cuda.set_device(local)
     device = torch.device('cuda', local)
     env = (rank, world, device)
-    out = measure(args, env, headline=True)
+    if args.sparse_heads:
+        #  the opt-in mode is never the headline: `value` is the dense figure of the same workload, the sparse
+        # figure goes under "sparse_heads" of the same line
+        dense = argparse.Namespace(**vars(args))
+        dense.sparse_heads = False
+        out = measure(dense, env, headline=True)
+        sp = argparse.Namespace(**vars(args))
+        sp.no_resident = sp.no_cpu_baseline = sp.no_roofline = True
+        try:
+            o = measure(sp, env, headline=False)
+            out['sparse_heads'] = {'fps': o['value'], 'device_ms_per_frame_batch': o.get('device_ms_per_frame_batch'),
+                                   'launches_per_frame': o.get('launches_per_frame'), 'workload': o['config']['workload'],
+                                   'note': 'opt.sparse_heads (opt-in, not the reference\'s computation graph); never `value`'}
+        except Exception as e:
+            out['sparse_heads'] = {'error': repr(e)}
+    else:
+        out = measure(args, env, headline=True)
     default_workload = (args.config == 'mot17_512' and args.streams <= 1 and not args.height and not args.width
                         and not args.no_graph and not args.sparse_heads)
 
@@ -309,10 +328,10 @@ def main():
             'generic_decode reads at K pixels): the same workload with those heads evaluated at the K winners only; rows '
             'equal the dense path\'s (tests/test_hip_sparse_heads.py); never `value`'))
         out['configs'] = []
-        for name, streams in EXTRA_CONFIGS:
+        for name, streams, nsteps in EXTRA_CONFIGS:
             a = argparse.Namespace(**vars(args))
             a.config, a.streams, a.frames_per_step = name, streams, 0
-            a.steps, a.warmup = args.extra_steps, 2
+            a.steps, a.warmup = (nsteps or args.extra_steps), 2
             a.no_resident = a.no_cpu_baseline = True
             a.raw_u8 = False
             t0 = time.perf_counter()
@@ -323,15 +342,19 @@ def main():
                     'fps': o['value'], 'steps': a.steps, 'frames_per_step': o['config']['frames_per_step'],
                     'timed_region_s': o['timed_region_s'], 'ms_per_frame_batch': o['ms_per_frame_batch'],
                     'device_ms_per_frame_batch': o['device_ms_per_frame_batch'], 'launches_per_frame': o['launches_per_frame'],
-                    'roofline': {'kernel': 'dcn_mfma_kernel (all DCNv2 launches of a frame batch)', 'bound': 'mfma',
-                                 'achieved': o['roofline']['achieved'], 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
-                                 'frac': o['roofline']['frac'], 'total_ms': o['roofline']['total_ms']},
-                    'roofline_conv': {'achieved': o['roofline_conv']['achieved'], 'frac': o['roofline_conv']['frac'],
-                                      'total_ms': o['roofline_conv']['total_ms'],
-                                      'algorithmic_tflops': o['roofline_conv']['algorithmic_tflops']},
                     'mean_detections_per_frame': o['config']['mean_detections_per_frame'],
                     'plan_hash': o['plan_hash'], 'wall_s': round(time.perf_counter() - t0, 1)})
-                if True:
+                if o.get('roofline') is not None:          # (absent with --no-roofline)
+                    out['configs'][-1]['roofline'] = {
+                        'kernel': 'dcn_mfma_kernel (all DCNv2 launches of a frame batch)', 'bound': 'mfma',
+                        'achieved': o['roofline']['achieved'], 'peak': PEAK_FP32_TFLOPS, 'unit': 'TFLOP/s',
+                        'frac': o['roofline']['frac'], 'total_ms': o['roofline']['total_ms']}
+                if o.get('roofline_conv') is not None:
+                    out['configs'][-1]['roofline_conv'] = {
+                        'achieved': o['roofline_conv']['achieved'], 'frac': o['roofline_conv']['frac'],
+                        'total_ms': o['roofline_conv']['total_ms'],
+                        'algorithmic_tflops': o['roofline_conv']['algorithmic_tflops']}
+                if streams <= 4:                           # (the opt-in mode beside the BASELINE batches only)
                     sp = sparse_line(name, streams)
                     if sp.get('active') or 'error' in sp:
                         out['configs'][-1]['sparse_heads'] = sp
@@ -458,15 +481,27 @@ def measure(args, env, headline=True):
         out['gathered'] = gathered
     clocks = None
     if not args.no_resident:
-        from tools import box_calib
         frames = [f.to(device) for f in frames_cpu]
-        sampler = box_calib.ClockSampler() if rank == 0 else None      # (reads sysfs beside the loop: never the headline)
-        if sampler is not None:
-            sampler.start()
         dt2, nfr2, _ = timed(lambda t: frames[t % T], args.steps)
-        if sampler is not None:
-            clocks = sampler.summary()
         out['resident_frames_fps'] = round(total_streams * nfr2 / dt2, 2)
+        if headline:
+            # clock levels under load: sampled in a SEPARATE, untimed pass of the same loop (the sampler thread
+            # polls sysfs from this process and would perturb a timed loop); every rank runs the pass (it holds barriers),
+            # rank 0 samples; a failure of the sampler never costs the line
+            sampler = None
+            if rank == 0:
+                try:
+                    from tools import box_calib
+                    sampler = box_calib.ClockSampler()
+                    sampler.start()
+                except Exception as e:
+                    sampler, clocks = None, {'error': repr(e)}
+            timed(lambda t: frames[t % T], max(2, args.steps // 4))
+            if sampler is not None:
+                try:
+                    clocks = sampler.summary()
+                except Exception as e:
+                    clocks = {'error': repr(e)}
     if rank == 0:
         ctx = det._ctx
         # device-only time of one frame (graph replay or eager launches), HIP events on the launch stream

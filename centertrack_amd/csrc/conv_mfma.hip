@@ -142,24 +142,24 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
             const int iy = iy0 + py, ix = ix0 + px;
             loff[r] = kk * C::SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
             goff[r] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                          ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4)
-                          : -1;
+                          ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4) * 4
+                          : (int)0x80000000;
         } else {
             loff[r] = -1;
-            goff[r] = -1;
+            goff[r] = (int)0x80000000;
         }
     }
     f32x4 stage[C::NR];
-    // Branch-free staging: out-of-image / padding items read element 0 and are zeroed by a
-    // select, so the compiler can count outstanding loads exactly (no vmcnt(0) drains).
+    // Branch-free staging through a buffer descriptor of this image (round 6): the item's byte offset in the vector offset,
+    // the chunk in the scalar offset; out-of-image / padding items carry an out-of-range offset and the hardware returns
+    // zeros for them -- no address arithmetic, no select (every VALU instruction is paid on top of the fp32 MFMA time)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xin), 0, (int)((((unsigned)a.H * a.W - 1u) * a.ldx + a.Cin) * 4u), 0x00020000);
     auto stage_load = [&](int chunk) {
-        const int coff = chunk * (16 * NKK);
+        const int coff = chunk * (16 * NKK * 4);
 #pragma unroll
-        for (int r = 0; r < C::NR; ++r) {
-            const bool ok = goff[r] >= 0;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
-            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int r = 0; r < C::NR; ++r)
+            stage[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[r], coff, 0));
     };
     auto stage_store = [&](int buf) {
         float *dst = lds + buf * C::BUF;
@@ -178,14 +178,16 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
     const int NCH16 = a.Cin >> 4;
     // B fragments: one contiguous 1 KiB block per (tap, 16-ch slab, n-tile); n-tiles past the
     // padded Cout are clamped to the last valid tile (their results are never stored).
-    const float *bptr[WN];
+    // (round 6: the lane's part of the address is a constant vector offset, the (tap, slab) part a scalar offset)
+    const int slab_bytes = a.NT << 10;                 // bytes between consecutive 16-ch slabs
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, KS * KS * NCH16 * slab_bytes, 0x00020000);
+    int bvo[WN];
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)a.NT << 8;      // floats between consecutive 16-ch slabs
+    for (int nt = 0; nt < WN; ++nt) bvo[nt] = (min(nt0 + nt, a.NT - 1) << 10) + (lane << 4);
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int kk, int tap) {
-        const size_t slab = (size_t)tap * NCH16 + (size_t)chunk * NKK + kk;
+        const int so = (tap * NCH16 + chunk * NKK + kk) * slab_bytes;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
+        for (int nt = 0; nt < WN; ++nt) b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo[nt], so, 0));
     };
 
     // epilogue operands (BN scale / shift of this wave's couts) first: they arrive while the main loop runs
@@ -262,11 +264,10 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
                 const int ky = tap / KS, kx = tap % KS;
                 if constexpr (PROJ) {
                     if (tap == 0 && proj) {     // the slab's 1x1 weights: 8 taps ahead of their MFMAs
-                        const size_t pslab = (size_t)c * NKK + kk;
+                        const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.proj_wp), 0, NCH16 * slab_bytes, 0x00020000);
 #pragma unroll
                         for (int nt = 0; nt < WN; ++nt)
-                            bproj[nt] = *reinterpret_cast<const f32x4 *>(a.proj_wp + ((size_t)min(nt0 + nt, a.NT - 1) << 8) +
-                                                                         (lane << 2) + pslab * slab_stride);
+                            bproj[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, bvo[nt], (c * NKK + kk) * slab_bytes, 0));
                     }
                 }
                 f32x4 af[WM];

@@ -784,7 +784,6 @@ struct SparseArgs {
     int flip_mode[CT_NUM_HEADS];     // per sparse head: 0 = image b alone, 1 = (v + v') / 2, 2 = the same with even channels of v' negated
     const unsigned long long *winners;
     float *partial;                  // [B * tiles][nheads][2 passes][4][16][8] partial head outputs (one hidden quarter each)
-    unsigned *arrive;                // (reserved: the arrival counters of the first form)
     float *out, *host_out;
     int *done_flag; unsigned *done_counter;
     int B, h, w, K, F, tiles;        // tiles = ceil(K / 16) winner tiles per image
@@ -958,6 +957,18 @@ int check(const ct_decode_desc *d, const char *who)
     if (d->K <= 0 || d->K > MAXK) CT_FAIL_ARG("%s: K=%d out of range (1..%d)", who, d->K, MAXK);
     if ((long)d->h * d->w < d->K) CT_FAIL_ARG("%s: h*w=%ld < K=%d (torch.topk would raise too)", who, (long)d->h * d->w, d->K);
     if ((double)d->C * d->h * d->w >= 4294967295.0) CT_FAIL_ARG("%s: C*h*w too large", who);
+    // the sparse-heads descriptor is validated HERE, for every entry point that reads it (ct_decode_workspace_bytes sizes the
+    // workspace from nheads, ct_decode_row_floats walks head[]: a bad descriptor must be an error, not a wrapped size)
+    if (const ct_sparse_heads_desc *sp = d->sparse) {
+        if (sp->nheads < 1 || sp->nheads > CT_NUM_HEADS || !sp->feat || sp->ldf < 64 || (sp->ldf & 3) || ((uintptr_t)sp->feat & 15))
+            CT_FAIL_ARG("%s: sparse heads need 1..%d heads and a 16-byte aligned NHWC feature view of >= 64 channels", who, CT_NUM_HEADS);
+        for (int i = 0; i < sp->nheads; ++i) {
+            if (sp->head[i] < 0 || sp->head[i] >= CT_NUM_HEADS || !sp->w1[i] || !sp->b1[i] || !sp->w2[i] || !sp->b2[i])
+                CT_FAIL_ARG("%s: sparse head %d is incomplete", who, i);
+            if (d->heads[sp->head[i]]) CT_FAIL_ARG("%s: head %d is both dense and sparse", who, sp->head[i]);
+        }
+        if (sp->flip_B < 0 || (sp->flip_B > 0 && sp->flip_B != d->B)) CT_FAIL_ARG("%s: sparse flip_B must be 0 or B (feat then holds 2 * B images)", who);
+    }
     return CT_OK;
 }
 
@@ -977,6 +988,11 @@ static unsigned present_mask(const ct_decode_desc *d)
 
 extern "C" int ct_decode_row_floats(const ct_decode_desc *d)
 {
+    if (!d) return 0;
+    if (d->sparse && (d->sparse->nheads < 1 || d->sparse->nheads > CT_NUM_HEADS)) {
+        ct_set_error("ct_decode_row_floats: sparse nheads=%d out of range (1..%d)", d->sparse->nheads, CT_NUM_HEADS);
+        return 0;
+    }
     const unsigned m = present_mask(d);
     auto has = [&](int hd) { return (m >> hd) & 1u; };
     int f = 4;
@@ -1009,12 +1025,12 @@ static int pick_groups(const ct_decode_desc *d, int seg, int nseg)
     return (int)G;
 }
 
-// sparse heads: [B][K] winner keys | [B * tiles] arrival counters (padded to 8 bytes) | partial head outputs
+// sparse heads (descriptor validated by check()): [B][K] winner keys | partial head outputs
 static size_t sparse_bytes(const ct_decode_desc *d)
 {
     if (!d->sparse) return 0;
     const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
-    return (size_t)d->B * d->K * 8 + ((tiles * 4 + 7) & ~(size_t)7) + tiles * (size_t)d->sparse->nheads * 2 * 4 * 16 * 8 * sizeof(float);
+    return (size_t)d->B * d->K * 8 + tiles * (size_t)d->sparse->nheads * 2 * 4 * 16 * 8 * sizeof(float);
 }
 
 extern "C" size_t ct_decode_workspace_bytes(const ct_decode_desc *d)
@@ -1038,16 +1054,6 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
     const int G = pick_groups(d, seg, nseg);
     const size_t need = ((size_t)d->B * M2 + (size_t)d->B * G * d->K) * sizeof(unsigned long long) + sparse_bytes(d);
     const ct_sparse_heads_desc *sp = d->sparse;
-    if (sp) {
-        if (sp->nheads < 1 || sp->nheads > CT_NUM_HEADS || !sp->feat || sp->ldf < 64 || (sp->ldf & 3) || ((uintptr_t)sp->feat & 15))
-            CT_FAIL_ARG("ct_decode: sparse heads need 1..%d heads and a 16-byte aligned NHWC feature view of >= 64 channels", CT_NUM_HEADS);
-        for (int i = 0; i < sp->nheads; ++i) {
-            if (sp->head[i] < 0 || sp->head[i] >= CT_NUM_HEADS || !sp->w1[i] || !sp->b1[i] || !sp->w2[i] || !sp->b2[i])
-                CT_FAIL_ARG("ct_decode: sparse head %d is incomplete", i);
-            if (d->heads[sp->head[i]]) CT_FAIL_ARG("ct_decode: head %d is both dense and sparse", sp->head[i]);
-        }
-        if (sp->flip_B < 0 || (sp->flip_B > 0 && sp->flip_B != d->B)) CT_FAIL_ARG("ct_decode: sparse flip_B must be 0 or B (feat then holds 2 * B images)");
-    }
     if (!d->workspace || d->workspace_bytes < need) {
         ct_set_error("ct_decode: needs %zu workspace bytes, got %zu", need, d->workspace_bytes);
         return CT_ERR_WORKSPACE;
@@ -1108,12 +1114,7 @@ extern "C" int ct_decode(const ct_decode_desc *d, void *stream)
         sa.depth_scale = sp->depth_scale; sa.zero_tracking = sp->zero_tracking;
         sa.flip_B = sp->flip_B;
         for (int i = 0; i < CT_NUM_HEADS; ++i) sa.flip_mode[i] = (i < sp->nheads) ? sp->flip_mode[i] : 0;
-        {
-            const size_t tiles = (size_t)d->B * ct_cdiv(d->K, 16);
-            unsigned char *base = (unsigned char *)(a2.winners + (size_t)d->B * d->K);
-            sa.arrive = (unsigned *)base;
-            sa.partial = (float *)(base + ((tiles * 4 + 7) & ~(size_t)7));
-        }
+        sa.partial = (float *)(a2.winners + (size_t)d->B * d->K);
         sa.winners = a2.winners; sa.out = d->out; sa.host_out = d->host_out;
         sa.done_flag = d->done_flag; sa.done_counter = d->done_counter;
         sa.B = d->B; sa.h = d->h; sa.w = d->w; sa.K = d->K; sa.F = a2.F; sa.tiles = ct_cdiv(d->K, 16);

@@ -87,21 +87,22 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
             const int py = P / C::PW, px = P - py * C::PW;
             const int iy = iy0 + py, ix = ix0 + px;
             loff[r] = kk * C::SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
-            goff[r] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ((iy * W + ix) * ldx + kk * 16 + q * 4) : -1;
+            goff[r] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ((iy * W + ix) * ldx + kk * 16 + q * 4) * 4 : (int)0x80000000;
         } else {
             loff[r] = -1;
-            goff[r] = -1;
+            goff[r] = (int)0x80000000;
         }
     }
+    // (round 6) staging through a buffer descriptor of the image: item byte offset in the vector offset, chunk in the scalar
+    // offset, out-of-image items out of range (the hardware returns zeros): no address arithmetic and no select per item
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xin), 0, (int)((((unsigned)H * W - 1u) * ldx + Cin) * 4u), 0x00020000);
     f32x4 stage[C::NR];
     auto stage_load = [&](int chunk) {
-        const int coff = chunk * (16 * WK);
+        const int coff = chunk * (16 * WK * 4);
 #pragma unroll
-        for (int r = 0; r < C::NR; ++r) {
-            const bool ok = goff[r] >= 0;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
-            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int r = 0; r < C::NR; ++r)
+            stage[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[r], coff, 0));
     };
     auto stage_store = [&](int buf) {
         float *dst = lds + buf * C::BUF;
@@ -115,15 +116,16 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
 #pragma unroll
     for (int mt = 0; mt < WM; ++mt) pbase[mt] = (mt * STRIDE) * C::PW + li * STRIDE;
     const int NCH16 = Cin >> 4;
-    const float *bptr[WN];
+    const int slab_bytes = NT << 10;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wp), 0, KS * KS * NCH16 * slab_bytes, 0x00020000);
+    int bvo[WN];
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) bptr[nt] = wp + ((size_t)min(nt0 + nt, NT - 1) << 8) + (lane << 2);
-    const size_t slab_stride = (size_t)NT << 8;
+    for (int nt = 0; nt < WN; ++nt) bvo[nt] = (min(nt0 + nt, NT - 1) << 10) + (lane << 4);
     // B fragment of (chunk, tap) for THIS wave's slab; chunks past the end clamp (loaded, never used)
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int tap) {
-        const size_t slab = (size_t)tap * NCH16 + (size_t)min(chunk, c_end - 1) * WK + wave;
+        const int so = (tap * NCH16 + min(chunk, c_end - 1) * WK + wave) * slab_bytes;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
+        for (int nt = 0; nt < WN; ++nt) b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo[nt], so, 0));
     };
 
     f32x4 acc[WM][WN];
@@ -170,11 +172,10 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
                         const int ky = s / KS, kx = s % KS;
                         if constexpr (SIDE) {
                             if (s == 0 && side) {      // this wave's slab of the 1x1 weights: 8 taps ahead of its MFMAs
-                                const size_t slab2 = (size_t)c * WK + wave;
+                                const __amdgpu_buffer_rsrc_t w2rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(wp2), 0, NCH16 * slab_bytes, 0x00020000);
 #pragma unroll
                                 for (int nt = 0; nt < WN; ++nt)
-                                    b2[nt] = *reinterpret_cast<const f32x4 *>(wp2 + ((size_t)min(nt0 + nt, NT - 1) << 8) + (lane << 2) +
-                                                                              slab2 * slab_stride);
+                                    b2[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(w2rs, bvo[nt], (c * WK + wave) * slab_bytes, 0));
                             }
                         }
                         f32x4 af[WM];

@@ -60,33 +60,38 @@ extern "C" int ct_memcpy_async(void *dst, const void *src, size_t bytes, int kin
     return CT_OK;
 }
 
-// (round 5: a KERNEL, not hipMemsetAsync -- inside a captured frame graph the runtime's memset node wrote garbage instead of
-//  the value on this stack (zero_tracking streams replayed through a graph: tracking rows of 1e-21 .. 1e12 instead of 0,
-//  tools/calls/dbg_zero.py; eager launches were fine).  Kernel nodes are what every other launch of the graph is.)
+// (round 5: KERNELS, not hipMemsetAsync -- inside a captured frame graph the runtime's memset node wrote garbage instead of the
+//  value (zero_tracking streams replayed through a graph: tracking rows of 1e-21 .. 1e12 instead of 0; eager launches were
+//  fine; root cause inside the runtime not established).  Regression test: tests/test_hip_sparse_heads.py -- the
+//  zero_tracking case compares a graph-replayed stream against the dense path.  Kernel nodes are what every other launch of
+//  the graph is; sizes or addresses that are not word multiples go through the byte kernel, never through the runtime.)
 __global__ __launch_bounds__(256) void fill_words_kernel(unsigned *dst, unsigned pattern, size_t nwords)
 {
     const size_t stride = (size_t)gridDim.x * 256;
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nwords; i += stride) dst[i] = pattern;
 }
 
+__global__ __launch_bounds__(256) void fill_bytes_kernel(unsigned char *dst, unsigned char value, size_t nbytes)
+{
+    const size_t stride = (size_t)gridDim.x * 256;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < nbytes; i += stride) dst[i] = value;
+}
+
 extern "C" int ct_memset_async(void *dst, int value, size_t bytes, void *stream)
 {
     if (!dst && bytes) CT_FAIL_ARG("ct_memset_async: null pointer");
     if (bytes == 0) return CT_OK;
+    const unsigned b = (unsigned)value & 0xffu;
     if (((uintptr_t)dst & 3) == 0 && (bytes & 3) == 0) {
-        const unsigned b = (unsigned)value & 0xffu;
         const size_t n = bytes / 4;
         const unsigned blocks = (unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
         hipLaunchKernelGGL(fill_words_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned *)dst,
                            b | (b << 8) | (b << 16) | (b << 24), n);
-        CT_CHECK_LAUNCH("ct_memset_async");
-        return CT_OK;
+    } else {
+        const unsigned blocks = (unsigned)((bytes + 255) / 256 < 2048 ? (bytes + 255) / 256 : 2048);
+        hipLaunchKernelGGL(fill_bytes_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (unsigned char *)dst, (unsigned char)b, bytes);
     }
-    hipError_t e = hipMemsetAsync(dst, value, bytes, (hipStream_t)stream);
-    if (e != hipSuccess) {
-        ct_set_error("ct_memset_async: %s", hipGetErrorString(e));
-        return CT_ERR_LAUNCH;
-    }
+    CT_CHECK_LAUNCH("ct_memset_async");
     return CT_OK;
 }
 

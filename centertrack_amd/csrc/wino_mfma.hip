@@ -85,8 +85,7 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
     static_assert(!HEADS || (NB == 8 && WM == 1 && WN == 2), "the fused heads run on 64 px x 8 blocks of 32 couts");
     using C = WCfg<WM>;
     constexpr int NTHR = 256 * KS;
-    constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF, W_ITEMS = C::ITEMS;
-    constexpr int W_NR = (W_ITEMS + NTHR - 1) / NTHR;
+    constexpr int W_PW = C::PW, W_PP = C::PP, W_SLAB = C::SLAB, W_BUF = C::BUF;
     extern __shared__ __attribute__((aligned(16))) float lds[];
     CT_STAMP_RT(0);
     CT_STAMP(1);
@@ -114,39 +113,50 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
 
     // ---- staging of the raw patch (rows oy0-1 .. oy0+4*WM, cols ox0-1 .. ox0+16) -------------------------
-    int goff[W_NR], loff[W_NR];
+    // thread -> (channel quad q = tid & 3, slot tid >> 2): a slot is a patch pixel P (+ SP per round) of the 16-channel slab
+    // kk0 (+ KG per round).  Everything that depends on the pixel -- its row / column, whether it lies inside the image, its
+    // swizzled LDS address -- is computed ONCE per pixel round (one or two of them); the slab is an immediate offset of the
+    // loads and the LDS stores (round 6: the item list it replaces cost two integer divisions and an address per item).
+    constexpr int SLOTS = NTHR / 4;                   // 64 / 128 / 256
+    constexpr int KG = SLOTS >= 256 ? 2 : 1;          // slab groups side by side in the thread block
+    constexpr int SP = SLOTS / KG;                    // pixel slots per round: 64 or 128
+    constexpr int RP = (W_PP + SP - 1) / SP;          // pixel rounds
+    constexpr int RK = 4 / KG;                        // slab rounds
+    constexpr int W_NR = RP * RK;
+    const int sq = tid & 3, sslot = tid >> 2;
+    const int skk0 = sslot / SP, sP0 = sslot - skk0 * SP;
+    int goff[RP], loff[RP];
 #pragma unroll
-    for (int r = 0; r < W_NR; ++r) {
-        const int it = tid + NTHR * r;
-        if (it < W_ITEMS) {
-            const int q = it & 3;
-            const int pp = it >> 2;
-            const int kk = pp / W_PP;
-            const int P = pp - kk * W_PP;
-            const int py = P / W_PW, px = P - py * W_PW;
-            const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
-            loff[r] = kk * W_SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
-            goff[r] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4) : -1;
-        } else {
-            loff[r] = -1;
-            goff[r] = -1;
-        }
+    for (int j = 0; j < RP; ++j) {
+        const int P = sP0 + SP * j;
+        const int py = P / W_PW, px = P - py * W_PW;
+        const int iy = oy0 - 1 + py, ix = ox0 - 1 + px;
+        loff[j] = (P < W_PP) ? skk0 * W_SLAB + P * 16 + ((sq ^ ((P >> 1) & 2)) << 2) : -1;
+        goff[j] = (P < W_PP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((iy * a.W + ix) * a.ldx + skk0 * 16 + sq * 4) * 4 : (int)0x80000000;
     }
+    // the patch comes through a buffer descriptor of this image: byte offset of the pixel in the vector offset, the chunk in
+    // the scalar offset, the slab in the immediate; the padding pixels carry an out-of-range offset and the hardware returns
+    // zeros for them -- no address arithmetic and no select per staged vector (fp32 MFMAs and vector instructions share the
+    // SIMD's lanes on this part: every VALU instruction of the loop is paid on top of the MFMA time)
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(xin), 0, (int)((((unsigned)a.H * a.W - 1u) * a.ldx + a.Cin) * 4u), 0x00020000);
     f32x4 stage[W_NR];
     auto stage_load = [&](int chunk) {
-        const int coff = (chunk0 + chunk) * 64;
+        const int coff = (chunk0 + chunk) * 256;
 #pragma unroll
-        for (int r = 0; r < W_NR; ++r) {
-            const bool ok = goff[r] >= 0;
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(xin + (ok ? goff[r] + coff : 0));
-            stage[r] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
+        for (int k = 0; k < RK; ++k)
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+                stage[k * RP + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j] + k * (KG * 64), coff, 0));
     };
     auto stage_store = [&](int buf) {
         float *dst = lds + buf * W_BUF;
 #pragma unroll
-        for (int r = 0; r < W_NR; ++r)
-            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
+        for (int j = 0; j < RP; ++j)
+            if (loff[j] >= 0) {
+#pragma unroll
+                for (int k = 0; k < RK; ++k) *reinterpret_cast<f32x4 *>(dst + loff[j] + k * (KG * W_SLAB)) = stage[k * RP + j];
+            }
     };
 
     // ---- A side: lane li = Winograd tile (row li>>3, column li&7), lg = channel quad; wave = row r of the
@@ -169,7 +179,8 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
 
     // ---- B side ----------------------------------------------------------------------------------------
     const int NCH16 = a.Cin >> 4;
-    const size_t slab_stride = (size_t)a.NT << 8;
+    const int slab_bytes = a.NT << 10;              // one (position, 16-channel slab): NT fragments of 1 KiB
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.up), 0, 16 * NCH16 * slab_bytes, 0x00020000);
     constexpr int SPK = 4 / KS;                     // slabs of a chunk per K part
     constexpr int S = 16 / KS, D = 3, R = 4;       // steps per chunk and wave, B prefetched 3 steps ahead, ring of 4
     float *exch = lds;                              // [kp KS][r 4][q 2][mt WM][nt WN][lane 64] float4
@@ -244,15 +255,15 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
     for (int nb = 0; nb < NB; ++nb) {
     const int nt0 = (cb * NB + nb) * WN;
     if (NB > 1 && nt0 >= a.NT) break;               // (uniform: cout blocks past the end of a ragged Cout)
-    const float *bptr[WN];
+    int bvo[WN];                                    // the lane's part of a fragment address: constant over the steps
 #pragma unroll
-    for (int nt = 0; nt < WN; ++nt) bptr[nt] = a.up + ((size_t)min(nt0 + nt, a.NT - 1) << 8) + (lane << 2);
+    for (int nt = 0; nt < WN; ++nt) bvo[nt] = (min(nt0 + nt, a.NT - 1) << 10) + (lane << 4);
     // step s of a chunk (for this wave) = (slab kp*SPK + (s>>2), column c = s&3); position = wave*4 + c
     auto load_b = [&](f32x4 (&b)[WN], int chunk, int s) {
         const int c = s & 3, kk = kp * SPK + (s >> 2);
-        const size_t slab = (size_t)(wave * 4 + c) * NCH16 + (size_t)(chunk0 + min(chunk, a.nchunks - 1)) * 4 + kk;
+        const int so = ((wave * 4 + c) * NCH16 + (chunk0 + min(chunk, a.nchunks - 1)) * 4 + kk) * slab_bytes;     // (uniform)
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) b[nt] = *reinterpret_cast<const f32x4 *>(bptr[nt] + slab * slab_stride);
+        for (int nt = 0; nt < WN; ++nt) b[nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo[nt], so, 0));
     };
 
     f32x4 acc[WM][4][WN];                          // [m-tile][column c of the transformed tile][n-tile]

@@ -1157,3 +1157,28 @@ def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
     _lib.check(_lib.load().ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()), 'ct_heads_fused')
     torch.cuda.synchronize()
     _close(out, want, atol=5e-4, rtol=2e-4, msg='fused heads')       # (Winograd tolerance of this suite)
+
+
+@pytest.mark.parametrize('offset,nbytes', [(0, 4096), (4, 1000), (1, 37), (3, 4099)])
+def test_memset_async_fills_words_and_bytes_also_inside_a_graph(device, offset, nbytes):
+    """ct_memset_async is a kernel on every path (the runtime's memset NODE wrote garbage inside captured frame
+    graphs, so neither the word path nor the unaligned / odd-size path may fall back to it): eager and graph-replayed fills
+    of aligned and unaligned ranges leave exactly the requested bytes changed"""
+    from centertrack_amd import _lib
+    lib = _lib.load()
+    buf = torch.full((8192,), 0x5a, dtype=torch.uint8, device=device)
+    ptr = buf.data_ptr() + 16 + offset
+    _lib.check(lib.ct_memset_async(ptr, 0xa7, nbytes, _lib.stream_ptr()), 'memset')
+    torch.cuda.synchronize()
+    want = torch.full((8192,), 0x5a, dtype=torch.uint8)
+    want[16 + offset:16 + offset + nbytes] = 0xa7
+    assert torch.equal(buf.cpu(), want)
+    g = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(g, stream=side):
+            _lib.check(lib.ct_memset_async(ptr, 0x11, nbytes, _lib.stream_ptr()), 'memset in capture')
+    g.replay()
+    torch.cuda.synchronize()
+    want[16 + offset:16 + offset + nbytes] = 0x11
+    assert torch.equal(buf.cpu(), want)

@@ -18,10 +18,10 @@ Policy asserted here, on exactly that stream (T = 32, nothing re-seeded):
 The flip itself depends on the last bits of the HIP path's sums (launch shapes).  It was found on round 3's plan; round
 4's plan (Tree.project computed by the stride-2 conv launches: other summation orders in four layers) puts that centre on
 the oracle's side of the integer and the same stream runs without a flip (profiles/r04_tie_report.json: 0 flips in 1760
-frames).  The test therefore runs the stream on BOTH plans: on round 3's launch structure (``model.FUSE_PROJ = False``, its
-pinned shapes are still in the table) the flip must occur -- at frame 24, blob (470, 344, 6) vs (469, 344, 6) -- and the
-exemption is exercised; on the shipped plan every frame has to meet the 1e-3 bar (or, should a re-tuned table bring a flip
-back, the same policy applies)."""
+frames).  The test therefore runs the stream on BOTH launch structures (``model.FUSE_PROJ = False`` = round 3's, its pinned
+shapes are still in the table); through round 5 the flip reproduced on round 3's -- frame 24, blob (470, 344, 6) vs
+(469, 344, 6) -- and exercised the exemption; since round 6 (other DCN arithmetic) neither structure flips on this stream.
+Every frame has to meet the 1e-3 bar, or, wherever a flip occurs, the policy above."""
 import os
 import sys
 
@@ -104,10 +104,11 @@ def test_prior_heatmap_flip_stream_follows_the_stated_policy(device, plan, monke
             flips.append((t, only_o[0], only_g[0]))
             after_flip = True
     assert len(flips) <= 2, 'a blob flip is a rare event (0.6 per 1000 frames measured): %s' % (flips,)
-    if plan == 'round3':
-        assert flips == [(24, (470, 344, 6), (469, 344, 6))], (
-            'the documented flip of this stream on round 3\'s launch structure did not reproduce (%s): were its pinned shapes '
-            're-tuned?  re-measure with tools/tie_report.py and update this test' % (flips,))
-        assert exempt == [25] and worst_exempt > ATOL, (exempt, worst_exempt)
+    # Rounds 3-5: on round 3's launch structure this stream flipped at frame 24 -- blob (470, 344, 6) vs (469, 344, 6) -- and
+    # frame 25 exercised the exemption (|dscore| 1.15e-2).  Round 6 changed the DCN arithmetic itself (Winograd offset convs,
+    # v_exp / v_rcp mask sigmoid, re-measured schedules): the centre lands on the oracle's side of the integer on both launch
+    # structures now and the stream runs without a flip (profiles/r06_gpu_tests.log).  Whatever flips, the policy above holds.
+    if flips:
+        assert exempt == [f[0] + 1 for f in flips if f[0] + 1 < T], (flips, exempt)
     print('tie policy [%s plan]: %d blob flip(s) %s; |dscore| max %.2e outside the exempt frames, %.2e inside (%s)'
           % (plan, len(flips), flips, worst, worst_exempt, exempt))
