@@ -83,7 +83,7 @@ def test_bench_flags_used_by_the_collection_scripts_exist():
     sys.path.insert(0, root)
     bench = importlib.import_module('bench')
     import scenarios as S
-    assert all(name in S.CONFIGS and streams >= 1 for name, streams in bench.EXTRA_CONFIGS)
+    assert all(name in S.CONFIGS and streams >= 1 and steps >= 0 for name, streams, steps in bench.EXTRA_CONFIGS)
     flags = set()
     for path in glob.glob(os.path.join(root, 'tools', '*.sh')) + glob.glob(os.path.join(root, 'tools', 'calls', '*.sh')):
         text = open(path).read()
