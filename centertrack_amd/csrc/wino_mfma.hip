@@ -18,6 +18,8 @@
 //     scale/shift/residual/ReLU and the NHWC store.
 #include "ct_common.h"
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 namespace {
 
 struct WinoArgs {
@@ -410,32 +412,47 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
                     yb[(tile * 2 + 1) * 16 + li] = y1[ee];
                 }
                 __builtin_amdgcn_s_waitcnt(0xc07f);               // lgkmcnt(0): the wave's own LDS writes have landed
+                // (round 6) stores and residual loads through buffer descriptors of image n: the lane's part of the offset
+                // (its pixel inside the 4 x 16 block, its cout quad) is computed once per item, the block / job part is a
+                // scalar offset; lanes past the map's edge or the last cout carry an out-of-range offset (store dropped,
+                // residual read as zero).  The item-by-item 64-bit address arithmetic this replaces was a third of the
+                // kernel's vector instructions on the short-K layers.
+                const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+                    ydst + (size_t)n * a.epi.Ho * a.epi.Wo * a.epi.ldy, 0,
+                    (int)((((unsigned)a.epi.Ho * a.epi.Wo - 1u) * a.epi.ldy + a.epi.Cout) * 4u), 0x00020000);
+                const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+                    const_cast<float *>(a.epi.res ? a.epi.res + (size_t)n * a.epi.Ho * a.epi.Wo * a.epi.ldr : ydst), 0,
+                    a.epi.res ? (int)((((unsigned)a.epi.Ho * a.epi.Wo - 1u) * a.epi.ldr + a.epi.Cout) * 4u) : 0, 0x00020000);
+                const int srow = oy0 + 4 * mt, scol = ox0 + q, sc0 = (nt0 + nt) * 16;     // (uniform)
+                const int so_y = ((srow * a.epi.Wo + scol) * a.epi.ldy + sc0) * 4;
+                const int so_r = ((srow * a.epi.Wo + scol) * a.epi.ldr + sc0) * 4;
 #pragma unroll
                 for (int h2 = 0; h2 < 2; ++h2) {
                     const int item = lane + 64 * h2;              // (tile*2 + p) * 4 + cout quad
                     const int cq = item & 3, tp = item >> 2;
                     const int tile = tp >> 1, pp = tp & 1;
-                    const int oy = oy0 + 4 * mt + 2 * (tile >> 3) + pp;
-                    const int ox = ox0 + 2 * (tile & 7) + q;
-                    const int c4 = (nt0 + nt) * 16 + cq * 4;
-                    if (oy < a.epi.Ho && ox < a.epi.Wo && c4 < a.epi.Cout) {
-                        const f32x4 raw = *reinterpret_cast<const f32x4 *>(yb + tp * 16 + cq * 4);
-                        const size_t pix = ((size_t)n * a.epi.Ho + oy) * a.epi.Wo + ox;
-                        f32x4 sc4, sh4;
-                        if (PRE) {
-                            sc4 = psc[PRE ? w0 / (4 * KS) : 0];
-                            sh4 = psh[PRE ? w0 / (4 * KS) : 0];
-                        } else {
-                            sc4 = a.epi.scale ? *reinterpret_cast<const f32x4 *>(a.epi.scale + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
-                            sh4 = a.epi.shift ? *reinterpret_cast<const f32x4 *>(a.epi.shift + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
-                        }
-                        const f32x4 r4 = a.epi.res ? *reinterpret_cast<const f32x4 *>(a.epi.res + pix * a.epi.ldr + c4)
-                                                   : f32x4{0.f, 0.f, 0.f, 0.f};
-                        f32x4 o;
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_plain(a.epi, raw[i], sc4[i], sh4[i], r4[i]);
-                        *reinterpret_cast<f32x4 *>(ydst + pix * a.epi.ldy + c4) = o;
+                    const int lrow = 2 * (tile >> 3) + pp, lcol = 2 * (tile & 7);
+                    const bool ok = lrow < a.epi.Ho - srow && lcol < a.epi.Wo - scol && cq * 4 < a.epi.Cout - sc0;
+                    const int lpix = lrow * a.epi.Wo + lcol;
+                    const int vo_y = ok ? (lpix * a.epi.ldy + cq * 4) * 4 : (int)0x80000000;
+                    const f32x4 raw = *reinterpret_cast<const f32x4 *>(yb + tp * 16 + cq * 4);
+                    f32x4 sc4, sh4;
+                    if (PRE) {
+                        sc4 = psc[PRE ? w0 / (4 * KS) : 0];
+                        sh4 = psh[PRE ? w0 / (4 * KS) : 0];
+                    } else {
+                        const int c4 = min(sc0 + cq * 4, a.epi.Cout - 4);      // (clamped: lanes past the end store nothing)
+                        sc4 = a.epi.scale ? *reinterpret_cast<const f32x4 *>(a.epi.scale + c4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                        sh4 = a.epi.shift ? *reinterpret_cast<const f32x4 *>(a.epi.shift + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
                     }
+                    f32x4 r4 = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (a.epi.res)                                  // (uniform)
+                        r4 = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(
+                                 rrs, ok ? (lpix * a.epi.ldr + cq * 4) * 4 : (int)0x80000000, so_r, 0));
+                    f32x4 o;
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_plain(a.epi, raw[i], sc4[i], sh4[i], r4[i]);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, vo_y, so_y, 0);
                 }
             } else if (co < a.epi.Cout) {
                 const float sc = a.epi.scale ? a.epi.scale[co] : 1.0f;
