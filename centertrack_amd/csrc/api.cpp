@@ -24,7 +24,7 @@ extern "C" int ct_version(void) { return CT_ABI_VERSION; }
 // ---- tuning knobs -------------------------------------------------------------------------
 enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,
        CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_HEADS_ORDER, CT_TUNE_STEM_ROWS, CT_TUNE_COUNT };
-static int g_tune[CT_TUNE_COUNT] = {-1, 1, 256, 512, 0, -1, 512, 2048, 0, 1, 0};
+static int g_tune[CT_TUNE_COUNT] = {-1, 1, 256, 512, 0, -1, 512, 2048, 0, 2, 0};
 static const char *g_tune_names[CT_TUNE_COUNT] = {"conv_cfg", "conv_pipe", "conv_small_tiles", "splitk_target", "dcn_bn",
                                                  "conv_ks", "conv_ks_below", "conv_ks_waves", "xcd_remap", "heads_order", "stem_rows"};
 

@@ -75,6 +75,11 @@ CT_DEFINE_STAMPS(dcn)       // (tools/dcn_phases.py; expands to nothing in the s
 #ifndef CT_ABL
 #define CT_ABL 0
 #endif
+// cache policy of the split-K partial / raw-tile stores (variant builds): 0 = plain, 16 = sc1 (write-through: the slab leaves the
+// XCD's L2 at once instead of staying dirty until the kernel boundary writes it back, MI355X_MICROARCH.md "publish-large")
+#ifndef CT_WS_AUX
+#define CT_WS_AUX 0
+#endif
 
 // sigmoid of the mask channels (upstream dcn_v2.py: mask = torch.sigmoid(mask)): v_exp_f32 + v_rcp_f32, 1 ulp each -- the
 // table build runs once per workgroup on the same SIMD lanes the MFMAs use, so its instruction count is kernel time
@@ -455,7 +460,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
                 if (oyb + mt >= a.H) continue;                      // (uniform)
 #pragma unroll
                 for (int e = 0; e < 4; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][e]), srs, vo[e], mt * rowb2 + e * pixb, 0);
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][e]), srs, vo[e], mt * rowb2 + e * pixb, CT_WS_AUX);
             }
         }
     } else {

@@ -98,7 +98,21 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
     const int li = lane & 15, lg = lane >> 4;
 
     int cb;
-    if (HEADS && a.headMajor) {
+    if (HEADS && a.headMajor == 2) {
+        // XCD-affine head-major order (round 6; knob "heads_order" = 2): workgroup ids are dealt to the 8 XCDs
+        // round-robin (id % 8; observed, not promised: a speed matter only), so XCD x is handed the CONTIGUOUS eighth
+        // [x * per, (x + 1) * per) of the head-major list -- at most two heads' Winograd weights (1 MB each) ever pass
+        // through one L2 instead of all of them through every L2: FETCH_SIZE x 2 of the launch 47.9 -> 34.4 MB at one stream
+        // (profiles/r06_m_fetch_heads_order{1,2}.txt; what remains is the feature map, read once per head with its halo), same
+        // time within noise (profiles/r06_m_ab_switches.txt), bit-identical results.  (Also measured there and not kept: this
+        // kernel's multi-chunk 64 x 32 shape capped at 168 VGPRs for a third wave per SIMD -- 4 spilled registers, no change.)
+        const unsigned per = nblocks >> 3;
+        const unsigned ubid = (unsigned)bid;
+        const unsigned lin = ubid < per * 8u ? (ubid & 7u) * per + (ubid >> 3) : ubid;     // (the last nblocks % 8 keep their place)
+        const int per_head = (int)(nblocks / (unsigned)a.coutBlocks);
+        cb = (int)lin / per_head;
+        bid = (int)lin - cb * per_head;
+    } else if (HEADS && a.headMajor) {
         // every head has its own 1 MB of Winograd weights: with the head as the SLOWEST index the workgroups resident
         // at any time work on <= 3 heads (3 MB per XCD L2 of 4 MB) instead of cycling through all of them (5.2 MB for
         // the five MOT heads: every XCD kept re-streaming the weights, 119 MB of fetches per launch in round 2)
@@ -716,7 +730,7 @@ extern "C" int ct_heads_fused(const ct_heads_desc *d, void *stream)
     a.x = d->x; a.up = d->w0_winograd;
     a.N = d->N; a.H = d->H; a.W = d->W; a.Cin = 64; a.ldx = d->ldx;
     a.tilesX = ct_cdiv(d->W, 16); a.tilesY = ct_cdiv(d->H, 4); a.coutBlocks = d->nheads; a.xcdPer = 0;
-    a.headMajor = ct_tune_get(CT_TUNE_HEADS_ORDER) ? 1 : 0;
+    a.headMajor = ct_tune_get(CT_TUNE_HEADS_ORDER);
     a.NT = d->nheads * 16; a.nchunks = 1;
     a.epi.scale = nullptr; a.epi.shift = d->b0; a.epi.res = nullptr; a.epi.y = nullptr;
     a.epi.ldr = 0; a.epi.ldy = 0; a.epi.Cout = d->nheads * 256; a.epi.Ho = d->H; a.epi.Wo = d->W;

@@ -49,7 +49,8 @@ int ct_version(void);                      /* CT_ABI_VERSION the library was bui
  * (workgroups aimed at when splitting K), "dcn_bn" (0 auto, 64, 128), "conv_ks" (-1 auto, -2 never,
  * 0..4 force a K-split-in-workgroup tile), "conv_ks_below" / "conv_ks_waves" (K-split kernel is
  * used below this many 64x64 tiles / sized to reach this many waves), "xcd_remap" (0/1 XCD-aware workgroup order of
- * the wide layers), "heads_order" (1 = head-major workgroup order of ct_heads_fused), "stem_rows" (0 auto,
+ * the wide layers), "heads_order" (0 = tile-major, 1 = head-major, 2 = head-major and
+ * XCD-affine [default]: workgroup order of ct_heads_fused), "stem_rows" (0 auto,
  * 8 / 16: rows of 32 pixels per workgroup of ct_stem_forward). */
 int ct_set_tuning(const char *key, int value);
 

@@ -1157,6 +1157,19 @@ def test_heads_fused_equals_conv_relu_conv(device, N, H, W, heads, sig, dep):
     _lib.check(_lib.load().ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()), 'ct_heads_fused')
     torch.cuda.synchronize()
     _close(out, want, atol=5e-4, rtol=2e-4, msg='fused heads')       # (Winograd tolerance of this suite)
+    # the workgroup ORDER is a speed knob only: tile-major (0), head-major (1) and the XCD-affine head-major default (2) -- every
+    # XCD takes a contiguous eighth of the (head, tile) list, also when the count is no multiple of eight -- give the same bits
+    lib = _lib.load()
+    try:
+        for order in (0, 1, 2):
+            _lib.check(lib.ct_set_tuning(b'heads_order', order), 'heads_order')
+            again = torch.full((N, ctot, H, W), float('nan'), device=device)
+            hd.out = again.data_ptr()
+            _lib.check(lib.ct_heads_fused(ctypes.byref(hd), _lib.stream_ptr()), 'ct_heads_fused')
+            torch.cuda.synchronize()
+            assert torch.equal(again, out), 'heads_order %d' % order
+    finally:
+        _lib.check(lib.ct_set_tuning(b'heads_order', 2), 'heads_order')
 
 
 @pytest.mark.parametrize('offset,nbytes', [(0, 4096), (4, 1000), (1, 37), (3, 4099)])
