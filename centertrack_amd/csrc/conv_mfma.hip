@@ -127,45 +127,45 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(ConvArgs a)
 
     const float *xin = a.x + (size_t)n * a.H * a.W * a.ldx;
 
-    // ---- staging assignment: item -> (slab kk, patch pixel P, channel quad q) ----------
-    int goff[C::NR];    // element offset into xin (without the chunk offset), -1 = zero fill
-    int loff[C::NR];    // float offset inside one chunk buffer, -1 = no item
+    // ---- staging assignment (round 6): thread -> (channel quad q = tid & 3, pixel slot tid >> 2); a slot covers patch pixels
+    // P, P + 64, .. of every 16-channel slab.  What depends on the pixel (row / column, inside the image?, swizzled LDS
+    // address) is computed once per pixel round; the slab is an immediate offset of the loads and of the LDS stores (the item
+    // list this replaces cost two integer divisions and an address per item: two thirds of the level-0 launch's vector
+    // instructions, which are paid on top of its MFMA time).
+    constexpr int RP = (C::PP + 63) / 64;           // pixel rounds
+    constexpr int SNR = RP * NKK;                   // staged vectors per thread
+    const int sq = tid & 3, sslot = tid >> 2;
+    int goff[RP], loff[RP];
 #pragma unroll
-    for (int r = 0; r < C::NR; ++r) {
-        const int it = tid + 256 * r;
-        if (it < C::ITEMS) {
-            const int q = it & 3;
-            const int pp = it >> 2;
-            const int kk = pp / C::PP;
-            const int P = pp - kk * C::PP;
-            const int py = P / C::PW, px = P - py * C::PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            loff[r] = kk * C::SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
-            goff[r] = (iy >= 0 && iy < a.H && ix >= 0 && ix < a.W)
-                          ? ((iy * a.W + ix) * a.ldx + kk * 16 + q * 4) * 4
-                          : (int)0x80000000;
-        } else {
-            loff[r] = -1;
-            goff[r] = (int)0x80000000;
-        }
+    for (int j = 0; j < RP; ++j) {
+        const int P = sslot + 64 * j;
+        const int py = P / C::PW, px = P - py * C::PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        loff[j] = (P < C::PP) ? P * 16 + ((sq ^ ((P >> 1) & 2)) << 2) : -1;
+        goff[j] = (P < C::PP && iy >= 0 && iy < a.H && ix >= 0 && ix < a.W) ? ((iy * a.W + ix) * a.ldx + sq * 4) * 4 : (int)0x80000000;
     }
-    f32x4 stage[C::NR];
-    // Branch-free staging through a buffer descriptor of this image (round 6): the item's byte offset in the vector offset,
-    // the chunk in the scalar offset; out-of-image / padding items carry an out-of-range offset and the hardware returns
-    // zeros for them -- no address arithmetic, no select (every VALU instruction is paid on top of the fp32 MFMA time)
+    f32x4 stage[SNR];
+    // Branch-free staging through a buffer descriptor of this image: the pixel's byte offset in the vector offset, the chunk
+    // in the scalar offset, the slab in the immediate; out-of-image / padding pixels carry an out-of-range offset and the
+    // hardware returns zeros for them
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(xin), 0, (int)((((unsigned)a.H * a.W - 1u) * a.ldx + a.Cin) * 4u), 0x00020000);
     auto stage_load = [&](int chunk) {
         const int coff = chunk * (16 * NKK * 4);
 #pragma unroll
-        for (int r = 0; r < C::NR; ++r)
-            stage[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[r], coff, 0));
+        for (int k = 0; k < NKK; ++k)
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+                stage[k * RP + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j] + k * 64, coff, 0));
     };
     auto stage_store = [&](int buf) {
         float *dst = lds + buf * C::BUF;
 #pragma unroll
-        for (int r = 0; r < C::NR; ++r)
-            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
+        for (int j = 0; j < RP; ++j)
+            if (loff[j] >= 0) {
+#pragma unroll
+                for (int k = 0; k < NKK; ++k) *reinterpret_cast<f32x4 *>(dst + loff[j] + k * C::SLAB) = stage[k * RP + j];
+            }
     };
 
     // ---- fragment addressing -----------------------------------------------------------

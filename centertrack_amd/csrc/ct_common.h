@@ -154,17 +154,17 @@ __device__ __forceinline__ void ct_store_tile(const EpiArgs &e, f32x4 acc, int n
     if (oy >= e.Ho) return;
     const int co = co0 + (lane & 15);
     const int xr = ox0 + ((lane >> 4) << 2);
-    if (co >= e.Cout) return;
-    const size_t pix = ((size_t)n * e.Ho + oy) * e.Wo;
-    float v[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int ox = xr + i;
-        float r = 0.0f;
-        if (e.res && ox < e.Wo) r = e.res[(pix + ox) * e.ldr + co];
-        v[i] = ct_epilogue_value(e, acc[i], co, sc, sh, r);
-    }
     if (e.flags & CT_OUT_NCHW) {
+        if (co >= e.Cout) return;
+        const size_t pix = ((size_t)n * e.Ho + oy) * e.Wo;
+        float v[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int ox = xr + i;
+            float r = 0.0f;
+            if (e.res && ox < e.Wo) r = e.res[(pix + ox) * e.ldr + co];
+            v[i] = ct_epilogue_value(e, acc[i], co, sc, sh, r);
+        }
         float *dst = e.y + ((size_t)n * e.Cout + co) * ((size_t)e.Ho * e.Wo) + (size_t)oy * e.Wo + xr;
         if (xr + 3 < e.Wo && ((e.Wo & 3) == 0)) {
             *reinterpret_cast<f32x4 *>(dst) = f32x4{v[0], v[1], v[2], v[3]};
@@ -173,10 +173,31 @@ __device__ __forceinline__ void ct_store_tile(const EpiArgs &e, f32x4 acc, int n
             for (int i = 0; i < 4; ++i)
                 if (xr + i < e.Wo) dst[i] = v[i];
         }
-    } else {
+        return;
+    }
+    // NHWC (round 6): stores and residual loads through buffer descriptors of image n -- the lane's (pixel, cout) byte offset
+    // once per tile, the four pixels of the lane as scalar offsets; lanes past the row's end or the last cout carry an
+    // out-of-range offset (store dropped by the hardware, residual read as zero).  Replaces a 64-bit address per value:
+    // vector instructions are paid on top of the fp32 MFMA time on this part.
+    const unsigned img = (unsigned)e.Ho * e.Wo;
+    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+        e.y + (size_t)n * img * e.ldy, 0, (int)(((img - 1u) * e.ldy + e.Cout) * 4u), 0x00020000);
+    const int lpix = oy * e.Wo + xr;
+    const bool cok = co < e.Cout;
+    const int vy = (lpix * e.ldy + co) * 4;
+    float r[4] = {0.f, 0.f, 0.f, 0.f};
+    if (e.res) {                                                  // (uniform)
+        const __amdgpu_buffer_rsrc_t rrs = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<float *>(e.res) + (size_t)n * img * e.ldr, 0, (int)(((img - 1u) * e.ldr + e.Cout) * 4u), 0x00020000);
+        const int vr = (lpix * e.ldr + co) * 4;
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            if (xr + i < e.Wo) e.y[(pix + xr + i) * e.ldy + co] = v[i];
+            r[i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rrs, (cok && xr + i < e.Wo) ? vr : (int)0x80000000, i * e.ldr * 4, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float v = ct_epilogue_value(e, acc[i], co, sc, sh, r[i]);
+        __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(v), yrs, (cok && xr + i < e.Wo) ? vy : (int)0x80000000, i * e.ldy * 4, 0);
     }
 }
 

@@ -75,40 +75,48 @@ __device__ __forceinline__ void ksplit_conv_tile(const float *xin, int H, int W,
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // = K slab inside a chunk (uniform: SGPR)
     const int iy0 = oy0 * STRIDE - PAD, ix0 = ox0 * STRIDE - PAD;
 
-    int goff[C::NR], loff[C::NR];
+    // staging (round 6): thread -> (channel quad q = tid & 3, slot tid >> 2); a slot is patch pixel P (+ SP per pixel round) of
+    // slab kk0 (+ KG per slab round).  Row / column, the inside-the-image test and the swizzled LDS address are computed once
+    // per pixel round; the slab is an immediate offset of the loads and of the LDS stores.  The patch comes through a buffer
+    // descriptor of the image: out-of-image pixels carry an out-of-range offset and the hardware returns zeros for them.
+    constexpr int SLOTS = C::NTHR / 4;                   // 32 / 64 / 128
+    constexpr int SP = SLOTS < 64 ? SLOTS : 64;          // pixel slots per round
+    constexpr int KG = SLOTS / SP;                       // slab groups side by side in the thread block
+    constexpr int RP = (C::PP + SP - 1) / SP;
+    constexpr int RK = (WK + KG - 1) / KG;
+    constexpr int SNR = RP * RK;
+    const int sq = tid & 3, sslot = tid >> 2;
+    const int skk0 = sslot / SP, sP0 = sslot - skk0 * SP;
+    int goff[RP], loff[RP];
 #pragma unroll
-    for (int r = 0; r < C::NR; ++r) {
-        const int it = tid + C::NTHR * r;
-        if (it < C::ITEMS) {
-            const int q = it & 3;
-            const int pp = it >> 2;
-            const int kk = pp / C::PP;
-            const int P = pp - kk * C::PP;
-            const int py = P / C::PW, px = P - py * C::PW;
-            const int iy = iy0 + py, ix = ix0 + px;
-            loff[r] = kk * C::SLAB + P * 16 + ((q ^ ((P >> 1) & 2)) << 2);
-            goff[r] = (iy >= 0 && iy < H && ix >= 0 && ix < W) ? ((iy * W + ix) * ldx + kk * 16 + q * 4) * 4 : (int)0x80000000;
-        } else {
-            loff[r] = -1;
-            goff[r] = (int)0x80000000;
-        }
+    for (int j = 0; j < RP; ++j) {
+        const int P = sP0 + SP * j;
+        const int py = P / C::PW, px = P - py * C::PW;
+        const int iy = iy0 + py, ix = ix0 + px;
+        loff[j] = (P < C::PP) ? skk0 * C::SLAB + P * 16 + ((sq ^ ((P >> 1) & 2)) << 2) : -1;
+        goff[j] = (P < C::PP && iy >= 0 && iy < H && ix >= 0 && ix < W) ? ((iy * W + ix) * ldx + skk0 * 16 + sq * 4) * 4 : (int)0x80000000;
     }
-    // (round 6) staging through a buffer descriptor of the image: item byte offset in the vector offset, chunk in the scalar
-    // offset, out-of-image items out of range (the hardware returns zeros): no address arithmetic and no select per item
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(xin), 0, (int)((((unsigned)H * W - 1u) * ldx + Cin) * 4u), 0x00020000);
-    f32x4 stage[C::NR];
+    f32x4 stage[SNR];
     auto stage_load = [&](int chunk) {
         const int coff = chunk * (16 * WK * 4);
 #pragma unroll
-        for (int r = 0; r < C::NR; ++r)
-            stage[r] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[r], coff, 0));
+        for (int k = 0; k < RK; ++k)
+#pragma unroll
+            for (int j = 0; j < RP; ++j)
+                if (skk0 + k * KG < WK)                         // (compile-time true unless WK is no multiple of KG)
+                    stage[k * RP + j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, goff[j] + k * (KG * 64), coff, 0));
     };
     auto stage_store = [&](int buf) {
         float *dst = lds + buf * C::BUF;
 #pragma unroll
-        for (int r = 0; r < C::NR; ++r)
-            if (loff[r] >= 0) *reinterpret_cast<f32x4 *>(dst + loff[r]) = stage[r];
+        for (int j = 0; j < RP; ++j)
+            if (loff[j] >= 0) {
+#pragma unroll
+                for (int k = 0; k < RK; ++k)
+                    if (skk0 + k * KG < WK) *reinterpret_cast<f32x4 *>(dst + loff[j] + k * (KG * C::SLAB)) = stage[k * RP + j];
+            }
     };
 
     const int li = lane & 15, lg = lane >> 4;
