@@ -33,6 +33,7 @@ struct DcnArgs {
     int NT;
     int nchunks, chunksPerSplit;     // chunks of 32 channels
     int tiles;                       // N * tilesY * tilesX * coutBlocks: workgroups per split
+    int ptiles, splits;              // N * tilesY * tilesX pixel tiles; K splits (the persistent form strides over pixel tiles)
     float *ws;
     int wsCout;
     const float *w_off;              // fused offset/mask conv (FUSE kernels; per layer: nullptr = read `om`):
@@ -104,6 +105,92 @@ __device__ __forceinline__ f32x4 dcn_blend(const f32x4 w, const f32x4 (&c)[4])
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(lo) : "v"(w23), "v"(c[3].lo));
     asm("v_pk_fma_f32 %0, %1, %2, %0 op_sel:[1,0,0] op_sel_hi:[1,1,1]" : "+v"(hi) : "v"(w23), "v"(c[3].hi));
     return f32x4{lo[0], lo[1], hi[0], hi[1]};
+}
+
+// One entry of the sampling table: (pixel, tap) -> 4 corner BYTE offsets + 4 weights (bilinear x mask; an invalid corner has
+// offset 0 and weight 0).  fyk / fxk = the tap's undeformed position (float)(oy - 1 + ky), (float)(ox - 1 + kx); `in` = the
+// pixel lies inside the map.  Round 6: written without branches and with 24-bit multiplies -- a workgroup builds 9 entries
+// per pixel, all four waves of a SIMD do it at the same time (the dispatcher starts a launch's workgroups in rounds), and
+// vector instructions are paid on top of the fp32 MFMA time on this part: the 7.6 k clocks of this phase (of 56 k in a
+// 64 -> 64 workgroup's life at four streams, profiles/r06_q_dcn_phases_b4.txt) were instruction issue, not latency.
+// Entries are stored TAP-major (index k * BM + m): thread `it` of a pass owns tap it / BM, pixel it % BM -- no division by 9.
+__device__ __forceinline__ void dcn_tab_entry(float dy, float dx, float mk, float fyk, float fxk, bool in, int H, int W, int ldx4,
+                                              int rowb, int4 &o, f32x4 &w)
+{
+    const float ys = fyk + dy, xs = fxk + dx;
+    const float yf = floorf(ys), xf = floorf(xs);
+    const int y0 = (int)yf, x0 = (int)xf;
+    const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
+    const bool ok = in & (ys > -1.0f) & (xs > -1.0f) & (ys < (float)H) & (xs < (float)W);
+    const bool vy0 = ok & (y0 >= 0), vy1 = ok & (y0 + 1 <= H - 1), vx0 = x0 >= 0, vx1 = x0 + 1 <= W - 1;
+    const int base = __mul24(__mul24(y0, W) + x0, ldx4);            // (only the valid corners use it)
+    o.x = (vy0 & vx0) ? base : 0;
+    o.y = (vy0 & vx1) ? base + ldx4 : 0;
+    o.z = (vy1 & vx0) ? base + rowb : 0;
+    o.w = (vy1 & vx1) ? base + rowb + ldx4 : 0;
+    w[0] = (vy0 & vx0) ? hy * hx * mk : 0.0f;
+    w[1] = (vy0 & vx1) ? hy * lx * mk : 0.0f;
+    w[2] = (vy1 & vx0) ? ly * hx * mk : 0.0f;
+    w[3] = (vy1 & vx1) ? ly * lx * mk : 0.0f;
+}
+
+// accumulators of one tile (WM rows of 16 pixels x WN tiles of 16 couts per wave) -> split-K partials / raw tiles (a.ws) or the
+// finished output (BN + ReLU)
+template <int WM, int WN>
+__device__ __forceinline__ void dcn_store_acc(const DcnArgs &a, const f32x4 (&acc)[WM][WN], int n, int oy0, int ox0, int split, int nt0,
+                                              int wm, int lane, const float (&psc)[WN], const float (&psh)[WN])
+{
+    const int li = lane & 15, lg = lane >> 4;
+    if (a.ws) {
+        // raw tiles / split-K partials: buffer stores -- the lane's (pixel, cout) offset once per n-tile, row and pixel steps as
+        // scalar offsets; lanes past the map's edge or the padded Cout get an out-of-range offset the hardware drops
+        const size_t Mtot = (size_t)a.N * a.H * a.W;
+        float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
+        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(wsp, 0, (int)(Mtot * a.wsCout * 4), 0x00020000);
+        const int pixb = a.wsCout * 4, rowb2 = a.W * pixb;
+        const int oyb = oy0 + wm * WM;
+        const int px0 = ox0 + lg * 4;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int co = (nt0 + nt) * 16 + li;
+            const int vbase = (((n * a.H + oyb) * a.W + px0) * a.wsCout + co) * 4;
+            int vo[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vo[e] = (co < a.wsCout && px0 + e < a.W) ? vbase : (int)0x80000000;
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt) {
+                if (oyb + mt >= a.H) continue;                      // (uniform)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][e]), srs, vo[e], mt * rowb2 + e * pixb, CT_WS_AUX);
+            }
+        }
+    } else {
+        // finished output: BN + ReLU (the DCN entry points take no other epilogue), stored like the partials above
+        const EpiArgs &e = a.epi;
+        const unsigned img = (unsigned)a.H * a.W;
+        const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(
+            e.y + (size_t)n * img * e.ldy, 0, (int)(((img - 1u) * e.ldy + e.Cout) * 4u), 0x00020000);
+        const int pixb = e.ldy * 4, rowb2 = a.W * pixb;
+        const int oyb = oy0 + wm * WM;
+        const int px0 = ox0 + lg * 4;
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) {
+            const int co = (nt0 + nt) * 16 + li;
+            const int vbase = (__mul24(__mul24(oyb, a.W) + px0, e.ldy) + co) * 4;
+            int vo[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) vo[i] = (co < e.Cout && px0 + i < a.W) ? vbase : (int)0x80000000;
+#pragma unroll
+            for (int mt = 0; mt < WM; ++mt) {
+                if (oyb + mt >= a.H) continue;                      // (uniform)
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(ct_epilogue_plain(e, acc[mt][nt][i], psc[nt], psh[nt], 0.0f)),
+                                                          yrs, vo[i], mt * rowb2 + i * pixb, 0);
+            }
+        }
+    }
 }
 
 template <int BM, int WN, bool FUSE, int NKK = 2>
@@ -236,7 +323,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         if (!a.ws) ct_load_scale_shift(a.epi, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
     }
 
-    // ---- sampling table: (pixel m, tap k) -> 4 corner BYTE offsets + 4 weights (mask folded in) ----
+    // ---- sampling table: (pixel m, tap k) -> 4 corner BYTE offsets + 4 weights (mask folded in), tap-major ----
     // (all offset/mask loads of a thread are issued before any of them is used: one round trip; a wave whose lanes hold no
     //  entry in a pass skips it -- 288 entries on 256 threads: the second pass is wave 0's alone)
     {
@@ -248,7 +335,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         for (int i = 0; i < TI; ++i) {
             if (wave * 64 + NTHR * i >= E) continue;                 // (uniform)
             const int it = tid + NTHR * i;
-            const int m = it / 9, k = it - m * 9;
+            const int k = it / BM, m = it & (BM - 1);
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             const bool in = it < E && oy < a.H && ox < a.W;
             if (parts) {
@@ -276,30 +363,17 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         for (int i = 0; i < TI; ++i) {
             if (wave * 64 + NTHR * i >= E) continue;                 // (uniform)
             const int it = tid + NTHR * i;
-            if (it >= E) continue;
-            const int m = it / 9, k = it - m * 9;
+            const int k = it / BM, m = it & (BM - 1);
             const int ky = (k * 11) >> 5, kx = k - 3 * ky;            // k / 3, k % 3 for k < 9
-            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);   // m < BM
-            int o[4] = {0, 0, 0, 0};
-            float wgt[4] = {0.f, 0.f, 0.f, 0.f};
-            if (oy < a.H && ox < a.W) {
-                const float dy = tdy[i], dx = tdx[i], mk = tmk[i];
-                const float ys = (float)(oy - 1 + ky) + dy;
-                const float xs = (float)(ox - 1 + kx) + dx;
-                if (ys > -1.0f && xs > -1.0f && ys < (float)a.H && xs < (float)a.W) {
-                    const float yf = floorf(ys), xf = floorf(xs);
-                    const int y0 = (int)yf, x0 = (int)xf;
-                    const float ly = ys - yf, lx = xs - xf, hy = 1.0f - ly, hx = 1.0f - lx;
-                    const bool vy0 = y0 >= 0, vy1 = y0 + 1 <= a.H - 1, vx0 = x0 >= 0, vx1 = x0 + 1 <= a.W - 1;
-                    const int base = (y0 * a.W + x0) * ldx4;         // (only the valid corners use it)
-                    if (vy0 && vx0) { o[0] = base; wgt[0] = hy * hx * mk; }
-                    if (vy0 && vx1) { o[1] = base + ldx4; wgt[1] = hy * lx * mk; }
-                    if (vy1 && vx0) { o[2] = base + rowb; wgt[2] = ly * hx * mk; }
-                    if (vy1 && vx1) { o[3] = base + rowb + ldx4; wgt[3] = ly * lx * mk; }
-                }
+            const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
+            int4 o;
+            f32x4 wgt;
+            dcn_tab_entry(tdy[i], tdx[i], tmk[i], (float)(oy - 1 + ky), (float)(ox - 1 + kx), it < E && oy < a.H && ox < a.W,
+                          a.H, a.W, ldx4, rowb, o, wgt);
+            if (it < E) {
+                *reinterpret_cast<int4 *>(tab_off + it * 4) = o;
+                *reinterpret_cast<f32x4 *>(tab_w + it * 4) = wgt;
             }
-            *reinterpret_cast<int4 *>(tab_off + it * 4) = make_int4(o[0], o[1], o[2], o[3]);
-            *reinterpret_cast<f32x4 *>(tab_w + it * 4) = f32x4{wgt[0], wgt[1], wgt[2], wgt[3]};
         }
     }
     __syncthreads();
@@ -318,13 +392,13 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float *>(xin), 0, (int)((((unsigned)a.H * a.W - 1u) * a.ldx + a.Cin) * 4u), 0x00020000);
     const int tconst = (gk0 * 16 + gq * 4) * 4;
-    const int taddr = gm * (9 * 16);                             // byte offset of this pixel's first table entry
+    const int taddr = gm * 16;                                   // byte offset of this pixel's entry of tap 0 (tap-major table)
     // two gather stages in flight (register slots 0/1): the corner loads of step s+2 are issued
     // before the MFMAs of step s and consumed (blend + LDS store) after the MFMAs of step s+1
     f32x4 cv[2][GK][4];
     f32x4 gw[2];
     auto gather_load = [&](int slot, int chunk, int tap) {
-        const int ta = taddr + tap * 16;
+        const int ta = taddr + tap * (BM * 16);
         const int4 o = *reinterpret_cast<const int4 *>(reinterpret_cast<const char *>(tab_off) + ta);
         gw[slot] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(tab_w) + ta);
         const int so = chunk * (16 * NKK * 4);
@@ -439,39 +513,326 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
     CT_STAMP(5);
     CT_STAMP_VAL(8, pi);
     CT_STAMP_VAL(9, nmax);
-    if (a.ws) {
-        // raw tiles / split-K partials: buffer stores -- the lane's (pixel, cout) offset once per n-tile, row and pixel steps as
-        // scalar offsets; lanes past the map's edge or the padded Cout get an out-of-range offset the hardware drops
-        const size_t Mtot = (size_t)a.N * a.H * a.W;
-        float *wsp = a.ws + (size_t)split * Mtot * a.wsCout;
-        const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(wsp, 0, (int)(Mtot * a.wsCout * 4), 0x00020000);
-        const int pixb = a.wsCout * 4, rowb2 = a.W * pixb;
-        const int oyb = oy0 + wm * WM;
-        const int px0 = ox0 + lg * 4;
+    dcn_store_acc<WM, WN>(a, acc, n, oy0, ox0, split, nt0, wm, lane, psc, psh);
+    CT_STAMP(6);
+    CT_STAMP_RT(7);
+}
+
+// ---- persistent form of the MAIN launch (round 6) ----------------------------------------------------------------------
+// Phase stamps of the kernel above at four streams (profiles/r06_q_dcn_phases_b4.txt): inside its loop a workgroup runs AT the
+// matrix pipe's rate -- 2060 clocks per (chunk, tap) step with four workgroups per CU, 4 x 512 clocks of MFMA issue per SIMD --
+// but a third of a 64 -> 64 workgroup's life is not the loop (kernel arguments 3.3 k clocks, sampling table 7.6 k, first
+// gathers 3.1 k, epilogue 4.9 k against 37 k of loop), and the dispatcher starts a launch's workgroups in rounds that stay
+// in phase: all of them build tables at the same time, then all of them loop.  Here a launch is `slots` resident workgroups;
+// each owns one (layer, cout block, K split) column and strides over its pixel tiles as ONE stream of (chunk, tap) steps:
+// the corner loads two steps ahead and the weight loads one step ahead run across tile boundaries, the next tile's
+// offset / mask values are fetched during the first two steps of a tile and its sampling table (a second LDS copy) is
+// built right after them, the epilogue is stores between two steps.  Same tile shape, same K order, same splits as the
+// kernel above: bit-identical results.
+struct DcnPersist {
+    DcnArgs p[DCN_MAX_GROUP];
+    int first[DCN_MAX_GROUP + 1];    // workgroup ids [first[i], first[i+1]) work on layer i ...
+    int per_col[DCN_MAX_GROUP];      // ... per_col[i] of them on each of its (cout block, K split) columns
+    int n;
+};
+
+template <int WN, int NKK>
+__global__ __launch_bounds__(256) void dcn_persist_kernel(DcnPersist g)
+{
+    constexpr int BM = 32, WM = 2, WGN = 4;
+    constexpr int SLAB = BM * 16, BUF = NKK * SLAB, NTHR = 256, UPC2 = NKK / 2;
+    constexpr int E = BM * 9;
+    constexpr int TABB = 2 * E * 16;                 // bytes of one table: int4 offsets[E], then float4 weights[E]
+    // dynamic LDS: A tile double buffer | two sampling tables
+    extern __shared__ __attribute__((aligned(16))) float dlds[];
+    float *lds_a = dlds;
+    char *tab = reinterpret_cast<char *>(dlds + 2 * BUF);
+
+    // (stamps, debug builds: 0 / 15 real time at start / end, 1 start, 2 first table + gathers done, then per tile i < 4:
+    //  3+3i first two steps + next table, 4+3i loop, 5+3i stores; 16 tiles walked, 17 steps per tile, 18 layer)
+    CT_STAMP_RT(0);
+    CT_STAMP(1);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wn = wave;                             // 1 x 4 waves: every wave holds all 32 pixels x its own WN cout tiles
+
+    int bid = blockIdx.x;
+    int pi = 0;
 #pragma unroll
-        for (int nt = 0; nt < WN; ++nt) {
-            const int co = (nt0 + nt) * 16 + li;
-            const int vbase = (((n * a.H + oyb) * a.W + px0) * a.wsCout + co) * 4;
-            int vo[4];
+    for (int i = 1; i < DCN_MAX_GROUP; ++i)
+        if (i < g.n && bid >= g.first[i]) pi = i;
+    const DcnArgs &a = g.p[pi];
+    bid -= g.first[pi];
+    const int per = g.per_col[pi];
+    const int col = bid / per;
+    int t = bid - col * per;                         // first pixel tile; then t += per
+    const int cb = col % a.coutBlocks, split = col / a.coutBlocks;
+    const int ptiles = a.ptiles;
+    if (t >= ptiles) return;                         // (uniform; the host never launches such workgroups)
+    const int tilesX = a.tilesX, txy = tilesX * a.tilesY;
+    auto coords = [&](int tt, int &n, int &oy0, int &ox0) {
+        n = tt / txy;
+        const int r = tt - n * txy;
+        const int ty = r / tilesX;
+        oy0 = ty * 2;
+        ox0 = (r - ty * tilesX) * 16;
+    };
+    const int nunits = a.nchunks / UPC2;
+    const int c_begin = split * (a.chunksPerSplit / UPC2);
+    const int c_end = min(nunits, c_begin + a.chunksPerSplit / UPC2);
+    const int nsteps = (c_end - c_begin) * 9;        // per tile; even (host)
+
+    // ---- weights: as in dcn_mfma_kernel ----
+    const int li = lane & 15, lg = lane >> 4;
+    const int nt0 = cb * (WGN * WN) + wn * WN;
+    const int NCH16 = a.Cin >> 4;
+    const int slab_bytes = a.NT << 10;
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.wp), 0, 9 * NCH16 * slab_bytes, 0x00020000);
+    int bvo[WN];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) vo[e] = (co < a.wsCout && px0 + e < a.W) ? vbase : (int)0x80000000;
+    for (int nt = 0; nt < WN; ++nt) bvo[nt] = (min(nt0 + nt, a.NT - 1) << 10) + (lane << 4);
+    auto load_b = [&](f32x4 (&b)[NKK][WN], int chunk, int tap) {
+        const int so = (tap * NCH16 + chunk * NKK) * slab_bytes;
 #pragma unroll
-            for (int mt = 0; mt < WM; ++mt) {
-                if (oyb + mt >= a.H) continue;                      // (uniform)
+        for (int kk = 0; kk < NKK; ++kk)
 #pragma unroll
-                for (int e = 0; e < 4; ++e)
-                    __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(acc[mt][nt][e]), srs, vo[e], mt * rowb2 + e * pixb, CT_WS_AUX);
+            for (int nt = 0; nt < WN; ++nt)
+                b[kk][nt] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, bvo[nt], so + kk * slab_bytes, 0));
+    };
+    float psc[WN], psh[WN];
+#pragma unroll
+    for (int nt = 0; nt < WN; ++nt) {
+        psc[nt] = 1.0f; psh[nt] = 0.0f;
+        if (!a.ws) ct_load_scale_shift(a.epi, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
+    }
+
+    // ---- sampling table of one tile, in two halves: fetch (global loads into registers) and build (-> LDS) ----
+    // Tap-major entries: pass 0 = tap tid >> 5 of pixel tid & 31 (all threads), pass 1 = tap 8 of pixel tid (the first 32 lanes
+    // of wave 0) -- the same pixel in both passes.  Everything of an entry that does not depend on the tile is computed here,
+    // once per workgroup; per tile the offset / mask values come through ONE buffer descriptor (the tile's first pixel in the
+    // scalar offset, the entry's own offset a constant VGPR).
+    const int H = a.H, W = a.W, omSplits = a.omSplits;          // (kept in SGPRs: the tile loop reads them at every boundary)
+    const bool parts = omSplits > 0;                 // (uniform)
+    const int ldx4 = a.ldx * 4, rowb = a.W * ldx4;
+    const unsigned imgb = (unsigned)a.H * a.W * (unsigned)ldx4;      // bytes of one image of the input view
+    const int my = (tid >> 4) & 1, mx = tid & 15;
+    const int k0 = tid >> 5, ky0 = (k0 * 11) >> 5, kx0 = k0 - 3 * ky0;
+    const float fy0 = (float)(my - 1 + ky0), fx0 = (float)(mx - 1 + kx0);
+    const int opitch = parts ? 32 : a.ldom;
+    const int epix = (my * a.W + mx) * opitch * 4;
+    const unsigned oplane = (unsigned)a.N * a.H * a.W * 32u * 4u;   // bytes of one partial map (parts)
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(parts ? a.omPart : a.om), 0,
+        parts ? (int)((unsigned)a.omSplits * oplane) : (int)((((unsigned)a.N * a.H * a.W - 1u) * a.ldom + 27u) * 4u), 0x00020000);
+    float bdy0 = 0.f, bdx0 = 0.f, bmk0 = 0.f, bdy1 = 0.f, bdx1 = 0.f, bmk1 = 0.f;      // conv_offset_mask.bias of the two taps
+    if (parts) {
+        bdy0 = a.b_off[2 * k0]; bdx0 = a.b_off[2 * k0 + 1]; bmk0 = a.b_off[18 + k0];
+        bdy1 = a.b_off[16]; bdx1 = a.b_off[17]; bmk1 = a.b_off[26];
+    }
+    constexpr int TI = 2;
+    auto om_fetch = [&](int n, int oy0, int ox0, float (&tdy)[TI], float (&tdx)[TI], float (&tmk)[TI]) {
+        const bool in0 = (oy0 + my < H) & (ox0 + mx < W), in1 = in0 & (tid < 32);
+        const int so = (int)((((unsigned)n * H + oy0) * W + ox0) * (unsigned)opitch * 4u);
+        const int v0 = in0 ? epix + 8 * k0 : (int)0x80000000, m0 = in0 ? epix + (18 + k0) * 4 : (int)0x80000000;
+        const int v1 = in1 ? epix + 64 : (int)0x80000000, m1 = in1 ? epix + 104 : (int)0x80000000;
+        tdy[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v0, so, 0));
+        tdx[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v0 + 4, so, 0));
+        tmk[0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, m0, so, 0));
+        tdy[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v1, so, 0));
+        tdx[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v1 + 4, so, 0));
+        tmk[1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, m1, so, 0));
+    };
+    auto table_build = [&](char *tb, int n, int oy0, int ox0, float (&tdy)[TI], float (&tdx)[TI], float (&tmk)[TI]) {
+        const bool in0 = (oy0 + my < H) & (ox0 + mx < W), in1 = in0 & (tid < 32);
+        if (parts) {
+            // the other chunks of the K-split offset conv (chunk order), then the bias and the mask's sigmoid
+            const int v0 = in0 ? epix + 8 * k0 : (int)0x80000000, m0 = in0 ? epix + (18 + k0) * 4 : (int)0x80000000;
+            const int v1 = in1 ? epix + 64 : (int)0x80000000, m1 = in1 ? epix + 104 : (int)0x80000000;
+            int so = (int)((((unsigned)n * H + oy0) * W + ox0) * 128u);
+            for (int sp = 1; sp < omSplits; ++sp) {
+                so += (int)oplane;
+                const float a0 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v0, so, 0));
+                const float a1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v0 + 4, so, 0));
+                const float a2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, m0, so, 0));
+                const float a3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v1, so, 0));
+                const float a4 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, v1 + 4, so, 0));
+                const float a5 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(ors, m1, so, 0));
+                tdy[0] += a0; tdx[0] += a1; tmk[0] += a2; tdy[1] += a3; tdx[1] += a4; tmk[1] += a5;
+            }
+            tdy[0] += bdy0; tdx[0] += bdx0; tmk[0] = dcn_mask_sigmoid(tmk[0] + bmk0);
+        }
+        const float oyf = (float)oy0, oxf = (float)ox0;
+        int4 o;
+        f32x4 wgt;
+        dcn_tab_entry(tdy[0], tdx[0], tmk[0], oyf + fy0, oxf + fx0, in0, H, W, ldx4, rowb, o, wgt);
+        *reinterpret_cast<int4 *>(tb + tid * 16) = o;
+        *reinterpret_cast<f32x4 *>(tb + E * 16 + tid * 16) = wgt;
+        if (wave == 0) {                                 // (uniform) tap 8: ky = kx = 2
+            if (parts) { tdy[1] += bdy1; tdx[1] += bdx1; tmk[1] = dcn_mask_sigmoid(tmk[1] + bmk1); }
+            dcn_tab_entry(tdy[1], tdx[1], tmk[1], oyf + (float)(my + 1), oxf + (float)(mx + 1), in1, H, W, ldx4, rowb, o, wgt);
+            if (tid < 32) {
+                *reinterpret_cast<int4 *>(tb + (256 + tid) * 16) = o;
+                *reinterpret_cast<f32x4 *>(tb + E * 16 + (256 + tid) * 16) = wgt;
             }
         }
-    } else {
+    };
+
+    // ---- gather assignment (BM = 32): thread -> (pixel tl >> 3, quad tl & 3), slabs (tl >> 2) & 1, +2, .. ----
+    constexpr int GK = NKK / 2;
+    const int gm = tid >> 3, gq = tid & 3, gk0 = (tid >> 2) & 1;
+    const int lslot = gm * 16 + ((gq ^ ((gm >> 1) & 2)) << 2);
+    float *lds_g = lds_a;
+    // ONE buffer descriptor for the whole batch: the image goes into the scalar offset beside the chunk
+    const __amdgpu_buffer_rsrc_t xrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float *>(a.x), 0, (int)((unsigned)(a.N - 1) * imgb + (((unsigned)a.H * a.W - 1u) * a.ldx + a.Cin) * 4u), 0x00020000);
+    const int tconst = (gk0 * 16 + gq * 4) * 4;
+    const int taddr = gm * 16;
+    f32x4 cv[2][GK][4];
+    f32x4 gw[2];
+    auto gather_load = [&](int slot, const char *tb, int xoff, int chunk, int tap) {
+        const int ta = taddr + tap * (BM * 16);
+        const int4 o = *reinterpret_cast<const int4 *>(tb + ta);
+        gw[slot] = *reinterpret_cast<const f32x4 *>(tb + E * 16 + ta);
+        const int so = xoff + chunk * (16 * NKK * 4);
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            cv[slot][kk][0] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.x + tconst + kk * 128, so, 0));
+            cv[slot][kk][1] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.y + tconst + kk * 128, so, 0));
+            cv[slot][kk][2] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.z + tconst + kk * 128, so, 0));
+            cv[slot][kk][3] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, o.w + tconst + kk * 128, so, 0));
+        }
+    };
+    int aoff[WM];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt) {
+        const int m = mt * 16 + li;
+        aoff[mt] = m * 16 + ((lg ^ ((m >> 1) & 2)) << 2);
+    }
+    f32x4 acc[WM][WN];
+#pragma unroll
+    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // ---- the tile this workgroup starts with: table, the first two gathers, the first weights ----
+    int n_c, oy_c, ox_c;
+    coords(t, n_c, oy_c, ox_c);
+    int tsel_c = 0;                                  // byte offset of the current tile's table (0 / TABB)
+    {
+        float tdy[TI], tdx[TI], tmk[TI];
+        om_fetch(n_c, oy_c, ox_c, tdy, tdx, tmk);
+        table_build(tab, n_c, oy_c, ox_c, tdy, tdx, tmk);
+    }
+    f32x4 bq[2][NKK][WN];
+    load_b(bq[0], c_begin, 0);
+    __syncthreads();
+    int xoff_c = (int)((unsigned)n_c * imgb);
+    {
+        // (steps 0 and 1 of a tile: taps 0 and 1 of its first unit -- nsteps >= 18)
+        gather_load(0, tab, xoff_c, c_begin, 0);
+        gather_load(1, tab, xoff_c, c_begin, 1);
+#pragma unroll
+        for (int kk = 0; kk < GK; ++kk) {
+            const f32x4 v = dcn_blend(gw[0], cv[0][kk]);
+            *reinterpret_cast<f32x4 *>(lds_g + (gk0 + kk * 2) * SLAB + lslot) = v;
+        }
+    }
+    __syncthreads();
+    CT_STAMP(2);
+    int ntile = 0;
+    // The four workgroups of a CU share its SIMDs, and the issue arbiter serves the oldest wave first: identical workgroups
+    // drift apart (lives of 35 .. 55 us at 45 on average, profiles/r06_u), and the launch ends on stragglers that have nobody
+    // left to hide their latencies behind.  Priority by progress -- a workgroup starts at 3 and drops a level with every
+    // quarter of its tiles done -- keeps the four abreast (variant builds may switch it off: -DCT_DCN_PRIO=0).
+#ifndef CT_DCN_PRIO
+#define CT_DCN_PRIO 1
+#endif
+    const int ntiles = (ptiles - t + per - 1) / per;
+    if (CT_DCN_PRIO) __builtin_amdgcn_s_setprio(3);
+
+    for (;;) {
+        // the tile after this one (the last tile of the workgroup names itself: its fetches are valid and never used)
+        const int t_n = (t + per < ptiles) ? t + per : t;
+        int n_n, oy_n, ox_n;
+        coords(t_n, n_n, oy_n, ox_n);
+        const int tsel_n = TABB - tsel_c;
+        const int xoff_n = (int)((unsigned)n_n * imgb);
+        // step s of the stream (P = s & 1 static): as in dcn_mfma_kernel, except that steps s+1 / s+2 past the tile's end
+        // are steps 0 / 1 of the NEXT tile (its table, its image)
+        auto step = [&](auto ptag, int s) {
+            constexpr int P = decltype(ptag)::value;
+            int u1 = s + 1, u2 = s + 2;
+            const bool x1 = u1 >= nsteps, x2 = u2 >= nsteps;         // (uniform)
+            u1 = x1 ? u1 - nsteps : u1;
+            u2 = x2 ? u2 - nsteps : u2;
+            const int q1 = u1 / 9, q2 = u2 / 9;
+            const int c1 = c_begin + q1, t1 = u1 - q1 * 9;
+            const int c2 = c_begin + q2, t2 = u2 - q2 * 9;
+            f32x4 af[NKK][WM];
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                for (int mt = 0; mt < WM; ++mt)
+                    af[kk][mt] = *reinterpret_cast<const f32x4 *>(lds_g + P * BUF + kk * SLAB + aoff[mt]);
+            load_b(bq[P ^ 1], c1, t1);
+            gather_load(P, tab + (x2 ? tsel_n : tsel_c), x2 ? xoff_n : xoff_c, c2, t2);
+            f32x4 v[GK];
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+                v[kk] = dcn_blend(gw[P ^ 1], cv[P ^ 1][kk]);
+            __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+            for (int kk = 0; kk < NKK; ++kk)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int mt = 0; mt < WM; ++mt)
+#pragma unroll
+                        for (int nt = 0; nt < WN; ++nt)
+                            acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[kk][mt][e], bq[P][kk][nt][e], acc[mt][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0x386);
+#pragma unroll
+            for (int kk = 0; kk < GK; ++kk)
+                *reinterpret_cast<f32x4 *>(lds_g + (P ^ 1) * BUF + (gk0 + kk * 2) * SLAB + lslot) = v[kk];
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        // steps 0 / 1 with the next tile's offset / mask values in flight beside them, then its table
+        {
+            float tdy[TI], tdx[TI], tmk[TI];
+            om_fetch(n_n, oy_n, ox_n, tdy, tdx, tmk);
+            step(std::integral_constant<int, 0>{}, 0);
+            step(std::integral_constant<int, 1>{}, 1);
+            if (ntile < 2) CT_STAMP(19 + ntile);
+            table_build(tab + tsel_n, n_n, oy_n, ox_n, tdy, tdx, tmk);
+        }
+        if (ntile < 4) CT_STAMP(3 + 3 * ntile);
+        for (int s = 2; s < nsteps; s += 2) {
+            step(std::integral_constant<int, 0>{}, s);
+            step(std::integral_constant<int, 1>{}, s + 1);
+        }
+        if (ntile < 4) CT_STAMP(4 + 3 * ntile);
+        dcn_store_acc<WM, WN>(a, acc, n_c, oy_c, ox_c, split, nt0, 0, lane, psc, psh);
+        if (ntile < 4) CT_STAMP(5 + 3 * ntile);
+        ++ntile;
+        CT_STAMP_VAL(16, ntile);
+        if (t_n == t) break;
+        if (CT_DCN_PRIO) {
+            const int q = (4 * ntile) / ntiles;          // (uniform)
+            if (q == 1) __builtin_amdgcn_s_setprio(2);
+            else if (q == 2) __builtin_amdgcn_s_setprio(1);
+            else if (q >= 3) __builtin_amdgcn_s_setprio(0);
+        }
 #pragma unroll
         for (int mt = 0; mt < WM; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < WN; ++nt)
-                ct_store_tile(a.epi, acc[mt][nt], n, oy0 + wm * WM + mt, ox0, (nt0 + nt) * 16, lane, psc[nt], psh[nt]);
+            for (int nt = 0; nt < WN; ++nt) acc[mt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+        t = t_n; n_c = n_n; oy_c = oy_n; ox_c = ox_n; tsel_c = tsel_n; xoff_c = xoff_n;
     }
-    CT_STAMP(6);
-    CT_STAMP_RT(7);
+    CT_STAMP_VAL(17, nsteps);
+    CT_STAMP_VAL(18, pi);
+    CT_STAMP_RT(15);
 }
 
 // Measured and dropped in round 6 (profiles/r06_c_kbench_ws_b8.txt, r06_d_ws_ablations_b8.txt, r06_e_priorities_b8.txt): a
@@ -516,6 +877,7 @@ struct DcnPlan {
     int parts;                       // offset/mask conv K-split into Cin / 64 partial maps (fuse_offset == 2)
     int BM, BN, NKK, tilesX, tilesY, coutBlocks, NT, nchunks, splits, chunksPerSplit;
     int use_ws;                      // partial / raw tiles go through the workspace (split-K, or a fused IDAUp step of a group)
+    int persist;                     // MAIN launch in its persistent form (dcn_persist_kernel; algo 5xxxx / 6xxxx)
 };
 
 // `grouped`: the layer is one of several in a ct_dcn_v2_group launch (32-pixel x 64-cout tiles for all of them; a
@@ -556,8 +918,16 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     // algo: 0 heuristic; 64 / 128 = 64-pixel tile with 64 / 128 couts; 3264 / 32128 = 32-pixel tile; 43264 / 432128 =
     // 32-pixel tile stepping through 64 channels (32 * WN MFMAs per barrier)
     int algo = d->algo;
-    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128)
+    if (algo != 0 && algo != 64 && algo != 128 && algo != 3264 && algo != 32128 && algo != 43264 && algo != 432128 &&
+        algo != 53264 && algo != 532128 && algo != 63264 && algo != 632128)
         CT_FAIL_ARG("ct_dcn_v2: unknown algo %d", d->algo);
+    p->persist = 0;
+    if (algo == 53264 || algo == 532128 || algo == 63264 || algo == 632128) {
+        // persistent form of 3264 / 32128 / 43264 / 432128: same tiles, same K order, same splits
+        if (d->fuse_offset == 1) CT_FAIL_ARG("ct_dcn_v2: the persistent shapes (algo %d) read their offsets from a map (fuse_offset 0 / 2 / 3)", algo);
+        p->persist = 1;
+        algo = algo == 53264 ? 3264 : algo == 532128 ? 32128 : algo == 63264 ? 43264 : 432128;
+    }
     if (algo == 43264) { p->NKK = 4; algo = 3264; }
     else if (algo == 432128) { p->NKK = 4; algo = 32128; }
     if (grouped) {
@@ -600,6 +970,14 @@ int make_plan(const ct_dcn_desc *d, DcnPlan *p, bool grouped)
     p->chunksPerSplit = ct_cdiv(nunits, splits) * upc;
     p->splits = ct_cdiv(p->nchunks, p->chunksPerSplit);
     p->use_ws = (p->splits > 1 || (grouped && d->up_w)) ? 1 : 0;
+    if (p->persist) {
+        // every split owns the same EVEN number of step units (the stream of steps keeps its LDS / register parity across
+        // tiles), and one buffer descriptor spans the batch
+        const int ups = p->chunksPerSplit / upc;
+        if (p->BM != 32 || (ups & 1) || nunits % ups)
+            CT_FAIL_ARG("ct_dcn_v2: persistent shape needs an even number of %d-channel units per split (Cin=%d, split_k=%d)", 16 * p->NKK, d->Cin, p->splits);
+        if ((double)d->N * d->H * d->W * d->ldx * 4.0 >= 4294967296.0) CT_FAIL_ARG("ct_dcn_v2: persistent shape: input view of 4 GiB or more");
+    }
     return CT_OK;
 }
 
@@ -625,6 +1003,8 @@ struct RedArgs {
     int splits, wsCout;
     size_t Mtot;
     int N, H, W;
+    int rowBlocks;       // workgroups per output row (IDAUp step) / per input row (plain): a workgroup never straddles rows, so
+                         // (image, row) are scalar divisions of the workgroup id and a thread only splits (pixel, channel quad)
     EpiArgs e;
     UpArgs u;
 };
@@ -634,6 +1014,8 @@ struct RedGroup {
     int n;
 };
 
+// (round 6: 32-bit index arithmetic, rows decoded per workgroup -- the kernel moves 66 MB in the first FINISH launch of a
+//  four-stream frame and spent its time in three 64-bit divisions per thread: 22.6 us = 2.9 TB/s)
 __global__ __launch_bounds__(256) void dcn_reduce_kernel(RedGroup g)
 {
     int bid = blockIdx.x;
@@ -643,62 +1025,66 @@ __global__ __launch_bounds__(256) void dcn_reduce_kernel(RedGroup g)
         if (i < g.n && bid >= g.first[i]) pi = i;
     const RedArgs &r = g.p[pi];
     const EpiArgs &e = r.e;
-    const size_t idx = (size_t)(bid - g.first[pi]) * 256 + threadIdx.x;
+    bid -= g.first[pi];
+    const int row = bid / r.rowBlocks;                    // (scalar)
+    const unsigned inrow = (unsigned)(bid - row * r.rowBlocks) * 256u + threadIdx.x;
     const float *ws = r.ws;
     const int splits = r.splits, wsCout = r.wsCout;
-    const size_t Mtot = r.Mtot;
+    const unsigned plane = (unsigned)r.Mtot * wsCout;     // floats of one split's partial map (< 2^30: host)
     if (r.u.f == 0) {
-        const int quads = wsCout >> 2;
-        if (idx >= Mtot * quads) return;
-        const size_t m = idx / quads;
-        const int c4 = (int)(idx - m * quads) << 2;
-        f32x4 s = *reinterpret_cast<const f32x4 *>(ws + m * wsCout + c4);
-        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(ws + ((size_t)k * Mtot + m) * wsCout + c4);
+        const unsigned quads = wsCout >> 2;
+        const unsigned x = inrow / quads;
+        if (x >= (unsigned)r.W) return;
+        const unsigned c4 = (inrow - x * quads) << 2;
+        const unsigned m = (unsigned)row * r.W + x;       // row = n * H + y
+        const float *src = ws + (size_t)(m * wsCout + c4);
+        f32x4 s = *reinterpret_cast<const f32x4 *>(src);
+        for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(src + (size_t)k * plane);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int co = c4 + i;
             if (co >= e.Cout) break;
             const float sc = e.scale ? e.scale[co] : 1.0f;
             const float sh = e.shift ? e.shift[co] : 0.0f;
-            e.y[m * e.ldy + co] = ct_epilogue_value(e, s[i], co, sc, sh, 0.0f);
+            e.y[(size_t)m * e.ldy + co] = ct_epilogue_value(e, s[i], co, sc, sh, 0.0f);
         }
         return;
     }
     const UpArgs &u = r.u;
     const int H = r.H, W = r.W;
-    const int C = e.Cout, C4 = C >> 2, f = u.f, kw = 2 * f, p = f >> 1;
+    const int C = e.Cout, f = u.f, kw = 2 * f, p = f >> 1;
+    const unsigned C4 = C >> 2;
+    const int lf = 31 - __builtin_clz(f);                 // f = 2 / 4 / 8
     const int Ho = H * f, Wo = W * f;
-    const size_t total = (size_t)r.N * Ho * Wo * C4;
-    if (idx >= total) return;
-    const int c = (int)(idx % C4) * 4;
-    size_t q = idx / C4;
-    const int ox = (int)(q % Wo); q /= Wo;
-    const int oy = (int)(q % Ho);
-    const int n = (int)(q / Ho);
-    const int iy = (oy + p) / f, ky = (oy + p) - iy * f;
-    const int ix = (ox + p) / f, kx = (ox + p) - ix * f;
-    const size_t opix = ((size_t)n * Ho + oy) * Wo + ox;
-    f32x4 acc = *reinterpret_cast<const f32x4 *>(u.skip + opix * u.lds + c);
+    const unsigned ox = inrow / C4;
+    if (ox >= (unsigned)Wo) return;
+    const int c = (int)(inrow - ox * C4) * 4;
+    const int n = row / Ho, oy = row - n * Ho;            // (scalar)
+    const int iy = (oy + p) >> lf, ky = (oy + p) & (f - 1);
+    const int ix = ((int)ox + p) >> lf, kx = ((int)ox + p) & (f - 1);
+    const unsigned opix = (unsigned)row * Wo + ox;
+    f32x4 acc = *reinterpret_cast<const f32x4 *>(u.skip + (size_t)opix * u.lds + c);
     const f32x4 sc = e.scale ? *reinterpret_cast<const f32x4 *>(e.scale + c) : f32x4{1.f, 1.f, 1.f, 1.f};
     const f32x4 sh = e.shift ? *reinterpret_cast<const f32x4 *>(e.shift + c) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int jy = 0; jy < 2; ++jy) {
         const int yy = iy - jy;
-        if (yy < 0 || yy >= H) continue;
+        if (yy < 0 || yy >= H) continue;                  // (uniform)
 #pragma unroll
         for (int jx = 0; jx < 2; ++jx) {
             const int xx = ix - jx;
             if (xx < 0 || xx >= W) continue;
-            const size_t m = ((size_t)n * H + yy) * W + xx;
-            f32x4 s = *reinterpret_cast<const f32x4 *>(ws + m * wsCout + c);
-            for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(ws + ((size_t)k * Mtot + m) * wsCout + c);
+            const unsigned m = ((unsigned)n * H + yy) * W + xx;
+            const float *src = ws + (size_t)(m * wsCout + c);
+            f32x4 s = *reinterpret_cast<const f32x4 *>(src);
+            for (int k = 1; k < splits; ++k) s += *reinterpret_cast<const f32x4 *>(src + (size_t)k * plane);
             const int widx = (ky + f * jy) * kw + (kx + f * jx);
-            const f32x4 wv = *reinterpret_cast<const f32x4 *>(u.w + (size_t)widx * C + c);
+            const f32x4 wv = *reinterpret_cast<const f32x4 *>(u.w + widx * C + c);
 #pragma unroll
             for (int i = 0; i < 4; ++i) acc[i] += ct_epilogue_value(e, s[i], c + i, sc[i], sh[i], 0.0f) * wv[i];
         }
     }
-    *reinterpret_cast<f32x4 *>(u.y + opix * u.ldy + c) = acc;
+    *reinterpret_cast<f32x4 *>(u.y + (size_t)opix * u.ldy + c) = acc;
 }
 
 void fill_args(const ct_dcn_desc *d, const DcnPlan &p, DcnArgs *a)
@@ -719,6 +1105,8 @@ void fill_args(const ct_dcn_desc *d, const DcnPlan &p, DcnArgs *a)
     a->omPart = p.parts ? d->om_partial : nullptr;
     a->omSplits = p.parts;
     a->offsOnly = 0;
+    a->ptiles = d->N * p.tilesX * p.tilesY;
+    a->splits = p.splits;
 }
 
 // dynamic LDS of one workgroup: A double buffers + the two tables (+ om tile and the offset-conv scratch when fused)
@@ -750,7 +1138,7 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         if (rc != CT_OK) return rc;
         // (one MAIN launch = one kernel instantiation; the OFFSETS / FINISH launches do not depend on the tile shape, so
         //  layers whose MAIN launches differ -- e.g. in channels per step -- may share them)
-        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK))
+        if ((phases & CT_DCN_MAIN) && (p.BM != plans[0].BM || p.BN != plans[0].BN || p.NKK != plans[0].NKK || p.persist != plans[0].persist))
             CT_FAIL_ARG("ct_dcn_v2_group: layer %d resolves to another tile shape than layer 0", i);
         const size_t need = ws_bytes(d, p);
         if (need > 0 && (!d->workspace || d->workspace_bytes < need)) {
@@ -769,16 +1157,23 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
             r.Mtot = (size_t)d->N * d->H * d->W;
             r.N = d->N; r.H = d->H; r.W = d->W;
             r.e = g.p[i].epi;
-            size_t nq;
+            long rows;
             if (d->up_w) {
                 r.u.w = d->up_w; r.u.skip = d->up_skip; r.u.y = d->up_y; r.u.f = d->up_f; r.u.lds = d->up_lds; r.u.ldy = d->up_ldy;
-                nq = r.Mtot * (size_t)(d->up_f * d->up_f) * (size_t)(d->Cout / 4);
+                r.rowBlocks = (d->W * d->up_f * (d->Cout / 4) + 255) / 256;
+                rows = (long)d->N * d->H * d->up_f;
             } else {
                 r.u.w = nullptr; r.u.skip = nullptr; r.u.y = nullptr; r.u.f = 0; r.u.lds = r.u.ldy = 0;
-                nq = r.Mtot * (size_t)(r.wsCout / 4);
+                r.rowBlocks = (d->W * (r.wsCout / 4) + 255) / 256;
+                rows = (long)d->N * d->H;
             }
+            // (32-bit indices in the kernel: one split's partial map, the output and the skip view in elements)
+            if ((double)r.Mtot * r.wsCout >= 1073741824.0 ||
+                (d->up_w && (double)r.Mtot * d->up_f * d->up_f * (d->up_lds > d->up_ldy ? d->up_lds : d->up_ldy) >= 4294967296.0))
+                CT_FAIL_ARG("ct_dcn_v2: layer %d: partial map / IDAUp output too large for the finishing launch", i);
             rg.first[rg.n] = (int)rblocks;
-            rblocks += (long)((nq + 255) / 256);
+            rblocks += rows * r.rowBlocks;
+            if (rblocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
             ++rg.n;
         } else if (d->up_w) {
             legacy_up = d;      // (single launch without split-K: the plain IDAUp step on the finished DCN output)
@@ -830,6 +1225,51 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
     const dim3 grid((unsigned)blocks);
     if (!(phases & CT_DCN_MAIN)) {
         // finish only: the partials were written by an earlier CT_DCN_MAIN call on the same descriptors
+    } else if (p0.persist) {
+        // `slots` resident workgroups shared out so that every layer's workgroups run the same number of steps: layer i has
+        // cols[i] (cout block, K split) columns of P[i] pixel tiles, a tile costs its steps plus a boundary's worth; the
+        // smallest makespan T with sum_i cols[i] * ceil(P[i] / floor(T / cost[i])) <= slots
+        DcnPersist pg;
+        pg.n = n;
+        long cols[DCN_MAX_GROUP], P[DCN_MAX_GROUP], cost[DCN_MAX_GROUP];
+        long slots = ct_tune_get(CT_TUNE_DCN_SLOTS), lo = 0, hi = 0, all = 0;
+        for (int i = 0; i < n; ++i) {
+            cols[i] = (long)plans[i].coutBlocks * plans[i].splits;
+            P[i] = g.p[i].ptiles;
+            cost[i] = (long)(plans[i].chunksPerSplit / (plans[i].NKK / 2)) * 9 + 3;
+            if (cost[i] > lo) lo = cost[i];
+            hi += cost[i] * P[i];
+            all += cols[i];
+        }
+        if (slots < all) slots = all;                 // (at least one workgroup per column)
+        auto need = [&](long T) {
+            long w = 0;
+            for (int i = 0; i < n; ++i) w += cols[i] * ((P[i] + T / cost[i] - 1) / (T / cost[i]));
+            return w;
+        };
+        while (lo < hi) {
+            const long mid = (lo + hi) / 2;
+            if (need(mid) <= slots) hi = mid; else lo = mid + 1;
+        }
+        long pblocks = 0;
+        for (int i = 0; i < n; ++i) {
+            pg.p[i] = g.p[i];
+            const long k = lo / cost[i];
+            pg.per_col[i] = (int)((P[i] + k - 1) / k);
+            pg.first[i] = (int)pblocks;
+            pblocks += cols[i] * pg.per_col[i];
+        }
+        for (int i = n; i <= DCN_MAX_GROUP; ++i) pg.first[i] = (int)pblocks;
+        for (int i = n; i < DCN_MAX_GROUP; ++i) { pg.p[i] = pg.p[0]; pg.per_col[i] = 1; }
+        const dim3 pgrid((unsigned)pblocks);
+        const size_t lds = sizeof(float) * (size_t)(2 * p0.NKK * 32 * 16) + 2 * (size_t)(2 * 32 * 9 * 16);
+        if (p0.NKK == 4) {
+            if (p0.BN == 128) hipLaunchKernelGGL((dcn_persist_kernel<2, 4>), pgrid, dim3(256), lds, s, pg);
+            else hipLaunchKernelGGL((dcn_persist_kernel<1, 4>), pgrid, dim3(256), lds, s, pg);
+        } else {
+            if (p0.BN == 128) hipLaunchKernelGGL((dcn_persist_kernel<2, 2>), pgrid, dim3(256), lds, s, pg);
+            else hipLaunchKernelGGL((dcn_persist_kernel<1, 2>), pgrid, dim3(256), lds, s, pg);
+        }
     } else if (p0.NKK == 4) {
         if (p0.BM != 32) CT_FAIL_ARG("ct_dcn_v2: the 64-channel-step shapes run on 32-pixel tiles");
         const size_t lds = lds_bytes(32, fuse_any, single_chunk, 4);

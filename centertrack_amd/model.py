@@ -567,6 +567,11 @@ class DLASegHIP(torch.nn.Module):
         split_offsets = knobs[3] if len(knobs) > 3 else 1
         cps_small = knobs[4] if len(knobs) > 4 else 0
         small_unfuse = knobs[5] if len(knobs) > 5 else 0      # small slots: offset convs out of the MAIN launch too
+        # knobs[6] (round 6) = 1: MAIN launches as persistent launches (ct_dcn_desc.algo 5xxxx / 6xxxx: `dcn_slots` resident
+        # workgroups striding over the pixel tiles of their column, gathers / weights / the next sampling table running
+        # across tile boundaries) wherever every layer of the launch can -- no fused offset conv, an even number of step
+        # units per split; bit-identical to the one-workgroup-per-tile launch
+        persist = knobs[6] if len(knobs) > 6 else 0
         slot_cps = {}
         sizes, mains = self._dcn_slot_sizes(layers, produced0, N, cps, with_mains=True)
         if cps_small and cps_small < cps:
@@ -659,9 +664,14 @@ class DLASegHIP(torch.nn.Module):
                 part = lys[i:i + 4]
                 arr = (_lib.DcnDesc * len(part))()
                 keep = []
+                def can_persist(ly):
+                    cpsplit = -(-(ly.x.C // 32) // ly.splits)
+                    return (not ly.fused and (ly.x.C // 32) % cpsplit == 0
+                            and cpsplit % (4 if ly.nkk == 4 else 2) == 0)
+                pers = bool(persist) and phases == _lib.CT_DCN_MAIN and all(can_persist(ly) for ly in part)
                 for j, ly in enumerate(part):
                     ctypes.memmove(ctypes.byref(arr[j]), ctypes.byref(ly.desc[0]), ctypes.sizeof(_lib.DcnDesc))
-                    arr[j].algo = 43264 if ly.nkk == 4 else 3264
+                    arr[j].algo = (43264 if ly.nkk == 4 else 3264) + (20000 if pers and ly.nkk == 4 else 50000 if pers else 0)
                     keep.append(ly.desc[1])
                 name = '%s[%s]' % (tag, ' + '.join(ly.name for ly in part))
                 out.append(_Launch(name, 'dcn_group', (arr, len(part), phases), keep))
@@ -742,20 +752,25 @@ class DLASegHIP(torch.nn.Module):
         if env:
             knobs = tuple(int(v) for v in env.split(','))
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs, tune)
-        default = (128, 4, 2, 1, 0, 0)
+        default = (128, 4, 2, 1, 0, 0, 0)
         if not tune:
             return default, self._schedule_dcn(layers, produced0, N, dev, default, tune)
-        key = 'dcnplan4:%d,%d,%d' % (N, H, W)
+        key = 'dcnplan5:%d,%d,%d' % (N, H, W)
+        key4 = 'dcnplan4:%d,%d,%d' % (N, H, W)          # (tables before the persistent launches: six knobs)
         key3 = 'dcnplan3:%d,%d,%d' % (N, H, W)          # (round-2 tables: four knobs, no fine-split slots)
         autotune._load_file()
         retune = os.environ.get('CENTERTRACK_DCN_RETUNE', '0') == '1'      # (tools/retune_dcn.py: measure again)
         if key in autotune._CACHE and not retune:
             knobs = tuple(int(v) for v in autotune._CACHE[key][:-1])
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
+        if key4 in autotune._CACHE and not retune:
+            knobs = tuple(int(v) for v in autotune._CACHE[key4][:-1]) + (0,)
+            return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         if key3 in autotune._CACHE and not retune:
-            knobs = tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0, 0)
+            knobs = tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0, 0, 0)
             return knobs, self._schedule_dcn(layers, produced0, N, dev, knobs)
         best = None
+        tried = []
         # (split_offsets = 0 -- one conv launch per un-fused layer -- never won in round 2's sweeps: 368 against 336 us
         # at one stream, 1932 against 1818 us at eight; it stays reachable through CENTERTRACK_DCN_KNOBS.  Neither did
         # 128-cout tiles for the layers with >= 128 couts in a MAIN launch of their own: 6866 against 6830 us at 32
@@ -767,14 +782,28 @@ class DLASegHIP(torch.nn.Module):
                         small = [t for t, w in self._dcn_slot_sizes(layers, produced0, N, cps).items() if w < SMALL_SLOT_WGS]
                         for cs, un in (((0, 0), (0, 2)) + tuple((c, u) for c in (2, 1) if c < cps for u in (0, 1, 2)) if small
                                        else ((0, 0), (0, 2))):
-                            knobs = (fuse_max, cps, nkk, so, cs, un)
+                            knobs = (fuse_max, cps, nkk, so, cs, un, 0)
                             launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
                             us = self._time_launches(launches)
                             if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
                                 print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us' % (N, H, W, knobs, len(launches), us))
+                            tried.append((us, knobs))
                             if best is None or us < best[0]:
                                 best = (us, knobs)
                             del launches
+        # second stage: the persistent MAIN launches on top of the five best schedules and of every schedule that keeps all
+        # offset convs out of the MAIN launches (the only layers a persistent launch takes)
+        tried.sort()
+        for us0, k0 in tried[:5] + [t for t in tried[5:] if t[1][0] == 0 and t[1][5] == 0]:
+            knobs = k0[:6] + (1,)
+            launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
+            if any(l.fn == 'dcn_group' and int(l.args[0][0].algo) >= 50000 for l in launches):
+                us = self._time_launches(launches)
+                if os.environ.get('CENTERTRACK_TUNE_VERBOSE'):
+                    print('dcn schedule N=%d %dx%d knobs %s: %d launches, %.1f us (%.1f without)' % (N, H, W, knobs, len(launches), us, us0))
+                if us < best[0]:
+                    best = (us, knobs)
+            del launches
         autotune._CACHE[key] = tuple(best[1]) + (round(best[0], 1),)
         autotune._save_file()
         return best[1], self._schedule_dcn(layers, produced0, N, dev, best[1])

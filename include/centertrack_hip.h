@@ -51,7 +51,8 @@ int ct_version(void);                      /* CT_ABI_VERSION the library was bui
  * used below this many 64x64 tiles / sized to reach this many waves), "xcd_remap" (0/1 XCD-aware workgroup order of
  * the wide layers), "heads_order" (0 = tile-major, 1 = head-major, 2 = head-major and
  * XCD-affine [default]: workgroup order of ct_heads_fused), "stem_rows" (0 auto,
- * 8 / 16: rows of 32 pixels per workgroup of ct_stem_forward). */
+ * 8 / 16: rows of 32 pixels per workgroup of ct_stem_forward), "dcn_slots" (resident workgroups of the persistent
+ * DCN launches, algo 5xxxx / 6xxxx: 1024 = four per CU). */
 int ct_set_tuning(const char *key, int value);
 
 /* ---- weight packing ---------------------------------------------------------------
@@ -156,7 +157,13 @@ typedef struct ct_dcn_desc {
     int algo;                                   /* 0 = heuristic; 64 / 128 = 64-pixel tile x 64 / 128 couts per
                                                    workgroup; 3264 / 32128 = 32-pixel tile x 64 / 128 couts;
                                                    43264 / 432128 = the same stepping through 64 instead of 32
-                                                   channels per barrier (Cin % 64 == 0) */
+                                                   channels per barrier (Cin % 64 == 0);
+                                                   53264 / 532128 / 63264 / 632128 = 3264 / 32128 / 43264 / 432128 as a
+                                                   PERSISTENT launch: "dcn_slots" resident workgroups, each striding over
+                                                   the pixel tiles of one (cout block, K split) column with the gathers,
+                                                   weight loads and the next tile's sampling table running across tile
+                                                   boundaries; needs fuse_offset != 1 and an even number of step units
+                                                   per split; bit-identical to the non-persistent code */
     int fuse_offset;                            /* 1: compute DCN.conv_offset_mask (+ mask sigmoid) inside this launch
                                                    from w_off_packed [27,Cin,3,3 packed] / b_off [27]; `om` is then
                                                    unused (may be NULL); needs Cin % 64 == 0 and a 32-pixel tile.

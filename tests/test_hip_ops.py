@@ -633,6 +633,96 @@ def test_dcn_group_launch_with_winograd_offsets(device):
         assert torch.equal(got, single[i].to_nchw()), 'group layer %d vs single launch' % i
 
 
+@pytest.mark.parametrize('palgo,algo,slots', [(53264, 3264, 5), (53264, 3264, 23), (53264, 3264, 1024), (532128, 32128, 9),
+                                              (63264, 43264, 6), (632128, 432128, 1024)])
+def test_dcn_persistent_launch_is_bit_identical(device, palgo, algo, slots):
+    """The persistent MAIN launch (round 6: algo 5xxxx / 6xxxx -- `dcn_slots` resident workgroups, each striding over the pixel
+    tiles of one (cout block, K split) column with gathers, weight loads and the next tile's sampling table running across
+    tile boundaries) == the one-workgroup-per-tile launch of the same tile shape bit for bit, and == the oracle: three layers
+    of a group (offset/mask map from HBM + IDAUp step; Winograd K-split offsets + split-K; K-split offsets, unsplit), with so
+    few slots that every workgroup walks through many tiles (several images, ragged maps) and with more slots than tiles"""
+    import ctypes
+    from centertrack_amd import _lib, ops
+    from oracle import dcn_v2 as odcn
+    lib = _lib.load()
+    wide = algo in (43264, 432128)               # 64-channel steps: an even number of 64-channel units per split
+    specs = [dict(N=2, H=9, W=21, Cin=128, Cout=64, split=1, offs='map', f=2),
+             dict(N=3, H=5, W=17, Cin=256, Cout=128, split=1 if wide else 2, offs='wino', f=0),
+             dict(N=2, H=12, W=40, Cin=128 if wide else 64, Cout=64, split=1, offs='split', f=0)]
+    res = {}
+    try:
+        for which in (algo, palgo):
+            assert lib.ct_set_tuning(b'dcn_slots', slots) == 0
+            descs, keep, outs, want = [], [], [], []
+            for i, sp in enumerate(specs):
+                N, H, W, Cin, Cout = sp['N'], sp['H'], sp['W'], sp['Cin'], sp['Cout']
+                x = F.relu(_rand(N, Cin, H, W, seed=560 + i))
+                w, b = _rand(Cout, Cin, 3, 3, seed=570 + i, scale=(Cin * 9) ** -0.5), _rand(Cout, seed=580 + i)
+                wo, bo = _rand(27, Cin, 3, 3, seed=590 + i, scale=0.5 * (Cin * 9) ** -0.5), _rand(27, seed=600 + i, scale=0.3)
+                scale = torch.rand(Cout, generator=torch.Generator().manual_seed(610 + i)) + 0.5
+                y = F.relu(odcn.dcn_forward(x, w, None, wo, bo) * scale.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+                xv = ops.view_from_nchw(x.to(device))
+                wod = wo.to(device)
+                wp, wop, wow = ops.pack_weight(w.to(device)), ops.pack_weight(wod), ops.pack_winograd(wod)
+                sc_d, b_d, bo_d = scale.to(device), b.to(device), bo.to(device)
+                om = None
+                if sp['offs'] == 'map':
+                    om = ops.conv2d(xv, wop, 27, 3, 1, shift=bo_d, sig=(18, 27), out=ops.new_view(N, H, W, 32, device))
+                up = None
+                out = ops.new_view(N, H, W, Cout, device)
+                if sp['f']:
+                    f = sp['f']
+                    wup, skip = _rand(Cout, 1, 2 * f, 2 * f, seed=620 + i), _rand(N, Cout, H * f, W * f, seed=630 + i)
+                    y = F.conv_transpose2d(y, wup, None, stride=f, padding=f // 2, groups=Cout) + skip
+                    up = (ops.upsample_weight(wup.to(device)), f, ops.view_from_nchw(skip.to(device)), ops.new_view(N, H * f, W * f, Cout, device))
+                want.append(y)
+                own = sp['offs'] != 'map'
+                fuse_kw = dict(w_off=wop, b_off=bo_d) if own else {}
+                part = torch.empty((Cin // 64) * N * H * W * 32, device=device) if own else None
+                d = ops.make_dcn_desc(xv, om, wp, Cout, sc_d, b_d, True, out, split_k=sp['split'], algo=which, up=up, om_partial=part,
+                                      w_off_wino=wow if sp['offs'] == 'wino' else None, **fuse_kw)
+                need = ctypes.c_size_t(0)
+                _lib.check(lib.ct_dcn_v2_group_plan(ctypes.byref(d), ctypes.byref(need), None), 'plan')
+                ws = torch.empty(max(need.value, 4) // 4, device=device)
+                d.workspace, d.workspace_bytes = ws.data_ptr(), need.value
+                descs.append(d)
+                outs.append(up[3] if up is not None else out)
+                keep += [xv, wp, wop, wow, sc_d, b_d, bo_d, om, up, ws, out, part]
+            arr = (_lib.DcnDesc * len(specs))(*descs)
+            _lib.check(lib.ct_dcn_v2_group(arr, len(specs), _lib.CT_DCN_OFFSETS | _lib.CT_DCN_MAIN | _lib.CT_DCN_FINISH, _lib.stream_ptr()), 'group')
+            torch.cuda.synchronize()
+            res[which] = [o.to_nchw().clone() for o in outs]
+            if which == palgo:                       # ... and alone, through ct_dcn_v2
+                d1 = descs[2]
+                outs[2].buf.zero_()
+                _lib.check(lib.ct_dcn_v2(ctypes.byref(d1), _lib.stream_ptr()), 'single persistent launch')
+                torch.cuda.synchronize()
+                assert torch.equal(outs[2].to_nchw(), res[algo][2]), 'single persistent launch'
+    finally:
+        lib.ct_set_tuning(b'dcn_slots', 1024)
+    for i in range(len(specs)):
+        _close(res[palgo][i], want[i], msg='persistent layer %d vs oracle' % i)
+        assert torch.equal(res[palgo][i], res[algo][i]), 'layer %d: persistent vs one workgroup per tile' % i
+
+
+def test_dcn_persistent_argument_errors(device):
+    """shapes the persistent launch cannot run are refused before anything is launched"""
+    import ctypes
+    from centertrack_amd import _lib, ops
+    lib = _lib.load()
+    xv = ops.view_from_nchw(torch.zeros(1, 64, 8, 16, device=device))
+    wp = ops.pack_weight(torch.zeros(64, 64, 3, 3, device=device))
+    om = ops.new_view(1, 8, 16, 32, device)
+    out = ops.new_view(1, 8, 16, 64, device)
+    ws = torch.empty(1 << 16, device=device)
+    for algo, split, kw in ((53264, 2, {}),                    # one 32-channel chunk per split: 9 steps
+                            (63264, 1, {}),                    # one 64-channel unit
+                            (53264, 1, dict(w_off=wp, b_off=torch.zeros(27, device=device)))):      # fused offset conv
+        d = ops.make_dcn_desc(xv, om, wp, 64, None, None, False, out, workspace=ws, split_k=split, algo=algo, **kw)
+        assert lib.ct_dcn_v2(ctypes.byref(d), _lib.stream_ptr()) == _lib.CT_ERR_ARG, (algo, split)
+        assert b'persistent' in lib.ct_last_error()
+
+
 @pytest.mark.parametrize('with_img,with_hm,shape', [(True, True, (2, 24, 40)), (True, False, (1, 16, 32)),
                                                    (False, False, (1, 9, 33)), (True, True, (1, 64, 96))])
 def test_stem_matches_torch(device, with_img, with_hm, shape):

@@ -71,6 +71,29 @@ def main():
         assert raw.ct_dcn_read_stamps(host.ctypes.data_as(ctypes.c_void_p), NB) == 0
         st = host.reshape(NB, WORDS).astype(np.int64)
         st = st[st[:, 1] != 0]
+        if int(l.args[0][0].algo) >= 50000:        # persistent launch: its own stamp layout (dcn_persist_kernel)
+            span = (st[:, 15].max() - st[:, 0].min()) * 10e-3
+            print('%s\n  persistent: %d workgroups, wall span %.1f us; start spread max %.1f us' % (
+                l.name, len(st), span, (st[:, 0] - st[:, 0].min()).max() * 10e-3))
+            for j in range(l.args[1]):
+                d = l.args[0][j]
+                s = st[st[:, 18] == j]
+                if not len(s):
+                    continue
+                line = '  layer %d: %3d->%3d @%dx%d split %d: %4d WGs, %.1f tiles each (max %d) of %d steps; clk first table+gathers %.0f' % (
+                    j, d.Cin, d.Cout, d.H, d.W, max(1, d.split_k), len(s), s[:, 16].mean(), s[:, 16].max(), s[:, 17].mean(),
+                    (s[:, 2] - s[:, 1]).mean())
+                prev = s[:, 2]
+                for i in range(4):
+                    ok = s[:, 16] > i
+                    if not ok.any():
+                        break
+                    a3, a4, a5 = s[ok, 3 + 3 * i], s[ok, 4 + 3 * i], s[ok, 5 + 3 * i]
+                    line += '; tile %d: 2 steps + table %.0f, loop %.0f (per step %.0f), stores %.0f' % (
+                        i, (a3 - prev[ok]).mean(), (a4 - a3).mean(), (a4 - a3).mean() / max(s[:, 17].mean() - 2, 1), (a5 - a4).mean())
+                    prev = s[:, 5 + 3 * i].copy()
+                print(line + '; life %.1f us (max %.1f)' % ((s[:, 15] - s[:, 0]).mean() * 10e-3, (s[:, 15] - s[:, 0]).max() * 10e-3))
+            continue
         rt0, rt1 = st[:, 0], st[:, 7]
         span = (rt1.max() - rt0.min()) * 10e-3            # s_memrealtime: 100 MHz
         print('%s\n  %d workgroups, wall span %.1f us; start spread p50 %.1f p90 %.1f max %.1f us' % (
