@@ -23,10 +23,10 @@ extern "C" int ct_version(void) { return CT_ABI_VERSION; }
 
 // ---- tuning knobs -------------------------------------------------------------------------
 enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,
-       CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_HEADS_ORDER, CT_TUNE_STEM_ROWS, CT_TUNE_DCN_SLOTS, CT_TUNE_COUNT };
-static int g_tune[CT_TUNE_COUNT] = {-1, 1, 256, 512, 0, -1, 512, 2048, 0, 2, 0, 1024};
+       CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_HEADS_ORDER, CT_TUNE_STEM_ROWS, CT_TUNE_DCN_SLOTS, CT_TUNE_DCN_XCD, CT_TUNE_COUNT };
+static int g_tune[CT_TUNE_COUNT] = {-1, 1, 256, 512, 0, -1, 512, 2048, 0, 2, 0, 1024, 1};
 static const char *g_tune_names[CT_TUNE_COUNT] = {"conv_cfg", "conv_pipe", "conv_small_tiles", "splitk_target", "dcn_bn",
-                                                 "conv_ks", "conv_ks_below", "conv_ks_waves", "xcd_remap", "heads_order", "stem_rows", "dcn_slots"};
+                                                 "conv_ks", "conv_ks_below", "conv_ks_waves", "xcd_remap", "heads_order", "stem_rows", "dcn_slots", "dcn_xcd"};
 
 int ct_tune_get(int key) { return g_tune[key]; }
 

@@ -29,7 +29,7 @@ static inline int ct_cdiv(int a, int b) { return (a + b - 1) / b; }
 
 // tuning knobs (ct_set_tuning); defaults chosen from MI355X measurements, see DESIGN.md
 enum { CT_TUNE_CONV_CFG = 0, CT_TUNE_CONV_PIPE, CT_TUNE_CONV_SMALL_TILES, CT_TUNE_SPLITK_TARGET, CT_TUNE_DCN_BN,
-       CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_HEADS_ORDER, CT_TUNE_STEM_ROWS, CT_TUNE_DCN_SLOTS, CT_TUNE_COUNT };
+       CT_TUNE_CONV_KS, CT_TUNE_CONV_KS_BELOW, CT_TUNE_CONV_KS_WAVES, CT_TUNE_XCD_REMAP, CT_TUNE_HEADS_ORDER, CT_TUNE_STEM_ROWS, CT_TUNE_DCN_SLOTS, CT_TUNE_DCN_XCD, CT_TUNE_COUNT };
 int ct_tune_get(int key);
 void ct_affine_inverse(const double *trans, double *M);   // host_preprocess.cpp
 // wino_mfma.hip: the offset/mask convs of up to 4 DCN layers in one Winograd launch, K-split over 64-channel chunks into

@@ -34,6 +34,12 @@ struct DcnArgs {
     int nchunks, chunksPerSplit;     // chunks of 32 channels
     int tiles;                       // N * tilesY * tilesX * coutBlocks: workgroups per split
     int ptiles, splits;              // N * tilesY * tilesX pixel tiles; K splits (the persistent form strides over pixel tiles)
+    // XCD-aware workgroup order (round 6; 0 = plain order): workgroup ids go round-robin to the 8 XCDs (id % 8) and each XCD has
+    // its own L2.  XCD x contracts the K splits s = x mod xsx only (xsx = gcd(splits, 8): an eighth of a 512-channel layer's
+    // weights and input channels per L2 instead of all of them) and, of the 8 / xsx XCDs that share a split set, each one
+    // `pband` consecutive pixel tiles (neighbouring tiles share their halo rows in ONE L2).  The layer's id range is padded to
+    // 8 * xper ids; ids past the last tile of a band exit.
+    int xsx, xper, pband;
     float *ws;
     int wsCout;
     const float *w_off;              // fused offset/mask conv (FUSE kernels; per layer: nullptr = read `om`):
@@ -229,9 +235,22 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         if (i < g.n && bid >= g.first[i]) pi = i;
     const DcnArgs &a = g.p[pi];
     bid -= g.first[pi];
-    const int split = bid / a.tiles;
-    bid -= split * a.tiles;
-    const int cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    int split, cb;
+    if (a.xsx && !(FUSE && a.offsOnly)) {
+        const int xcd = bid & 7;
+        int j = bid >> 3;
+        cb = j % a.coutBlocks; j /= a.coutBlocks;
+        const int sper = a.splits / a.xsx;
+        const int sh = j % sper; j /= sper;
+        split = (xcd & (a.xsx - 1)) + a.xsx * sh;
+        const int tile = (xcd / a.xsx) * a.pband + j;
+        if (j >= a.pband || tile >= a.ptiles) return;       // (uniform: padding of the id range)
+        bid = tile;
+    } else {
+        split = bid / a.tiles;
+        bid -= split * a.tiles;
+        cb = bid % a.coutBlocks; bid /= a.coutBlocks;
+    }
     const int tx = bid % a.tilesX; bid /= a.tilesX;
     const int ty = bid % a.tilesY; bid /= a.tilesY;
     const int n = bid;
@@ -1107,6 +1126,14 @@ void fill_args(const ct_dcn_desc *d, const DcnPlan &p, DcnArgs *a)
     a->offsOnly = 0;
     a->ptiles = d->N * p.tilesX * p.tilesY;
     a->splits = p.splits;
+    a->xsx = 0; a->xper = 0; a->pband = 0;
+    if (ct_tune_get(CT_TUNE_DCN_XCD)) {
+        int sx = 1;
+        while (sx < 8 && p.splits % (2 * sx) == 0) sx *= 2;          // gcd(splits, 8)
+        a->xsx = sx;
+        a->pband = ct_cdiv(a->ptiles, 8 / sx);
+        a->xper = p.coutBlocks * (p.splits / sx) * a->pband;         // ids per XCD
+    }
 }
 
 // dynamic LDS of one workgroup: A double buffers + the two tables (+ om tile and the offset-conv scratch when fused)
@@ -1148,8 +1175,8 @@ int launch_group(const ct_dcn_desc *descs, int n, bool grouped, int phases, void
         fill_args(d, p, &g.p[i]);
         fuse_any = fuse_any || p.fuse;
         if (p.fuse && d->Cin != 64) single_chunk = false;
-        g.first[i] = (int)blocks;
-        blocks += (long)g.p[i].tiles * p.splits;
+        g.first[i] = (int)blocks;                  // (a multiple of 8 when the XCD-aware order is on: id % 8 stays the XCD)
+        blocks += g.p[i].xsx ? 8L * g.p[i].xper : (long)g.p[i].tiles * p.splits;
         if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_dcn_v2: grid too large");
         if (p.use_ws) {
             RedArgs &r = rg.p[rg.n];

@@ -791,10 +791,13 @@ class DLASegHIP(torch.nn.Module):
                             if best is None or us < best[0]:
                                 best = (us, knobs)
                             del launches
-        # second stage: the persistent MAIN launches on top of the five best schedules and of every schedule that keeps all
-        # offset convs out of the MAIN launches (the only layers a persistent launch takes)
+        # second stage (CENTERTRACK_DCN_TUNE_PERSIST=1): the persistent MAIN launches on top of the five best schedules and of
+        # every schedule that keeps all offset convs out of the MAIN launches (the only layers a persistent launch takes).
+        # Off by default: over the 28 pinned shapes the persistent form lost everywhere, by 1 .. 8 %
+        # (profiles/r06_z_persistent_vs_per_tile_all_shapes.txt)
         tried.sort()
-        for us0, k0 in tried[:5] + [t for t in tried[5:] if t[1][0] == 0 and t[1][5] == 0]:
+        stage2 = os.environ.get('CENTERTRACK_DCN_TUNE_PERSIST', '0') == '1'
+        for us0, k0 in (tried[:5] + [t for t in tried[5:] if t[1][0] == 0 and t[1][5] == 0]) if stage2 else ():
             knobs = k0[:6] + (1,)
             launches = self._schedule_dcn(layers, produced0, N, dev, knobs)
             if any(l.fn == 'dcn_group' and int(l.args[0][0].algo) >= 50000 for l in launches):

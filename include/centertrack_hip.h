@@ -52,7 +52,8 @@ int ct_version(void);                      /* CT_ABI_VERSION the library was bui
  * the wide layers), "heads_order" (0 = tile-major, 1 = head-major, 2 = head-major and
  * XCD-affine [default]: workgroup order of ct_heads_fused), "stem_rows" (0 auto,
  * 8 / 16: rows of 32 pixels per workgroup of ct_stem_forward), "dcn_slots" (resident workgroups of the persistent
- * DCN launches, algo 5xxxx / 6xxxx: 1024 = four per CU). */
+ * DCN launches, algo 5xxxx / 6xxxx: 1024 = four per CU), "dcn_xcd" (0/1 [default]: XCD-aware workgroup order of the DCN
+ * MAIN launches -- every XCD's L2 sees its own K splits and a band of consecutive pixel tiles). */
 int ct_set_tuning(const char *key, int value);
 
 /* ---- weight packing ---------------------------------------------------------------

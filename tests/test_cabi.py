@@ -234,13 +234,15 @@ def test_pinned_tune_table_is_well_formed():
     with open(autotune.PINNED_TABLE) as f:
         t = json.load(f)
     plans = {k: v for k, v in t.items() if k.startswith('dcnplan')}
-    assert len(plans) >= 20 and all(k.startswith(('dcnplan3:', 'dcnplan4:')) for k in plans)
+    assert len(plans) >= 20 and all(k.startswith(('dcnplan3:', 'dcnplan4:', 'dcnplan5:')) for k in plans)
     for k, v in plans.items():
         n, h, w = (int(x) for x in k.split(':')[1].split(','))
         assert n >= 1 and h % 32 == 0 and w % 32 == 0
-        nk = 4 if k.startswith('dcnplan3:') else 6             # (round 3 added the two knobs of the small slots)
+        # (round 3 added the two knobs of the small slots, round 6 the persistent MAIN launches)
+        nk = 4 if k.startswith('dcnplan3:') else 6 if k.startswith('dcnplan4:') else 7
         assert len(v) == nk + 1 and v[0] in (0, 64, 128, 256) and v[1] in (2, 4, 8) and v[2] in (2, 4) and v[3] in (1, 2, 3), (k, v)
         assert nk == 4 or (v[4] in (0, 1, 2) and v[5] in (0, 1, 2)), (k, v)
+        assert nk < 7 or v[6] in (0, 1), (k, v)
         assert v[nk] > 0
     for k, v in t.items():
         if k.startswith('conv'):

@@ -49,10 +49,12 @@ def test_benchmarked_plan_matches_oracle(device, name, streams, sample, T):
     NB = streams * (2 if cfg['flip'] else 1)
     key = 'dcnplan4:%d,%d,%d' % (NB, cfg['H'], cfg['W'])
     key3 = key.replace('dcnplan4', 'dcnplan3')                 # (round-2 entries: four knobs, fine-split slots off)
+    key5 = key.replace('dcnplan4', 'dcnplan5')                 # (round 6: a seventh knob, persistent MAIN launches)
     autotune._load_file()
-    assert key in autotune._CACHE or key3 in autotune._CACHE, 'no pinned DCN schedule for %s' % key
-    want = (tuple(int(v) for v in autotune._CACHE[key][:-1]) if key in autotune._CACHE
-            else tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0, 0))
+    assert key5 in autotune._CACHE or key in autotune._CACHE or key3 in autotune._CACHE, 'no pinned DCN schedule for %s' % key
+    want = (tuple(int(v) for v in autotune._CACHE[key5][:-1]) if key5 in autotune._CACHE
+            else tuple(int(v) for v in autotune._CACHE[key][:-1]) + (0,) if key in autotune._CACHE
+            else tuple(int(v) for v in autotune._CACHE[key3][:4]) + (0, 0, 0))
     assert tuple(det._ctx['plan']['dcn_knobs']) == want
     compared = sum(c.frames for c in checks)
     stopped = [(c.tag,) + c.stopped for c in checks if c.stopped is not None]

@@ -89,8 +89,11 @@ def main():
                     if not ok.any():
                         break
                     a3, a4, a5 = s[ok, 3 + 3 * i], s[ok, 4 + 3 * i], s[ok, 5 + 3 * i]
-                    line += '; tile %d: 2 steps + table %.0f, loop %.0f (per step %.0f), stores %.0f' % (
-                        i, (a3 - prev[ok]).mean(), (a4 - a3).mean(), (a4 - a3).mean() / max(s[:, 17].mean() - 2, 1), (a5 - a4).mean())
+                    mid = s[ok, 19 + i] if i < 2 else None
+                    line += '; tile %d: 2 steps%s + table %.0f, loop %.0f (per step %.0f), stores %.0f' % (
+                        i, ' %.0f' % (mid - prev[ok]).mean() if mid is not None else '',
+                        (a3 - mid).mean() if mid is not None else (a3 - prev[ok]).mean(), (a4 - a3).mean(),
+                        (a4 - a3).mean() / max(s[:, 17].mean() - 2, 1), (a5 - a4).mean())
                     prev = s[:, 5 + 3 * i].copy()
                 print(line + '; life %.1f us (max %.1f)' % ((s[:, 15] - s[:, 0]).mean() * 10e-3, (s[:, 15] - s[:, 0]).max() * 10e-3))
             continue

@@ -1,7 +1,8 @@
 #!/usr/bin/env python
-"""Re-measure the DCN schedule knobs (`dcnplan4:N,H,W`, six knobs; round 6 added offset mode 3) for every (streams, size) the pinned table holds and write the
+"""Re-measure the DCN schedule knobs (`dcnplan5:N,H,W`, seven knobs; round 6 added offset mode 3 and the persistent MAIN
+launches, the latter only searched with CENTERTRACK_DCN_TUNE_PERSIST=1) for every (streams, size) the pinned table holds and write the
 merged table: run on the GPU box with CENTERTRACK_TUNE_CACHE=<out.json>; the conv entries of the pinned table are
-kept, older `dcnplan3:*` / `dcnplan4:*` entries of a re-measured shape dropped.  Optional further arguments: N,H,W shapes to restrict the run to.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
+kept, older `dcnplan3:*` / `dcnplan4:*` / `dcnplan5:*` entries of a re-measured shape dropped.  Optional further arguments: N,H,W shapes to restrict the run to.     python tools/retune_dcn.py gpurun_out/tune_new.json"""
 import json
 import os
 import sys
@@ -32,13 +33,13 @@ for (N, H, Wd) in shapes:
     model.load_state_dict(sd)
     model = model.to('cuda')
     plan = model.get_plan(N, H, Wd, True, True, True)
-    print('dcnplan4:%d,%d,%d -> %s' % (N, H, Wd, (plan['dcn_knobs'],)), flush=True)
+    print('dcnplan5:%d,%d,%d -> %s' % (N, H, Wd, (plan['dcn_knobs'],)), flush=True)
     del plan, model
     torch.cuda.empty_cache()
 merged = {k: list(v) for k, v in table.items() if not k.startswith('dcnplan')}       # (the cache file holds un-pinned keys only)
-merged.update({k: list(v) for k, v in autotune._CACHE.items() if not k.startswith(('dcnplan2:', 'dcnplan3:'))})
+merged.update({k: list(v) for k, v in autotune._CACHE.items() if not k.startswith(('dcnplan2:', 'dcnplan3:', 'dcnplan4:'))})
 # shapes that were not re-measured keep their older schedules
-done = {k.split(':')[1] for k in merged if k.startswith('dcnplan4:')}
+done = {k.split(':')[1] for k in merged if k.startswith('dcnplan5:')}
 merged.update({k: list(v) for k, v in table.items() if k.startswith('dcnplan') and k.split(':')[1] not in done})
 with open(out, 'w') as f:
     json.dump(dict(sorted(merged.items())), f, indent=0)
