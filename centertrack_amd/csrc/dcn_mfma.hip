@@ -350,10 +350,15 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         constexpr int TI = (E + NTHR - 1) / NTHR;
         const int ldx4 = a.ldx * 4, rowb = a.W * ldx4;
         float tdy[TI], tdx[TI], tmk[TI];
+        // the short last pass (32 of the 288 entries) rotates over the waves with the workgroup id: the four workgroups of a CU
+        // build their tables at the same time (they start together), wave w of each on SIMD w -- with the last pass always on
+        // wave 0, SIMD 0 issued two passes for all four of them while the other SIMDs waited at the barrier
+        const int rot = (blockIdx.x >> 8) & 3;
+        const int wrot = (wave - rot) & 3, trot = (tid - rot * 64) & 255;
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            if (wave * 64 + NTHR * i >= E) continue;                 // (uniform)
-            const int it = tid + NTHR * i;
+            if (wrot * 64 + NTHR * i >= E) continue;                 // (uniform)
+            const int it = trot + NTHR * i;
             const int k = it / BM, m = it & (BM - 1);
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);
             const bool in = it < E && oy < a.H && ox < a.W;
@@ -380,8 +385,8 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
         }
 #pragma unroll
         for (int i = 0; i < TI; ++i) {
-            if (wave * 64 + NTHR * i >= E) continue;                 // (uniform)
-            const int it = tid + NTHR * i;
+            if (wrot * 64 + NTHR * i >= E) continue;                 // (uniform)
+            const int it = trot + NTHR * i;
             const int k = it / BM, m = it & (BM - 1);
             const int ky = (k * 11) >> 5, kx = k - 3 * ky;            // k / 3, k % 3 for k < 9
             const int oy = oy0 + (m >> 4), ox = ox0 + (m & 15);

@@ -555,6 +555,10 @@ struct WinoGroup {
     WinoArgs p[4];
     int first[5];
     int tiles[4];                 // workgroups per chunk of layer i
+    // XCD-aware order (as in the DCN MAIN launch, dcn_mfma.hip): ids go round-robin to the 8 XCDs; XCD x runs the chunks
+    // c = x mod sx[i] only (sx = gcd(Cin / 64, 8): the chunk's weights and input channels pass through ONE L2) and, of the
+    // 8 / sx XCDs sharing a chunk set, `pband[i]` consecutive pixel blocks each.  first[i] is a multiple of 8.
+    int sx[4], pband[4];
     int n;
 };
 
@@ -568,8 +572,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
     const WinoArgs &a = g.p[pi];
     bid -= g.first[pi];
     const int tiles = g.tiles[pi];
-    const int split = bid / tiles;
-    bid -= split * tiles;
+    const int sx = g.sx[pi], sper = (a.Cin >> 6) / sx;
+    const int xcd = bid & 7;
+    int j = bid >> 3;
+    const int sh = j % sper; j /= sper;
+    const int split = (xcd & (sx - 1)) + sx * sh;
+    bid = (xcd / sx) * g.pband[pi] + j;
+    if (j >= g.pband[pi] || bid >= tiles) return;             // (uniform: padding of the id range)
     float *ydst = a.epi.y + (size_t)split * a.N * a.H * a.W * 32;
     wino_body<1, 2, 1, false>(a, bid, (unsigned)tiles, split, ydst);
 }
@@ -702,11 +711,15 @@ int ct_wino_offsets_group(const ct_wino_off_layer *L, int n, void *stream)
         for (int j = 0; j < CT_MAX_FUSED_HEADS; ++j) { a.hcout[j] = 0; a.hcoff[j] = 0; }
         g.tiles[i] = l.N * a.tilesX * a.tilesY;
         g.first[i] = (int)blocks;
-        blocks += (long)g.tiles[i] * (l.Cin / 64);
+        int sx = 1;
+        while (sx < 8 && (l.Cin / 64) % (2 * sx) == 0) sx *= 2;
+        g.sx[i] = sx;
+        g.pband[i] = ct_cdiv(g.tiles[i], 8 / sx);
+        blocks += 8L * (l.Cin / 64 / sx) * g.pband[i];
         if (blocks > 0x7fffffffL) CT_FAIL_ARG("ct_wino_offsets_group: grid too large");
     }
     for (int i = n; i <= 4; ++i) g.first[i] = (int)blocks;
-    for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.tiles[i] = g.tiles[0]; }
+    for (int i = n; i < 4; ++i) { g.p[i] = g.p[0]; g.tiles[i] = g.tiles[0]; g.sx[i] = g.sx[0]; g.pband[i] = g.pband[0]; }
     g.n = n;
     using C = WCfg<1>;
     const size_t patch = sizeof(float) * (size_t)C::BUF;

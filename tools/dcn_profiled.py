@@ -6,8 +6,8 @@ fraction that follows from it -- so that `roofline.frac` of the bench line can b
 
     python tools/dcn_profiled.py profiles/r03_x_rocprofv3_kernel_stats_bench_steps3.txt > profiles/dcn_profiled.json
 
-Frames = launches of stem_kernel (one per frame).  DCN kernels: dcn_mfma_kernel (MAIN and OFFSETS launches) +
-dcn_reduce_kernel (FINISH launches).  Flops of one mot17_512 frame: 14.19 GFLOP main contraction,
+Frames = launches of stem_kernel (one per frame).  DCN kernels: dcn_mfma_kernel (MAIN launches, direct-form OFFSETS launches),
+wino_offsets_kernel (round 6: the Winograd form of the OFFSETS launches) + dcn_reduce_kernel (FINISH launches).  Flops of one mot17_512 frame: 14.19 GFLOP main contraction,
 + 4.65 GFLOP offset/mask convs = 18.84 GFLOP."""
 import json
 import re
@@ -28,7 +28,7 @@ def main(path):
     if not frames:
         raise SystemExit('no stem_kernel row in %s' % path)
     frames = frames[0]
-    dcn = {n: v for n, v in rows.items() if n.startswith(('dcn_mfma_kernel', 'dcn_reduce_kernel'))}
+    dcn = {n: v for n, v in rows.items() if n.startswith(('dcn_mfma_kernel', 'dcn_reduce_kernel', 'wino_offsets_kernel'))}
     total_us = sum(t for _, t in dcn.values())
     per_frame = total_us / frames
     main_us = sum(t for n, (_, t) in dcn.items() if n.startswith('dcn_mfma_kernel')) / frames

@@ -140,7 +140,11 @@ def main():
              ('F32x64/4', dict(algo=3264, split=4, fuse=1)), ('F32x64/8', dict(algo=3264, split=8, fuse=1)),
              ('4x32x64/1', dict(algo=43264, split=1)), ('4x32x64/2', dict(algo=43264, split=2)), ('4x32x64/4', dict(algo=43264, split=4)),
              ('4x32x128/1', dict(algo=432128, split=1)), ('4x32x128/4', dict(algo=432128, split=4)),
-             ('4F32x64/1', dict(algo=43264, split=1, fuse=1)), ('4F32x64/2', dict(algo=43264, split=2, fuse=1))]
+             ('4F32x64/1', dict(algo=43264, split=1, fuse=1)), ('4F32x64/2', dict(algo=43264, split=2, fuse=1)),
+             ('128/1', dict(algo=128, split=1)),
+             # round 6: the persistent form of the 32-pixel shapes (ct_dcn_desc.algo 5xxxx / 6xxxx)
+             ('P32x64/1', dict(algo=53264, split=1)), ('P32x64/2', dict(algo=53264, split=2)), ('P32x128/1', dict(algo=532128, split=1)),
+             ('P4x32x64/1', dict(algo=63264, split=1))]
     if args.no_conv and not args.dvariant:       # (the DCN study of round 2: 4- vs 8-wave workgroups)
         dvars = [v for v in dvars if v[0] in ('32x64/1', '32x64/2', '32x64/4', 'F32x64/1', 'F32x64/2', '32x128/1', '32x128/4') or v[0].startswith('4')]
     dcns = [c for c in dcns if args.dcn_layers in c[0]]
@@ -162,7 +166,11 @@ def main():
         gf = 2.0 * 9 * Cin * Cout * N * H * H / 1e9
         line = '%-24s %3d %8.3f |' % (name, cnt, gf)
         for vname, kw in dvars:
-            if kw.get('algo', 0) in (32128, 432128) and Cout < 128:
+            if kw.get('algo', 0) in (32128, 432128, 128, 532128) and Cout < 128:
+                line += ' %12s' % '-'
+                continue
+            upc = 64 if kw.get('algo', 0) == 63264 else 32         # (persistent: an even number of step units per split)
+            if kw.get('algo', 0) >= 50000 and (Cin // upc) % (2 * kw.get('split', 1)):
                 line += ' %12s' % '-'
                 continue
             fz = dict(w_off=w_off, b_off=b_off) if kw.get('fuse') else {}
