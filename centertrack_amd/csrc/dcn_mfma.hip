@@ -233,7 +233,7 @@ __global__ __launch_bounds__(256) void dcn_mfma_kernel(DcnGroup g)
 #pragma unroll
     for (int i = 1; i < DCN_MAX_GROUP; ++i)
         if (i < g.n && bid >= g.first[i]) pi = i;
-    const DcnArgs &a = g.p[pi];
+    const DcnArgs a = g.p[pi];       // (by value: one burst of wide scalar loads instead of ~17 dependent reloads before the loop)
     bid -= g.first[pi];
     int split, cb;
     if (a.xsx && !(FUSE && a.offsOnly)) {
@@ -586,7 +586,7 @@ __global__ __launch_bounds__(256) void dcn_persist_kernel(DcnPersist g)
 #pragma unroll
     for (int i = 1; i < DCN_MAX_GROUP; ++i)
         if (i < g.n && bid >= g.first[i]) pi = i;
-    const DcnArgs &a = g.p[pi];
+    const DcnArgs a = g.p[pi];       // (by value: bursts of wide scalar loads instead of dependent reloads)
     bid -= g.first[pi];
     const int per = g.per_col[pi];
     const int col = bid / per;
@@ -1047,7 +1047,7 @@ __global__ __launch_bounds__(256) void dcn_reduce_kernel(RedGroup g)
 #pragma unroll
     for (int i = 1; i < DCN_MAX_GROUP; ++i)
         if (i < g.n && bid >= g.first[i]) pi = i;
-    const RedArgs &r = g.p[pi];
+    const RedArgs r = g.p[pi];
     const EpiArgs &e = r.e;
     bid -= g.first[pi];
     const int row = bid / r.rowBlocks;                    // (scalar)

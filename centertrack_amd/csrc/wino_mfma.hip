@@ -569,7 +569,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4))) void w
 #pragma unroll
     for (int i = 1; i < 4; ++i)
         if (i < g.n && bid >= g.first[i]) pi = i;
-    const WinoArgs &a = g.p[pi];
+    const WinoArgs a = g.p[pi];       // (by value: bursts of wide scalar loads instead of dependent reloads)
     bid -= g.first[pi];
     const int tiles = g.tiles[pi];
     const int sx = g.sx[pi], sper = (a.Cin >> 6) / sx;

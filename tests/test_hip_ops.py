@@ -705,6 +705,31 @@ def test_dcn_persistent_launch_is_bit_identical(device, palgo, algo, slots):
         assert torch.equal(res[palgo][i], res[algo][i]), 'layer %d: persistent vs one workgroup per tile' % i
 
 
+@pytest.mark.parametrize('N,H,W,Cin,Cout,split_k,algo', [(2, 7, 19, 64, 96, 1, 3264), (1, 4, 4, 512, 256, 8, 3264), (3, 9, 21, 256, 128, 2, 32128),
+                                                       (1, 12, 40, 192, 64, 3, 3264), (2, 16, 16, 128, 64, 4, 64)])
+def test_dcn_xcd_aware_order_changes_no_value(device, N, H, W, Cin, Cout, split_k, algo):
+    """the XCD-aware workgroup order of the MAIN launch (round 6, knob "dcn_xcd": K splits and bands of pixel tiles per XCD, id range
+    padded to a multiple of 8) decides which workgroup computes which tile and nothing else: results equal the plain order bit for
+    bit -- odd split counts, fewer tiles than XCDs, several images"""
+    from centertrack_amd import _lib, ops
+    lib = _lib.load()
+    x = ops.view_from_nchw(_rand(N, Cin, H, W, seed=711).to(device))
+    w = ops.pack_weight(_rand(Cout, Cin, 3, 3, seed=712, scale=(Cin * 9) ** -0.5).to(device))
+    om = torch.zeros(N, H, W, 32)
+    om[..., :18] = _rand(N, H, W, 18, seed=713, scale=1.5)
+    om[..., 18:27] = torch.sigmoid(_rand(N, H, W, 9, seed=714))
+    omv = ops.View(om.to(device), 0, 27)
+    got = {}
+    try:
+        for x_on in (1, 0):
+            assert lib.ct_set_tuning(b'dcn_xcd', x_on) == 0
+            got[x_on] = ops.dcn_v2(x, omv, w, Cout, relu=True, split_k=split_k, algo=algo).to_nchw().clone()
+    finally:
+        lib.ct_set_tuning(b'dcn_xcd', 1)
+    assert torch.equal(got[0], got[1])
+    assert got[1].abs().sum() > 0
+
+
 def test_dcn_persistent_argument_errors(device):
     """shapes the persistent launch cannot run are refused before anything is launched"""
     import ctypes
