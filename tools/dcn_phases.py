@@ -106,6 +106,13 @@ def main():
             s = st[st[:, 8] == j]
             if not len(s):
                 continue
+            # first round (workgroups the dispatcher started with the launch) against the later ones: cold against warm
+            # instruction cache, everybody in phase against staggered
+            early = (s[:, 0] - rt0.min()) * 10e-3 < 3.0
+            for tag, sel in (('first round', early), ('later     ', ~early)):
+                if sel.any() and (~sel).any():
+                    php = np.diff(s[sel][:, 1:7], axis=1).mean(axis=0)
+                    print('    %s %4d WGs: clk ' % (tag, sel.sum()) + ', '.join('%s %.0f' % (n, v) for n, v in zip(names, php)))
             ph = np.diff(s[:, 1:7], axis=1)
             tot = s[:, 6] - s[:, 1]
             steps = s[:, 9].mean()
