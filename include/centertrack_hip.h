@@ -38,7 +38,9 @@ extern "C" {
  * binding compares it with ct_version() of the loaded library before the first descriptor call (centertrack_amd/_lib.py
  * does).  100 = rounds 1-3; 101 = ct_conv_desc.proj_* (fused Tree.project), key "stem_rows", box probes;
  * 102 = ct_decode_desc.sparse (sparse heads); 103 = the ct_calib_* box probes left this header and the library (they are
- * diagnostics of the measuring box: tools/micro/probes.hip -> tools/micro/libct_probes.so). */
+ * diagnostics of the measuring box: tools/micro/probes.hip -> tools/micro/libct_probes.so; ct_dcn_desc.w_off_winograd).
+ * Added under 103 without a layout change: ct_dcn_desc.algo 53264 / 532128 / 63264 / 632128 (persistent DCN launch), the
+ * tuning keys "dcn_slots" and "dcn_xcd". */
 #define CT_ABI_VERSION 103
 
 const char *ct_last_error(void);
