@@ -466,7 +466,13 @@ __device__ __forceinline__ void wino_body(const WinoArgs &a, int bid, const unsi
                     f32x4 o;
 #pragma unroll
                     for (int i = 0; i < 4; ++i) o[i] = ct_epilogue_plain(a.epi, raw[i], sc4[i], sh4[i], r4[i]);
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, vo_y, so_y, 0);
+                    // (the block offset goes into the VECTOR offset, the scalar offset stays the constant 0: hipcc pads the
+                    //  "VALU overwrites the data registers of a store wider than 64 bits" hazard only for stores WITHOUT a scalar
+                    //  offset register -- the published exemption -- and gfx950 does not honour the exemption: with `so_y` in the
+                    //  scalar field the Winograd OFFSETS kernel stored `2 | pp` (the next instruction's result) instead of o[0]
+                    //  in lanes 12-15 of every 16, once per ~15 launches of a 4-stream plan; tools/determinism.py,
+                    //  profiles/r06_an_store_hazard.txt, tests/test_hip_determinism.py)
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), yrs, vo_y + so_y, 0, 0);
                 }
             } else if (co < a.epi.Cout) {
                 const float sc = a.epi.scale ? a.epi.scale[co] : 1.0f;

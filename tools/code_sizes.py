@@ -38,7 +38,7 @@ def kernels_of(obj, tmp):
     fb = os.path.join(tmp, os.path.basename(obj) + '.fb')
     co = os.path.join(tmp, os.path.basename(obj) + '.co')
     try:
-        sh(LLVM + '/llvm-objcopy', '--dump-section', '.hip_fatbin=' + fb, obj)
+        sh(LLVM + '/llvm-objcopy', '--dump-section', '.hip_fatbin=' + fb, obj, fb + '.copy')     # (an explicit output: without one objcopy rewrites `obj` in place and the build takes it for fresh)
     except subprocess.CalledProcessError:
         return []
     if not os.path.exists(fb) or os.path.getsize(fb) == 0:
