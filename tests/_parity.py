@@ -19,7 +19,9 @@ north_star's bar, as asserted here:
     per 1000 frames and what the HIP path does when they do (profiles/r03_tie_report.json);
   * track IDs: a consistent bijection oracle-id <-> our-id over the WHOLE stream that is the identity, except for ids
     handed out inside one birth tie group (new ids are numbered in rank order, tracker.py:104-111, so a tie swap of
-    two births swaps their ids for the rest of the stream).  Every non-identity pair is enumerated and must be
+    two births swaps their ids for the rest of the stream) and for two results of one rank-tie group that exchange
+    their ids (greedy association serves detections in score order, tracker.py:56-76: which of two tied detections
+    takes a track both can reach follows their rank swap).  Every non-identity pair is enumerated and must be
     explained by such a tie; ``strict`` demands the identity.
 """
 import numpy as np
@@ -54,6 +56,7 @@ class StreamParity(object):
         # 1e-5 .. rank_tie apart): tolerated one by one, but COUNTED -- a decode that mis-orders close scores
         # systematically would swap in every frame, fp32 noise does in < 1 % of them (advisor, round 4)
         self.wide_swaps = []
+        self.exchanges = []         # (frame, oracle id, oracle id): ids exchanged between two results of one rank-tie group
 
     @staticmethod
     def _key(d, b, i):
@@ -109,6 +112,7 @@ class StreamParity(object):
         tol = ATOL * px_per_cell * 2 + 2e-3      # 1e-3 of a cell on either edge of a box / point pair + fp32 slack
         gbox = np.array([np.asarray(r['bbox'], np.float64) for r in got]).reshape(-1, 4)
         used = set()
+        pairs = []
         for rw in want:
             wb = np.asarray(rw['bbox'], np.float64)
             cand = [i for i in range(len(got)) if i not in used and int(got[i]['class']) == int(rw['class'])
@@ -116,6 +120,7 @@ class StreamParity(object):
             assert len(cand) == 1, '%s: oracle result %s has %d counterparts within %.1e px' % (tag, wb, len(cand), tol)
             rg = got[cand[0]]
             used.add(cand[0])
+            pairs.append((rw, rg))
             np.testing.assert_allclose(float(rg['score']), float(np.asarray(rw['score'])), atol=ATOL)
             for k in ('ct', 'tracking'):
                 np.testing.assert_allclose(np.asarray(rg[k], np.float64), np.asarray(rw[k], np.float64), atol=tol,
@@ -126,15 +131,38 @@ class StreamParity(object):
                     np.testing.assert_allclose(np.asarray(rg[k], np.float64).reshape(-1),
                                                np.asarray(rw[k], np.float64).reshape(-1), rtol=2e-3, atol=2e-3,
                                                err_msg='%s %s' % (tag, k))
+
+        def tied_group(r):
+            """index of the rank-tie group (> 1 member) the detection behind oracle result ``r`` sits in, else None"""
+            hit = np.nonzero(sc[:n] == np.float32(np.asarray(r['score'])))[0]
+            if not len(hit) or self._key(od, 0, int(hit[0])) not in tied_keys:
+                return None
+            return next(gi for gi, (a, b) in enumerate(groups) if a <= int(hit[0]) < b)
+
+        for rw, rg in pairs:
             wid, gid = int(rw['tracking_id']), int(rg['tracking_id'])
-            if wid not in self.id_map:                             # a birth (or the first sighting of an id)
-                assert gid not in self.rev, '%s: our id %d already stands for oracle id %d' % (tag, gid, self.rev.get(gid))
+            if wid in self.id_map and self.id_map[wid] == gid:
+                continue
+            if wid not in self.id_map and gid not in self.rev:      # a birth (or the first sighting of an id)
                 self.id_map[wid], self.rev[gid] = gid, wid
-                hit = np.nonzero(sc[:n] == np.float32(np.asarray(rw['score'])))[0]
-                # born this frame from the detection at oracle rank hit[0]: inside a tie group?
-                if len(hit) and self._key(od, 0, int(hit[0])) in tied_keys:
+                # born this frame from a detection inside a tie group?
+                if tied_group(rw) is not None:
                     self.tie_ids.add(wid)
-            assert self.id_map[wid] == gid, '%s: oracle track %d is our track %d, was %d' % (tag, wid, gid, self.id_map[wid])
+                continue
+            # Two results of ONE rank-tie group exchanged their ids: greedy association (tracker.py:56-76) serves the detections in
+            # score order, so which of two tied detections takes a track both can reach -- and which one is born, or takes the
+            # second-best track -- follows their rank swap (round 6: once in 1760 frames, profiles/r06_tie_report.json).  The other
+            # result of the exchange is the one that carries the id this one was expected to carry.
+            other = [(w2, g2) for w2, g2 in pairs if w2 is not rw and
+                     (int(g2['tracking_id']) == self.id_map[wid] if wid in self.id_map else int(w2['tracking_id']) == self.rev[gid])]
+            gi = tied_group(rw)
+            assert len(other) == 1 and gi is not None and tied_group(other[0][0]) == gi, (
+                '%s: oracle track %d is our track %d, was %s -- and no rank tie explains it' % (tag, wid, gid, self.id_map.get(wid)))
+            w2, g2 = int(other[0][0]['tracking_id']), int(other[0][1]['tracking_id'])
+            for w_, g_ in ((wid, gid), (w2, g2)):
+                self.id_map[w_], self.rev[g_] = g_, w_
+            self.tie_ids.update((wid, w2))
+            self.exchanges.append((t, wid, w2))
         self.frames += 1
         self.detections += len(want)
         return True

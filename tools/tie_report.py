@@ -16,6 +16,12 @@ trajectory (tracker state, prior heat-map), and frame by frame the tool records
     boundary (470.00000 vs 469.99997 -> the blob moves one pixel).  The next frame's scores then differ by up to ~1e-2
     around that object without any detection or id changing; score / box deltas are therefore reported separately for
     the frames that follow such a flip and for all others,
+  * peak ties (round 6): a detection above the threshold on one side only whose counterpart sits on a NEIGHBOURING cell with the same
+    score (two adjacent heat-map values within fp32 noise: the 3x3 NMS keeps one of them) -- one object located one cell apart, not
+    two threshold flips,
+  * id exchanges inside a rank-tie group (round 6): two results whose oracle scores lie < 1e-5 apart carry each other's ids -- greedy
+    association serves detections in score order (tracker.py:56-76), so which of them takes a track both can reach follows their rank
+    swap; the stream is compared on with the two ids exchanged,
   * ids: the oracle-id <-> hip-id map must stay a bijection; the first frame where it breaks (or where the result lists
     differ in length) is the stream's *id divergence*; its cause is classified (threshold flip this frame or earlier /
     unexplained) and the stream is not compared beyond it (the two trajectories differ from there on).
@@ -149,6 +155,8 @@ class Acc(object):
         self.prior_flips = []                 # |oracle score - pre_thresh| of tracked objects rendered on one side only
         self.dscore_after, self.dbox_after = [], []      # deltas in the frames right after such a flip
         self.frames_after = 0
+        self.peak_ties = []                   # |score difference| of objects whose heat-map peak sits one cell apart on the two sides
+        self.assoc_exchanges = []             # oracle score gap of two results of one rank-tie group that exchanged their ids
 
     def report(self):
         per_k = 1000.0 / max(self.frames, 1)
@@ -170,6 +178,16 @@ class Acc(object):
                                                for k, v in self.exposure.items()},
             'threshold_flips': {'count': len(self.flips), 'per_1000_frames': round(len(self.flips) * per_k, 2),
                                 'max_oracle_distance_from_threshold': float(max(f[0] for f in self.flips)) if self.flips else 0.0},
+            # (round 6) an object whose peak falls on NEIGHBOURING cells on the two sides -- two adjacent heat-map values within fp32
+            # noise of each other, the 3x3 NMS (decode.py:83-97 / utils.py:16-21) keeps one of them: counted here, not as two threshold flips
+            'peak_ties': {'count': len(self.peak_ties), 'per_1000_frames': round(len(self.peak_ties) * per_k, 2),
+                          'max_abs_score_difference': float(max(self.peak_ties)) if self.peak_ties else 0.0},
+            # (round 6) two results of ONE rank-tie group (oracle scores < 1e-5 apart) whose ids are exchanged: greedy association
+            # (tracker.py:56-76) serves detections in score order, so which of the two takes a track both can reach -- and which is
+            # born -- follows the rank swap.  The stream is compared on, with the two ids exchanged
+            'id_exchanges_inside_a_rank_tie_group': {'count': len(self.assoc_exchanges),
+                                                     'per_1000_frames': round(len(self.assoc_exchanges) * per_k, 2),
+                                                     'max_oracle_score_gap': float(max(self.assoc_exchanges)) if self.assoc_exchanges else 0.0},
             'streams': self.streams, 'streams_with_id_divergence': self.diverged,
             'streams_with_ids_permuted_by_a_birth_tie': self.id_permuted_streams,
             'frames_until_first_id_divergence': self.first_divergence,
@@ -201,6 +219,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
     """ours / ref: per frame (decode arrays, slim results).  Updates every accumulator in ``accs``."""
     id_map, rev = {}, {}
     flipped = False
+    peak_seen = False                         # an object located one cell apart on the two sides (their boxes differ by a cell from there on)
     after_prior_flip = False                  # the previous frame rendered different prior heat-maps on the two sides
     for a in accs:
         a.streams += 1
@@ -250,6 +269,19 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
         only_o = [k for k in ko if k not in pos_g]
         only_g = [k for k in kg if k not in pos_o]
         all_g = {key: i for i, key in enumerate(_keys(gd, len(sg)))}
+        peak = False
+        for k in list(only_o):
+            near = [q for q in only_g if q[0] == k[0] and abs(q[1] - k[1]) <= 1 and abs(q[2] - k[2]) <= 1
+                    and abs(float(sg[pos_g[q]]) - float(so[pos_o[k]])) < 2 * TIE]
+            if near:
+                q = near[0]
+                only_o.remove(k)
+                only_g.remove(q)
+                peak = True
+                for a in accs:
+                    a.peak_ties.append(abs(float(sg[pos_g[q]]) - float(so[pos_o[k]])))
+                    a.events.append({'stream': tag, 'frame': t, 'event': 'peak_tie', 'oracle_key': list(k), 'hip_key': list(q),
+                                     'oracle_score': float(so[pos_o[k]]), 'hip_score': float(sg[pos_g[q]])})
         for k in only_o:
             j = all_g.get(k)
             for a in accs:
@@ -268,6 +300,8 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
                                  'threshold': out_thresh})
         if only_o or only_g:
             flipped = True
+        if peak:
+            peak_seen = True
         # ids: bijection over the stream (results matched by class + box)
         broken = None
         if len(got) != len(want):
@@ -275,6 +309,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
         else:
             used = set()
             gb = np.array([r['bbox'] for r in got], np.float64).reshape(-1, 4)
+            pairs = []
             for rw in want:
                 wb = np.array(rw['bbox'], np.float64)
                 cand = [i for i in range(len(got)) if i not in used and got[i]['class'] == rw['class']
@@ -283,18 +318,34 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
                     broken = 'oracle result %s has %d counterparts' % (rw['bbox'], len(cand))
                     break
                 used.add(cand[0])
-                wid, gid = rw['id'], got[cand[0]]['id']
-                if pre_thresh is not None and meta is None and rw['active'] and got[cand[0]]['active'] and \
-                        (rw['score'] >= pre_thresh) != (got[cand[0]]['score'] >= pre_thresh):
+                pairs.append((rw, got[cand[0]]))
+            for rw, rg in (pairs if broken is None else []):
+                wid, gid = rw['id'], rg['id']
+                if pre_thresh is not None and meta is None and rw['active'] and rg['active'] and \
+                        (rw['score'] >= pre_thresh) != (rg['score'] >= pre_thresh):
                     # rendered into the next frame's prior heat-map on one side only (detector.py:262)
                     after_prior_flip = True
                     for a in accs:
                         a.prior_flips.append(abs(rw['score'] - pre_thresh))
                         a.events.append({'stream': tag, 'frame': t, 'event': 'prior_heatmap_flip', 'oracle_score': rw['score'],
-                                         'hip_score': got[cand[0]]['score'], 'pre_thresh': pre_thresh})
+                                         'hip_score': rg['score'], 'pre_thresh': pre_thresh})
                 if wid not in id_map and gid not in rev:
                     id_map[wid], rev[gid] = gid, wid
                 if id_map.get(wid) != gid:
+                    # the other result of the exchange: the one that now carries the id this one was expected to have (or, when this
+                    # one was born on the oracle's side, the oracle result our id stands for)
+                    other = [(w2, g2) for w2, g2 in pairs if (w2 is not rw) and
+                             (g2['id'] == id_map.get(wid) if wid in id_map else w2['id'] == rev.get(gid))]
+                    if len(other) == 1 and abs(other[0][0]['score'] - rw['score']) < TIE:
+                        w2, g2 = other[0]
+                        for a in accs:
+                            a.assoc_exchanges.append(abs(w2['score'] - rw['score']))
+                            a.events.append({'stream': tag, 'frame': t, 'event': 'id_exchange_in_rank_tie_group',
+                                             'oracle_ids': [wid, w2['id']], 'hip_ids': [gid, g2['id']],
+                                             'oracle_scores': [rw['score'], w2['score']], 'hip_scores': [rg['score'], g2['score']]})
+                        for w_, g_ in ((wid, gid), (w2['id'], g2['id'])):
+                            id_map[w_], rev[g_] = g_, w_
+                        continue
                     broken = 'oracle track %d is hip track %d (was %s)' % (wid, gid, id_map.get(wid))
                     break
         if pre_thresh is not None and meta is not None and broken is None:
@@ -313,7 +364,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
             if t > 0:
                 prev = ref[t - 1][0]['scores'].astype(np.float64)
                 near_pre = bool(min(np.abs(prev - th).min() for th in thresholds) < 10 * TIE)
-            cause = 'threshold_flip' if (flipped or near_pre) else 'unexplained'
+            cause = 'peak_tie' if (peak_seen and not flipped) else ('threshold_flip' if (flipped or near_pre) else 'unexplained')
             for a in accs:
                 a.diverged += 1
                 a.first_divergence.append(t)
@@ -328,7 +379,7 @@ def compare_stream(tag, ours, ref, out_thresh, thresholds, accs, box_tol=0.05, p
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r05_tie_report.json'))
+    ap.add_argument('--out', default=os.path.join(ROOT, 'profiles', 'r06_tie_report.json'))
     ap.add_argument('--quick', action='store_true', help='a few frames (plumbing check)')
     ap.add_argument('--mot-runs', type=int, default=0, help='runs of the headline plan (32 frames each); 0 = the PLAN default')
     ap.add_argument('--workers', type=int, default=0)
