@@ -41,7 +41,7 @@ def poison_free_memory(device, gib):
     del blocks
 
 
-def one_pass(name, streams, T, seed0, keep_heads, step_kw=None):
+def one_pass(name, streams, T, seed0, keep_heads, step_kw=None, sparse_heads=False):
     """T frames through a fresh model + StreamDetector; returns per-frame dicts {head: ndarray} / rows / result ids"""
     import scenarios as S
     from _parity import calibrated_state_dict, scrolled_stream
@@ -51,7 +51,7 @@ def one_pass(name, streams, T, seed0, keep_heads, step_kw=None):
     cfg = S.CONFIGS[name]
     heads = S.HEAD_SETS[cfg['heads']]
     H, W = cfg['H'], cfg['W']
-    opt = default_opt(heads, track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'])
+    opt = default_opt(heads, track_thresh=cfg['track_thresh'], pre_thresh=cfg['pre_thresh'], flip_test=cfg['flip'], sparse_heads=sparse_heads)
     model = DLASegHIP(heads)
     model.load_state_dict(calibrated_state_dict(name, heads))
     det = StreamDetector(opt, model=model, num_streams=streams)
@@ -217,6 +217,7 @@ def main():
     ap.add_argument('--passes', type=int, default=4)
     ap.add_argument('--poison', type=float, default=8.0, help='GiB of allocator pool filled with NaNs between passes')
     ap.add_argument('--no-heads', action='store_true')
+    ap.add_argument('--sparse-heads', action='store_true', help='stream passes with opt.sparse_heads (the opt-in mode)')
     a = ap.parse_args()
     cfgs = a.config or ['coco_512']
     strs = a.streams or [4] * len(cfgs)
@@ -227,10 +228,10 @@ def main():
         if a.model:
             rc |= 1 if model_mode(name, streams, a.model, a.graph) else 0
             continue
-        first = one_pass(name, streams, a.frames, 317 + 7, not a.no_heads)
+        first = one_pass(name, streams, a.frames, 317 + 7, not a.no_heads, sparse_heads=a.sparse_heads)
         for p in range(1, a.passes):
             poison_free_memory(dev, a.poison)
-            cur = one_pass(name, streams, a.frames, 317 + 7, not a.no_heads)
+            cur = one_pass(name, streams, a.frames, 317 + 7, not a.no_heads, sparse_heads=a.sparse_heads)
             d = diff_passes(first, cur)
             line = {'config': name, 'streams': streams, 'frames': a.frames, 'pass': p, 'identical': d is None}
             if d is not None:
