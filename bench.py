@@ -124,7 +124,7 @@ def kernel_pass(model, plan, reps=10):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _lib.capture_guard(collect=False), torch.cuda.graph(g):
             run()
         g.replay()
         torch.cuda.synchronize()

@@ -133,7 +133,7 @@ def _time_graph(fn, reps=REPS, pre=None):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g):
+    with _lib.capture_guard(collect=False), torch.cuda.graph(g):
         for _ in range(reps):
             fn()
     g.replay()

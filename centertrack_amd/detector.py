@@ -110,12 +110,12 @@ def imread_bgr(path):
 class _HipGraph(object):
     """One captured frame (ct_graph_begin / ct_graph_end); ``replay()`` enqueues it on the current stream."""
 
-    def __init__(self, fn):
+    def __init__(self, fn, collect=True):
         lib = _lib.load()
         side = torch.cuda.Stream()                 # (the legacy default stream cannot be captured)
         side.wait_stream(torch.cuda.current_stream())
         sp = ctypes.c_void_p(side.cuda_stream)
-        with torch.cuda.stream(side):
+        with _lib.capture_guard(collect=collect), torch.cuda.stream(side):
             _lib.check(lib.ct_graph_begin(sp), 'ct_graph_begin')
             try:
                 fn()
@@ -347,10 +347,10 @@ class StreamDetector(object):
                 raw = os.environ.get('CENTERTRACK_RAW_GRAPH', '1') != '0'
                 for sl in range(nslots):
                     if raw:
-                        g = _HipGraph(lambda: device_frame(sl, True))
+                        g = _HipGraph(lambda: device_frame(sl, True), collect=(sl == 0))      # (garbage is collected once, ahead of the first capture)
                     else:
                         g = torch.cuda.CUDAGraph()
-                        with torch.cuda.graph(g):
+                        with _lib.capture_guard(collect=False), torch.cuda.graph(g):
                             device_frame(sl)
                     ctx['graphs'][sl] = g
                 ctx['raw'] = raw

@@ -727,7 +727,7 @@ class DLASegHIP(torch.nn.Module):
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
+        with _lib.capture_guard(collect=False), torch.cuda.graph(g):
             for _ in range(reps):
                 self._run_plan(plan)
         g.replay()
