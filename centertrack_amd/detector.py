@@ -193,6 +193,11 @@ class StreamDetector(object):
         try:
             ctx = self._ctx
             if ctx is not None and ctx.get('loop') is not None:
+                # (collected while the current stream is capturing -- somebody else's graph: waiting for the device here would
+                #  invalidate that capture; the native loop is leaked instead.  The package's own captures keep the collector
+                #  out altogether, _lib.capture_guard)
+                if os.environ.get('CT_NO_CAPTURE_GUARD') != '1' and torch.cuda.is_current_stream_capturing():
+                    return
                 torch.cuda.synchronize()
                 _lib.load().ct_frame_loop_destroy(ctx['loop'])      # (joins its helper threads)
                 ctx['loop'] = None
