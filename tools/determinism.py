@@ -12,7 +12,6 @@ prints one JSON line per (config, pass): first differing frame, the differing he
 differing rows; exit status 1 if any pass differs.  tests/test_hip_determinism.py runs the same comparison in the GPU suite.
 """
 import argparse
-import hashlib
 import json
 import os
 import sys
@@ -41,7 +40,7 @@ def poison_free_memory(device, gib):
     del blocks
 
 
-def one_pass(name, streams, T, seed0, keep_heads, step_kw=None, sparse_heads=False):
+def one_pass(name, streams, T, seed0, keep_heads, sparse_heads=False):
     """T frames through a fresh model + StreamDetector; returns per-frame dicts {head: ndarray} / rows / result ids"""
     import scenarios as S
     from _parity import calibrated_state_dict, scrolled_stream
