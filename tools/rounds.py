@@ -2,7 +2,13 @@
 """Whole-round arithmetic of the launches of one frame, from a `rocprofv3 --kernel-trace` CSV (output format csv:
 *_kernel_trace.csv carries grid, workgroup size, LDS and register counts of every dispatch): workgroups, workgroups
 resident per CU by registers and by LDS, rounds = workgroups / (256 x per CU), duration -- which launches run a full round
-plus a fraction.        python tools/rounds.py TRACE.csv [--frame -2] [--marker decode_stage2]"""
+plus a fraction.        python tools/rounds.py TRACE.csv [--frame -2] [--marker decode_stage2]
+
+Two properties of the tracer's columns on gfx950 (rocprofv3 of ROCm 7.2), calibrated against the code-object metadata (round 6):
+`VGPR_Count` is HALF the allocated registers of a wave (stem_kernel<16>: 249 in the code object, 128 in the trace; the multi-chunk
+Winograd shape 192 / 96) -- doubled here; `LDS_Block_Size` holds the static LDS only, so kernels with dynamic LDS (the Winograd shapes:
+27.6 KB per patch buffer, two of them in the multi-chunk shapes; the DCN kernels) are limited by LDS more than this table says: their
+`per CU` is an upper bound."""
 import argparse
 import csv
 import re
@@ -42,7 +48,7 @@ def main():
     for r in rows[s:e + 1]:
         thr = int(r['Workgroup_Size_X']) * int(r['Workgroup_Size_Y']) * int(r['Workgroup_Size_Z'])
         wgs = int(r['Grid_Size_X']) * int(r['Grid_Size_Y']) * int(r['Grid_Size_Z']) // max(thr, 1)
-        v, a, lds = int(r['VGPR_Count']), int(r['Accum_VGPR_Count']), int(r['LDS_Block_Size'])
+        v, a, lds = 2 * int(r['VGPR_Count']), 2 * int(r['Accum_VGPR_Count']), int(r['LDS_Block_Size'])
         pc, _ = per_cu(v, a, lds, thr)
         us = (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1000.0
         tot += us
