@@ -61,5 +61,8 @@ def test_benchmarked_plan_matches_oracle(device, name, streams, sample, T):
     assert sum(c.detections for c in checks) >= 10 * compared
     # the 5e-5 rank-tie width must stay an exception: order changes between scores 1e-5 .. 5e-5 apart are counted
     # (tools/tie_report.py: 8 per 1000 frames over all widths) -- a systematic mis-ordering would show in every frame
+    # ... and so must an id exchange inside a rank-tie group (tests/_parity.py; tools/tie_report.py met one in 1760 frames)
+    exchanged = [(c.tag,) + e for c in checks for e in c.exchanges]
+    assert len(exchanged) <= 1, 'ids exchanged inside rank-tie groups: %s' % (exchanged,)
     wide = [(c.tag,) + w for c in checks for w in c.wide_swaps]
     assert len(wide) <= max(2, compared // 8), 'rank swaps between scores 1e-5 .. 5e-5 apart: %s' % (wide,)
