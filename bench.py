@@ -93,48 +93,55 @@ def parse():
 
 
 def kernel_pass(model, plan, reps=10):
-    """Average duration of the DCN / conv launches of the plan: all launches of one kind are captured
-    back-to-back in a HIP graph and the replay is timed with HIP events on the launch stream (device time,
-    kernel boundaries included, host launch cost excluded -- the same thing rocprofv3's kernel trace sees)."""
+    """Average duration of the DCN / conv launches of the plan INSIDE the frame: the plan's launch list is cut where the kind of
+    launch changes (stem | backbone convs | the DCN block | heads), every part is captured as its own HIP graph, and whole frames
+    are replayed part by part with a HIP event between the parts -- device time of a part = kernel boundaries included, host launch
+    cost excluded, and every part runs on what the part before it left in the caches, as in the real frame (the same thing
+    rocprofv3's kernel trace of the frame sees; until round 6 each kind was replayed on its own, back to back, which made the DCN
+    figure of the 4-stream configurations depend on the allocator's state by up to 10 % while the frame itself did not change)."""
     import ctypes
     from centertrack_amd import _lib
     lib = _lib.load()
     stats = {}
+
+    def kind_of(l):
+        if l.fn == 'dcn_group' or l.name.endswith('.offset'):
+            return 'dcn'
+        return 'conv' if l.fn in ('conv', 'heads') else 'other'
+    parts = []
+    for l in plan['launches']:
+        k = kind_of(l)
+        if not parts or parts[-1][0] != k:
+            parts.append((k, []))
+        parts[-1][1].append(l)
     model._run_plan(plan)
     torch.cuda.synchronize()
-    for kind in ('dcn', 'conv'):
-        if kind == 'dcn':       # the grouped DCN launches (MAIN + FINISH) and the offset/mask convs of the un-fused layers
-            launches = [l for l in plan['launches'] if l.fn == 'dcn_group' or l.name.endswith('.offset')]
-        else:
-            launches = [l for l in plan['launches'] if l.fn in ('conv', 'heads') and not l.name.endswith('.offset')]
-
-        def run():
-            st = _lib.stream_ptr()
-            for l in launches:
-                if l.fn == 'dcn_group':
-                    lib.ct_dcn_v2_group(l.args[0], l.args[1], l.args[2], st)
-                elif l.fn == 'heads':
-                    lib.ct_heads_fused(ctypes.byref(l.args), st)
-                else:
-                    lib.ct_conv2d(ctypes.byref(l.args), st)
+    graphs = []
+    for k, ls in parts:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            run()
+            model._run_plan(plan, launches=ls)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
         with _lib.capture_guard(collect=False), torch.cuda.graph(g):
-            run()
-        g.replay()
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(reps):
+            model._run_plan(plan, launches=ls)
+        graphs.append(g)
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(len(parts) + 1)] for _ in range(reps + 1)]
+    for r in range(reps + 1):                  # (frame 0 warms up)
+        ev[r][0].record()
+        for i, g in enumerate(graphs):
             g.replay()
-        e1.record()
-        torch.cuda.synchronize()
-        ms = e0.elapsed_time(e1) / reps
+            ev[r][i + 1].record()
+    torch.cuda.synchronize()
+    part_ms = {'dcn': 0.0, 'conv': 0.0, 'other': 0.0}
+    for r in range(1, reps + 1):
+        for i, (k, _) in enumerate(parts):
+            part_ms[k] += ev[r][i].elapsed_time(ev[r][i + 1]) / reps
+    for kind in ('dcn', 'conv'):
+        launches = [l for l in plan['launches'] if kind_of(l) == kind]
+        ms = part_ms[kind]
         flops = flops_main = flops_exec = bytes_ = bytes_up = 0.0
         nlayers = 0
         for l in launches:

@@ -493,7 +493,7 @@ class DLASegHIP(torch.nn.Module):
         if rc != 0:
             _lib.check(rc, 'stem (x / pre_img terms)')
 
-    def _run_plan(self, plan, inputs=None, stem_partial=None):
+    def _run_plan(self, plan, inputs=None, stem_partial=None, launches=None):
         """Enqueue every launch of the plan on the current stream.  ``inputs`` = (x, pre_img, pre_hm) tensors to read
         instead of the plan's own static input buffers (a detector rotates its frame buffers so that the
         previous frame never has to be copied).  ``stem_partial``: NHWC view that already holds the x / pre_img terms
@@ -501,7 +501,7 @@ class DLASegHIP(torch.nn.Module):
         P = self._prepared
         lib = _lib.load()
         st = _lib.stream_ptr()
-        for l in plan['launches']:
+        for l in (plan['launches'] if launches is None else launches):      # (``launches``: a contiguous part of the plan, bench.py)
             if l.fn == 'conv':
                 rc = lib.ct_conv2d(ctypes.byref(l.args), st)
             elif l.fn == 'dcn_group':
