@@ -564,6 +564,8 @@ def measure(args, env, headline=True):
                                'frac': round(tf / PEAK_FP32_TFLOPS, 4),
                                'frac_main': round(tf_main / PEAK_FP32_TFLOPS, 4),      # main contraction only
                                'traffic': None, 'traffic_source': None,
+                               'method': 'HIP events between the parts of the frame -- stem | backbone | DCN block | heads, each a graph, whole frames '
+                                         'replayed in order: in-frame device time of the DCN block, its kernel boundaries included',
                                'avg_launch_us': round(1000.0 * d['ms'] / nl, 2),
                                'hbm': {'achieved': round(gbs, 1), 'peak': PEAK_HBM_GBS, 'unit': 'GB/s',
                                        'frac': round(gbs / PEAK_HBM_GBS, 4),
